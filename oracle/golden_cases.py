@@ -1,0 +1,76 @@
+"""Case tables shared by oracle/gen_golden.py (which runs the REFERENCE) and the tests (which run
+the oracle and the HIP path against the stored vectors).  Test infrastructure only."""
+
+# torch ("parametrized") semantics -- each case is one ParametrizedProcessing configuration.
+#   shape      (B,H,W) of the raw batch
+#   kind       synthetic distribution (oracle.isp_oracle.synth_raw)
+#   camera     'drone' | 'microscopy' | 'identity'
+#   bn         batch_norm_output
+#   training   module in train() mode (batch statistics) or eval() (running statistics)
+#   track      track_stages (adds the YUV->RGB->YUV round trip and the 'sharpening' stage)
+#   additive   append_additive_layer (requires 256x256 frames)
+#   perturb    seed for non-default weights (None = reference defaults)
+#   full       store full tensors (False: strided samples only, for the large 256x256 case)
+PARAM_CASES = [
+    dict(name='drone_bn_train', seed=0, shape=(2, 16, 16), kind='scene', camera='drone',
+         bn=True, training=True, track=False, additive=False, perturb=None),
+    dict(name='drone_bn_train_track', seed=1, shape=(2, 16, 16), kind='scene', camera='drone',
+         bn=True, training=True, track=True, additive=False, perturb=None),
+    dict(name='drone_nobn', seed=2, shape=(2, 16, 16), kind='uniform', camera='drone',
+         bn=False, training=True, track=False, additive=False, perturb=None),
+    dict(name='drone_bn_eval', seed=0, shape=(2, 16, 16), kind='scene', camera='drone',
+         bn=True, training=False, track=False, additive=False, perturb=None),
+    dict(name='micro_bn_train', seed=1, shape=(1, 64, 64), kind='scene', camera='microscopy',
+         bn=True, training=True, track=False, additive=False, perturb=None),
+    dict(name='micro_nobn_track', seed=2, shape=(1, 64, 64), kind='uniform', camera='microscopy',
+         bn=False, training=True, track=True, additive=False, perturb=None),
+    dict(name='identity_bn_train', seed=0, shape=(1, 64, 64), kind='uniform', camera='identity',
+         bn=True, training=True, track=False, additive=False, perturb=None),
+    dict(name='drone_perturbed_bn_train', seed=3, shape=(2, 32, 48), kind='scene', camera='drone',
+         bn=True, training=True, track=False, additive=False, perturb=11),
+    dict(name='drone_perturbed_nobn', seed=4, shape=(3, 20, 36), kind='uniform', camera='drone',
+         bn=False, training=True, track=False, additive=False, perturb=12),
+    dict(name='drone_perturbed_track', seed=5, shape=(2, 24, 24), kind='scene', camera='drone',
+         bn=True, training=True, track=True, additive=False, perturb=13),
+    dict(name='drone_dark_nobn', seed=6, shape=(1, 32, 32), kind='dark', camera='drone',
+         bn=False, training=True, track=False, additive=False, perturb=None),
+    dict(name='drone_ragged_tile', seed=7, shape=(1, 70, 134), kind='scene', camera='drone',
+         bn=True, training=True, track=False, additive=False, perturb=14),
+    dict(name='tiny_4x4', seed=8, shape=(2, 4, 4), kind='uniform', camera='drone',
+         bn=True, training=True, track=False, additive=False, perturb=15),
+    dict(name='drone_additive_bn', seed=9, shape=(2, 256, 256), kind='scene', camera='drone',
+         bn=True, training=True, track=False, additive=True, perturb=16, full=False),
+    dict(name='drone_additive_nobn_track', seed=10, shape=(1, 256, 256), kind='scene',
+         camera='drone', bn=False, training=True, track=True, additive=True, perturb=17,
+         full=False),
+]
+
+SAMPLE_STRIDE = 8          # 'full=False' cases store [..., ::8, ::8] samples (+ f64 sums)
+
+# raw2rgb (pipeline_torch.py:240-283): all (reduce_size, out_channels) combinations
+RAW2RGB_CASES = [(True, 3), (True, 4), (False, 3), (False, 4)]
+
+# numpy ("static") semantics -- processing() (pipeline_numpy.py:70-141)
+STATIC_CASES = [
+    dict(name='drone_default_chain', seed=0, shape=(2, 32, 32), kind='scene', camera='drone',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='drone_default_chain_uniform', seed=1, shape=(1, 32, 48), kind='uniform',
+         camera='drone', debayer='bilinear', sharpening='sharpening_filter',
+         denoising='gaussian_denoising'),
+    dict(name='drone_short_chain', seed=2, shape=(2, 32, 32), kind='scene', camera='drone',
+         debayer='bilinear', sharpening='none', denoising='none'),
+    dict(name='drone_short_chain_dark', seed=3, shape=(1, 32, 32), kind='dark', camera='drone',
+         debayer='bilinear', sharpening='none', denoising='none'),
+    dict(name='micro_default_chain', seed=4, shape=(1, 32, 32), kind='scene', camera='microscopy',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='drone_malvar_chain', seed=5, shape=(1, 32, 32), kind='scene', camera='drone',
+         debayer='malvar2004', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='drone_malvar_short', seed=6, shape=(2, 24, 40), kind='uniform', camera='drone',
+         debayer='malvar2004', sharpening='none', denoising='none'),
+    dict(name='drone_median', seed=7, shape=(1, 32, 32), kind='scene', camera='drone',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='median_denoising'),
+    dict(name='drone_signature_default', seed=8, shape=(1, 16, 16), kind='scene', camera='drone',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='median_filter'),
+    dict(name='tiny_4x4', seed=9, shape=(1, 4, 4), kind='uniform', camera='drone',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+]
