@@ -1,0 +1,131 @@
+/* r2l_isp.h -- C ABI of libr2l_isp.so: the MI355X (gfx950) ISP hot path of raw2logit.
+ *
+ * The reference (aiaudit-org/raw2logit) is pure Python and has no FFI for this path: its boundary is
+ * the nn.Module API of processing/pipeline_torch.py and the callable API of
+ * processing/pipeline_numpy.py.  This header is the C boundary a maintainer binds underneath those
+ * modules (INTEGRATION.md shows the ctypes stub).  Each entry point names the reference code it
+ * replaces (path:line relative to the reference tree).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host;
+ *  - the caller owns every buffer; the library allocates no persistent device memory;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and returns;
+ *  - return value 0 = success, negative = error (r2l_last_error() gives the thread-local text);
+ *  - images are float32, raw is (B,H,W), RGB is (B,3,H,W) contiguous NCHW; H and W even, >= 4;
+ *  - no global mutable state: calls on different streams may run concurrently.
+ */
+#ifndef R2L_ISP_H
+#define R2L_ISP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R2L_ABI_VERSION 1
+
+/* ---- packed parameter block (device, float32[R2L_P_COUNT]) -----------------------------------
+ * The trainable parameters of ParametrizedProcessing (processing/pipeline_torch.py:152-166) in
+ * state_dict order, followed by the two registered buffers (:170-171).                           */
+enum {
+  R2L_P_BLACK_LEVEL = 0,   /* black_level            (4,)      R,G1,G2,B   :154 */
+  R2L_P_WHITE_BALANCE = 4, /* white_balance          (1,3)                 :155 */
+  R2L_P_CCM = 7,           /* colour_correction      (3,3) [k][c]          :156 */
+  R2L_P_GAMMA = 16,        /* gamma_correct          (1,)                  :158 */
+  R2L_P_DEBAYER = 17,      /* debayer.weight         (3,3,3,3) [k][c][i][j] :228-237 */
+  R2L_P_SHARPEN = 98,      /* sharpening_filter.weight (1,1,3,3)           :162-163 */
+  R2L_P_BLUR = 107,        /* gaussian_blur.weight   (1,1,5,5)             :165-166 */
+  R2L_P_NTRAIN = 132,      /* number of trainable scalars == length of grad_params */
+  R2L_P_M_RGB2YUV = 132,   /* buffer M_RGB_2_YUV (3,3)                     :170 */
+  R2L_P_M_YUV2RGB = 141,   /* buffer M_YUV_2_RGB (3,3)                     :171 */
+  R2L_P_COUNT = 150
+};
+
+/* flags for r2l_isp_fwd / r2l_isp_bwd */
+enum {
+  R2L_F_STATS_ONLY = 1, /* fwd: do not write `out`, only the BatchNorm partial sums */
+};
+
+/* static-pipeline selectors (processing/pipeline_numpy.py:92-122) */
+enum { R2L_DEBAYER_BILINEAR = 0, R2L_DEBAYER_MALVAR2004 = 1 };
+enum { R2L_SHARPEN_NONE = 0, R2L_SHARPEN_FILTER = 1 };
+enum { R2L_DENOISE_NONE = 0, R2L_DENOISE_GAUSSIAN = 1, R2L_DENOISE_MEDIAN = 2 };
+
+int r2l_abi_version(void);
+const char *r2l_last_error(void);
+
+/* 1 when the library runs on a GPU (libr2l_isp.so); 0 for the test-only host emulation of the same
+ * kernels (tests/_build/libr2l_emul.so), which the product loader refuses. */
+int r2l_is_device_build(void);
+
+/* ---- raw2rgb (processing/pipeline_torch.py:240-283; RawToRGB :43-80, NNProcessing front end :111)
+ * black_level: 4 floats (R,G1,G2,B) or NULL.  out: (B,out_channels,H,W) if !reduce_size (zero-filled
+ * mosaic) else (B,out_channels,H/2,W/2); out_channels in {3,4}.                                  */
+int r2l_raw2rgb_fwd(const float *raw, const float *black_level, float *out, int B, int H, int W,
+                    int reduce_size, int out_channels, void *stream);
+/* VJP: grad_raw (B,H,W) (or NULL) and grad_black_level double[4] (or NULL; needs workspace of
+ * r2l_raw2rgb_bwd_workspace_bytes()).                                                            */
+size_t r2l_raw2rgb_bwd_workspace_bytes(int B, int H, int W);
+int r2l_raw2rgb_bwd(const float *grad_out, float *grad_raw, double *grad_black_level, void *workspace,
+                    size_t workspace_bytes, int B, int H, int W, int reduce_size, int out_channels,
+                    void *stream);
+
+/* ---- fused parametrized ISP, torch semantics (ParametrizedProcessing.forward,
+ * processing/pipeline_torch.py:175-225 with track_stages=False):
+ *   black level + mosaic (:183) -> Debayer 3x3 mirror-pad conv (:187) -> white balance (:190) ->
+ *   CCM (:191) -> RGB->YUV (:194) -> sharpen Y 3x3 zero-pad (:195) -> blur Y 5x5 mirror-pad (:202) ->
+ *   YUV->RGB (:203) -> clip[1e-5,1] (:206) -> exp(log(x)/gamma) (:209) -> [+ additive_layer (:213)] ->
+ *   [BatchNorm2d(3, affine=False) normalisation (:217)]
+ * in ONE kernel: 4 B/px read, 12 B/px written.
+ *
+ *  params    float[R2L_P_COUNT]
+ *  additive  float[3*256*256] or NULL (requires H == W == 256, as in the reference :130)
+ *  bn_mean_istd  float[6] = mean[3], 1/sqrt(var+eps)[3] to apply, or NULL for no normalisation
+ *  out       (B,3,H,W), may be NULL with R2L_F_STATS_ONLY
+ *  stats     double[6] or NULL: receives sum_c(x-0.5)[3], sum_c((x-0.5)^2)[3] of the PRE-normalisation
+ *            output over this call's B*H*W pixels (the caller turns them into batch mean / biased
+ *            variance; with several GPUs it sums the vectors of all ranks first)
+ */
+size_t r2l_isp_workspace_bytes(int B, int H, int W);
+int r2l_isp_fwd(const float *raw, const float *params, const float *additive,
+                const float *bn_mean_istd, float *out, double *stats, void *workspace,
+                size_t workspace_bytes, int B, int H, int W, int flags, void *stream);
+
+/* BatchNorm backward reduction (nn.BatchNorm2d backward in train mode, :216-217):
+ * sums double[6] = sum_c(g)[3], sum_c(g*xhat)[3] with xhat == the saved forward output.          */
+int r2l_bn_bwd_reduce(const float *grad_out, const float *out, double *sums, void *workspace,
+                      size_t workspace_bytes, int B, int H, int W, void *stream);
+
+/* Backward of r2l_isp_fwd (what autograd computes for pipeline_torch.py:183-217), recomputing the
+ * forward from `raw`:
+ *  bn_mean_istd  float[6] as given to the forward (NULL: no BatchNorm)
+ *  bn_bwd        float[6] = mean_c(g)[3], mean_c(g*xhat)[3] over the GLOBAL batch (train mode), or NULL
+ *                (eval mode: only the 1/std scaling applies)
+ *  grad_params   float[R2L_P_NTRAIN], layout of the packed block
+ *  grad_raw      (B,H,W) or NULL
+ */
+int r2l_isp_bwd(const float *raw, const float *params, const float *additive,
+                const float *bn_mean_istd, const float *bn_bwd, const float *grad_out,
+                float *grad_params, float *grad_raw, void *workspace, size_t workspace_bytes, int B,
+                int H, int W, int flags, void *stream);
+
+/* gradient of the additive layer (:213): grad_additive[c,y,x] = sum_b d loss / d x[b,c,y,x], where the
+ * BatchNorm backward (if any) is applied on the fly from grad_out and the saved output.          */
+int r2l_additive_bwd(const float *grad_out, const float *out, const float *bn_mean_istd,
+                     const float *bn_bwd, float *grad_additive, int B, int H, int W, void *stream);
+
+/* ---- static pipeline, numpy semantics (processing(), processing/pipeline_numpy.py:70-141, batched):
+ * remove_blacklv (:152-158) -> demosaicing_CFA_Bayer_{bilinear,Malvar2004} (:92-95) -> wb (:161-162) ->
+ * CCM (:165-167) -> [sharpening_filter (:180-191)] -> [gaussian_denoising (:203-209)] -> clip[0,1] (:138)
+ * -> x**(1/gamma) (:241-244).  Linear part in float64 like the reference, output (B,3,H,W) float32
+ * (RawProcessingPipeline.__call__, :55-67).  camera_host: double[16] = black_level[4],
+ * white_balance[3], colour_matrix[9] (host memory).                                             */
+int r2l_static_fwd(const float *raw, float *out, int B, int H, int W, const double *camera_host,
+                   int debayer, int sharpening, int denoising, double gamma, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R2L_ISP_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of libr2l_isp.so (C ABI: include/r2l_isp.h).
+
+The product has exactly one compute path: the HIP kernels for gfx950.  If the shared library is
+missing, or a tensor is not on the GPU, every op raises -- there is no PyTorch / numpy fallback.
+
+The CPU-only test suite may register the HOST EMULATION of the same kernel source
+(tests/_build/libr2l_emul.so, built from tests/emul/r2l_emul.cpp) through
+``enable_test_emulation``; it then serves CPU tensors only, never CUDA tensors, and nothing in the
+package calls that hook."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, 'libr2l_isp.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+R2L_P_COUNT = 150
+R2L_P_NTRAIN = 132
+R2L_F_STATS_ONLY = 1
+
+_c_float_p = ctypes.c_void_p   # raw addresses from tensor.data_ptr()
+_SIGNATURES = {
+    'r2l_abi_version': (ctypes.c_int, []),
+    'r2l_last_error': (ctypes.c_char_p, []),
+    'r2l_is_device_build': (ctypes.c_int, []),
+    'r2l_raw2rgb_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_raw2rgb_bwd_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'r2l_raw2rgb_bwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_isp_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'r2l_isp_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_bn_bwd_reduce': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p]),
+    'r2l_isp_bwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                   _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_size_t,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p]),
+    'r2l_additive_bwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_static_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class R2LError(RuntimeError):
+    pass
+
+
+class Library:
+    def __init__(self, path, allow_emulation=False):
+        if not os.path.exists(path):
+            raise R2LError(
+                f'{path} not found: the HIP extension is not built. Run '
+                f'`python -c "import __graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950). '
+                f'raw2logit_amd has no CPU or PyTorch fallback.')
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)          # AttributeError if a declared symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        self.is_device = bool(self.cdll.r2l_is_device_build())
+        if not self.is_device and not allow_emulation:
+            raise R2LError(f'{path} is the test-only host emulation, not the gfx950 build')
+
+    def check(self, code, what):
+        if code != 0:
+            msg = self.cdll.r2l_last_error()
+            raise R2LError(f'{what} failed ({code}): {msg.decode() if msg else "?"}')
+
+    def __getattr__(self, name):
+        return getattr(self.cdll, name)
+
+
+_DEVICE_LIB = None
+_EMUL_LIB = None
+
+
+def device_library():
+    global _DEVICE_LIB
+    if _DEVICE_LIB is None:
+        _DEVICE_LIB = Library(LIB_PATH)
+    return _DEVICE_LIB
+
+
+def enable_test_emulation(path):
+    """TEST HOOK (tests/conftest.py only): serve CPU tensors with the host emulation of the kernels."""
+    global _EMUL_LIB
+    _EMUL_LIB = Library(path, allow_emulation=True) if path else None
+    return _EMUL_LIB
+
+
+def library_for(t):
+    """the library that may touch tensor `t`, plus the stream handle to enqueue on."""
+    if t.is_cuda:
+        lib = device_library()
+        return lib, ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if _EMUL_LIB is not None:
+        return _EMUL_LIB, ctypes.c_void_p(0)
+    raise R2LError('raw2logit_amd runs on MI355X only: the tensor is on the CPU and there is no CPU '
+                   'path (move it to the GPU: tensor.cuda())')
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def hipcc_command(out_path=LIB_PATH):
+    return ['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-shared', '-fPIC',
+            os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path]
+
+
+def build_device_library(verbose=True):
+    """compile libr2l_isp.so in-tree for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(REPO_ROOT, 'include', 'r2l_isp.h')]
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = hipcc_command()
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH

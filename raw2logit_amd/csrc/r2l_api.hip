@@ -1,0 +1,3 @@
+// r2l_api.hip -- libr2l_isp.so: the gfx950 build of the C ABI in include/r2l_isp.h.
+//   hipcc -O3 --offload-arch=gfx950 -shared -fPIC r2l_api.hip -o libr2l_isp.so
+#include "r2l_api_impl.h"

@@ -1,0 +1,317 @@
+// r2l_api_impl.h -- the C ABI of include/r2l_isp.h, written once.
+//
+// Included by r2l_api.hip (hipcc, gfx950: launches real kernels on a HIP stream) and by
+// tests/emul/r2l_emul.cpp (g++, R2L_EMUL: runs the same workgroup programs on host memory, for the
+// CPU-only test suite).
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "r2l_simple_kernels.h"
+#include "r2l_static_kernels.h"
+
+static thread_local std::string r2l_err;
+static int r2l_fail(int code, const std::string& msg) {
+  r2l_err = msg;
+  return code;
+}
+
+#ifdef R2L_EMUL
+#define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS)                         \
+  static int name(const ArgsT& a, int grid, void* stream) {                  \
+    (void)stream;                                                            \
+    std::vector<float> buf((size_t)(LDS_FLOATS) + 8);                        \
+    float* lds = (float*)(((uintptr_t)buf.data() + 15) & ~(uintptr_t)15);    \
+    for (int b = 0; b < grid; ++b) blockfn(a, b, grid, lds);                 \
+    return 0;                                                                \
+  }
+#else
+#define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS)                                           \
+  __global__ __launch_bounds__(R2L_NT) void name##_kernel(const ArgsT a) {                     \
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];                             \
+    blockfn(a, (int)blockIdx.x, (int)gridDim.x, lds);                                          \
+  }                                                                                            \
+  static int name(const ArgsT& a, int grid, void* stream) {                                    \
+    hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(R2L_NT), 0, (hipStream_t)stream, a);   \
+    const hipError_t e = hipGetLastError();                                                    \
+    if (e != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(e)); \
+    return 0;                                                                                  \
+  }
+#endif
+
+typedef R2LGeom<64, 64> GFwd;
+typedef R2LGeom<64, 64> GBwd1;
+typedef R2LGeom<64, 64> GBwd2;
+
+#define R2L_LDS3(G) (2 * G::PAD + 3 * G::PLANE)
+#define R2L_LDS4(G) (2 * G::PAD + 4 * G::PLANE)
+static_assert(R2L_LDS3(GFwd) >= R2L_RED_FLOATS, "reduction scratch must fit");
+static_assert(R2L_LDS4(GBwd2) >= R2L_RED_FLOATS, "reduction scratch must fit");
+
+R2L_KERNEL(r2l_launch_fold, R2LFoldArgs, r2l_fold_block, 4)
+R2L_KERNEL(r2l_launch_unfold, R2LUnfoldArgs, r2l_unfold_block, 4)
+R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 * R2L_NT)
+R2L_KERNEL(r2l_launch_fwd, R2LFwdArgs, r2l_fwd_block<GFwd>, R2L_LDS3(GFwd))
+R2L_KERNEL(r2l_launch_bwd1, R2LBwd1Args, r2l_bwd1_block<GBwd1>, R2L_LDS3(GBwd1))
+R2L_KERNEL(r2l_launch_bwd2, R2LBwd2Args, r2l_bwd2_block<GBwd2>, R2L_LDS4(GBwd2))
+R2L_KERNEL(r2l_launch_bn_reduce, R2LBnReduceArgs, r2l_bn_reduce_block, R2L_RED_FLOATS)
+R2L_KERNEL(r2l_launch_add_bwd, R2LAddBwdArgs, r2l_add_bwd_block, 4)
+R2L_KERNEL(r2l_launch_raw2rgb_fwd, R2LRaw2RgbArgs, r2l_raw2rgb_fwd_block, 4)
+R2L_KERNEL(r2l_launch_raw2rgb_bwd, R2LRaw2RgbArgs, r2l_raw2rgb_bwd_block, R2L_RED_FLOATS)
+R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L_STATIC_LDS_FLOATS)
+R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
+           R2L_STATIC_SHORT_LDS_FLOATS)
+
+// ---- grid sizing ------------------------------------------------------------------------------
+#define R2L_MAX_BLOCKS 1024
+static int r2l_env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  if (!s || !*s) return dflt;
+  const int v = atoi(s);
+  return v > 0 ? v : dflt;
+}
+// persistent tile-walking kernels: at most `cap` workgroups (256 CUs x resident workgroups per CU),
+// a multiple of 8 when possible so that the XCD-grouped walk applies
+static int r2l_tile_grid(int ntiles, int cap) {
+  if (cap > R2L_MAX_BLOCKS) cap = R2L_MAX_BLOCKS;
+  int g = ntiles < cap ? ntiles : cap;
+  if (g >= 8) g -= g % 8;
+  return g < 1 ? 1 : g;
+}
+
+// ---- workspace ----------------------------------------------------------------------------------
+struct R2LWorkspace {
+  R2LFolded* folded;
+  float* part_b1;
+  float* part_b2;
+  float* part_small;
+  double* sums;
+  float* gypp;
+  size_t total;
+};
+static size_t r2l_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+static R2LWorkspace r2l_carve(void* base, int B, int H, int W) {
+  R2LWorkspace w;
+  size_t off = 0;
+  char* p = (char*)base;
+  w.folded = (R2LFolded*)(p + off);
+  off += r2l_align_up(sizeof(R2LFolded));
+  w.part_b1 = (float*)(p + off);
+  off += r2l_align_up(sizeof(float) * R2L_B1_NACC * R2L_MAX_BLOCKS);
+  w.part_b2 = (float*)(p + off);
+  off += r2l_align_up(sizeof(float) * R2L_B2_NACC * R2L_MAX_BLOCKS);
+  w.part_small = (float*)(p + off);
+  off += r2l_align_up(sizeof(float) * 8 * R2L_MAX_BLOCKS);
+  w.sums = (double*)(p + off);
+  off += r2l_align_up(sizeof(double) * R2L_NSUMS);
+  w.gypp = (float*)(p + off);
+  off += r2l_align_up(sizeof(float) * (size_t)B * H * W);
+  w.total = off;
+  return w;
+}
+
+static int r2l_check_dims(int B, int H, int W) {
+  if (B < 1) return r2l_fail(-1, "B must be >= 1");
+  if (H < 4 || W < 4 || (H & 1) || (W & 1))
+    return r2l_fail(-1, "H and W must be even and >= 4 (Bayer quads; 5x5 mirror padding)");
+  if ((size_t)B * H * W > ((size_t)1 << 40)) return r2l_fail(-1, "batch too large");
+  return 0;
+}
+
+extern "C" {
+
+int r2l_abi_version(void) { return R2L_ABI_VERSION; }
+const char* r2l_last_error(void) { return r2l_err.c_str(); }
+int r2l_is_device_build(void) {
+#ifdef R2L_EMUL
+  return 0;
+#else
+  return 1;
+#endif
+}
+
+size_t r2l_isp_workspace_bytes(int B, int H, int W) {
+  if (B < 1 || H < 1 || W < 1) return 0;
+  return r2l_carve(nullptr, B, H, W).total;
+}
+
+int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
+                const float* bn_mean_istd, float* out, double* stats, void* workspace,
+                size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!raw || !params || !workspace) return r2l_fail(-1, "r2l_isp_fwd: null pointer");
+  if (additive && (H != 256 || W != 256))
+    return r2l_fail(-1, "additive_layer is (1,3,256,256): needs 256x256 frames");
+  const bool stats_only = (flags & R2L_F_STATS_ONLY) != 0;
+  if (stats_only) out = nullptr;
+  if (!out && !stats) return r2l_fail(-1, "r2l_isp_fwd: nothing to compute (no out, no stats)");
+  const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
+  if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_fwd: workspace too small");
+  R2LFoldArgs fa{params, ws.folded};
+  if (int e = r2l_launch_fold(fa, 1, stream)) return e;
+  const int ntiles = B * ((H + GFwd::TH - 1) / GFwd::TH) * ((W + GFwd::TW - 1) / GFwd::TW);
+  const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_FWD", 512));
+  R2LFwdArgs a;
+  a.raw = raw;
+  a.additive = additive;
+  a.F = ws.folded;
+  a.bn = bn_mean_istd;
+  a.out = out;
+  a.stat_partial = stats ? ws.part_small : nullptr;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  if (int e = r2l_launch_fwd(a, grid, stream)) return e;
+  if (stats) {
+    R2LReduceRowsArgs r{ws.part_small, stats, grid, 1.0};
+    if (int e = r2l_launch_reduce_rows(r, 6, stream)) return e;
+  }
+  return 0;
+}
+
+int r2l_bn_bwd_reduce(const float* grad_out, const float* out, double* sums, void* workspace,
+                      size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!grad_out || !out || !sums || !workspace) return r2l_fail(-1, "r2l_bn_bwd_reduce: null pointer");
+  const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
+  if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_bn_bwd_reduce: workspace too small");
+  const size_t hw = (size_t)H * W;
+  const size_t nitems = (size_t)3 * B * ((hw + R2L_SEG - 1) / R2L_SEG);
+  int grid = nitems < (size_t)R2L_MAX_BLOCKS ? (int)nitems : R2L_MAX_BLOCKS;
+  R2LBnReduceArgs a{grad_out, out, ws.part_small, B, H, W};
+  if (int e = r2l_launch_bn_reduce(a, grid, stream)) return e;
+  R2LReduceRowsArgs r{ws.part_small, sums, grid, 1.0};
+  return r2l_launch_reduce_rows(r, 6, stream);
+}
+
+int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
+                const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,
+                float* grad_params, float* grad_raw, void* workspace, size_t workspace_bytes, int B,
+                int H, int W, int flags, void* stream) {
+  (void)flags;
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!raw || !params || !grad_out || !grad_params || !workspace)
+    return r2l_fail(-1, "r2l_isp_bwd: null pointer");
+  if (bn_bwd && !bn_mean_istd) return r2l_fail(-1, "r2l_isp_bwd: bn_bwd given without bn_mean_istd");
+  if (additive && (H != 256 || W != 256))
+    return r2l_fail(-1, "additive_layer is (1,3,256,256): needs 256x256 frames");
+  if (grad_raw)
+    return r2l_fail(-3, "r2l_isp_bwd: grad_raw is produced by the staged path, not the fused kernels");
+  const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
+  if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_bwd: workspace too small");
+  R2LFoldArgs fa{params, ws.folded};
+  if (int e = r2l_launch_fold(fa, 1, stream)) return e;
+  const int ntiles = B * ((H + GBwd1::TH - 1) / GBwd1::TH) * ((W + GBwd1::TW - 1) / GBwd1::TW);
+  const int g1 = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_BWD1", 512));
+  R2LBwd1Args a1;
+  a1.raw = raw;
+  a1.additive = additive;
+  a1.F = ws.folded;
+  a1.bn = bn_mean_istd;
+  a1.bn_bwd = bn_bwd;
+  a1.gout = grad_out;
+  a1.gypp = ws.gypp;
+  a1.partial = ws.part_b1;
+  a1.B = B;
+  a1.H = H;
+  a1.W = W;
+  if (int e = r2l_launch_bwd1(a1, g1, stream)) return e;
+  const int ntiles2 = B * ((H + GBwd2::TH - 1) / GBwd2::TH) * ((W + GBwd2::TW - 1) / GBwd2::TW);
+  const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", 256));
+  R2LBwd2Args a2;
+  a2.raw = raw;
+  a2.F = ws.folded;
+  a2.gypp = ws.gypp;
+  a2.partial = ws.part_b2;
+  a2.B = B;
+  a2.H = H;
+  a2.W = W;
+  if (int e = r2l_launch_bwd2(a2, g2, stream)) return e;
+  R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0};
+  if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
+  R2LReduceRowsArgs r2{ws.part_b2, ws.sums + R2L_B1_NACC, g2, 1.0};
+  if (int e = r2l_launch_reduce_rows(r2, R2L_B2_NACC, stream)) return e;
+  R2LUnfoldArgs ua{params, ws.sums, grad_params};
+  return r2l_launch_unfold(ua, 1, stream);
+}
+
+int r2l_additive_bwd(const float* grad_out, const float* out, const float* bn_mean_istd,
+                     const float* bn_bwd, float* grad_additive, int B, int H, int W, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!grad_out || !grad_additive) return r2l_fail(-1, "r2l_additive_bwd: null pointer");
+  if (bn_mean_istd && !out) return r2l_fail(-1, "r2l_additive_bwd: BatchNorm needs the saved output");
+  R2LAddBwdArgs a{grad_out, out, bn_mean_istd, bn_bwd, grad_additive, B, H, W};
+  const size_t nchunk = (size_t)3 * H * W / 4;
+  int grid = (int)((nchunk + R2L_NT - 1) / R2L_NT);
+  if (grid > R2L_MAX_BLOCKS) grid = R2L_MAX_BLOCKS;
+  return r2l_launch_add_bwd(a, grid, stream);
+}
+
+int r2l_raw2rgb_fwd(const float* raw, const float* black_level, float* out, int B, int H, int W,
+                    int reduce_size, int out_channels, void* stream) {
+  if (B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return r2l_fail(-1, "raw2rgb: H and W must be even");
+  if (out_channels != 3 && out_channels != 4) return r2l_fail(-1, "raw2rgb: out_channels in {3,4}");
+  if (!raw || !out) return r2l_fail(-1, "raw2rgb: null pointer");
+  R2LRaw2RgbArgs a{raw, black_level, out, nullptr, nullptr, nullptr, B, H, W, reduce_size, out_channels};
+  const size_t nitems = (size_t)B * (H / 2) * ((W + 3) / 4);
+  size_t grid = (nitems + R2L_NT - 1) / R2L_NT;
+  if (grid > 4096) grid = 4096;
+  return r2l_launch_raw2rgb_fwd(a, (int)grid, stream);
+}
+
+size_t r2l_raw2rgb_bwd_workspace_bytes(int B, int H, int W) {
+  (void)B;
+  (void)H;
+  (void)W;
+  return sizeof(float) * 4 * R2L_MAX_BLOCKS;
+}
+
+int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_level, void* workspace,
+                    size_t workspace_bytes, int B, int H, int W, int reduce_size, int out_channels,
+                    void* stream) {
+  if (B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return r2l_fail(-1, "raw2rgb: H and W must be even");
+  if (out_channels != 3 && out_channels != 4) return r2l_fail(-1, "raw2rgb: out_channels in {3,4}");
+  if (!grad_out) return r2l_fail(-1, "raw2rgb_bwd: null pointer");
+  if (grad_black_level && (!workspace || workspace_bytes < r2l_raw2rgb_bwd_workspace_bytes(B, H, W)))
+    return r2l_fail(-2, "raw2rgb_bwd: workspace too small");
+  R2LRaw2RgbArgs a{nullptr, nullptr, nullptr, grad_out, grad_raw,
+                   grad_black_level ? (float*)workspace : nullptr, B, H, W, reduce_size, out_channels};
+  const size_t nitems = (size_t)B * (H / 2) * ((W + 3) / 4);
+  size_t grid = (nitems + R2L_NT - 1) / R2L_NT;
+  if (grid > R2L_MAX_BLOCKS) grid = R2L_MAX_BLOCKS;
+  if (int e = r2l_launch_raw2rgb_bwd(a, (int)grid, stream)) return e;
+  if (grad_black_level) {
+    R2LReduceRowsArgs r{(const float*)workspace, grad_black_level, (int)grid, 1.0};
+    return r2l_launch_reduce_rows(r, 4, stream);
+  }
+  return 0;
+}
+
+int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const double* camera_host,
+                   int debayer, int sharpening, int denoising, double gamma, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!raw || !out || !camera_host) return r2l_fail(-1, "r2l_static_fwd: null pointer");
+  if (debayer != R2L_DEBAYER_BILINEAR && debayer != R2L_DEBAYER_MALVAR2004)
+    return r2l_fail(-1, "r2l_static_fwd: unknown debayer");
+  if (sharpening != R2L_SHARPEN_NONE && sharpening != R2L_SHARPEN_FILTER)
+    return r2l_fail(-1, "r2l_static_fwd: unknown sharpening");
+  if (denoising != R2L_DENOISE_NONE && denoising != R2L_DENOISE_GAUSSIAN)
+    return r2l_fail(-4, "r2l_static_fwd: only gaussian_denoising (or none) is built on the device");
+  if (!(gamma > 0)) return r2l_fail(-1, "r2l_static_fwd: gamma must be > 0");
+  R2LStaticArgs a;
+  r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma);
+  const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
+  if (a.full && debayer == R2L_DEBAYER_MALVAR2004)
+    return r2l_fail(-4, "r2l_static_fwd: Malvar2004 + sharpening/denoising (halo 5) is not built yet");
+  if (a.full) {
+    const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC_FULL", 256));
+    return r2l_launch_static_full(a, grid, stream);
+  }
+  const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC", 1024));
+  return r2l_launch_static_short(a, grid, stream);
+}
+
+}  // extern "C"

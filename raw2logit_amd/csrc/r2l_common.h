@@ -1,0 +1,219 @@
+// r2l_common.h -- shared definitions of the raw2logit ISP kernels (gfx950 / CDNA4).
+//
+// Every kernel body is written as a sequence of PHASES: functions of (tid, LDS, per-thread
+// registers) separated by workgroup barriers.  libr2l_isp.so compiles them with hipcc for gfx950.
+// The same phase functions also compile as plain C++ when R2L_EMUL is defined: tests/_build/
+// libr2l_emul.so then runs every phase for tid = 0..255 in a loop, which lets the CPU-only test
+// suite check tiling / halo / indexing logic of the REAL kernel source against the oracle.  The
+// emulation is test infrastructure: the product loader (raw2logit_amd/_lib.py) refuses it.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/r2l_isp.h"
+
+#define R2L_NT 256  // threads per workgroup: 4 wavefronts of 64
+
+#ifdef R2L_EMUL
+#define R2L_HD static inline
+#define R2L_BLOCKFN static inline
+struct alignas(16) r2l_f4 {
+  float x, y, z, w;
+};
+struct alignas(8) r2l_f2 {
+  float x, y;
+};
+R2L_HD float r2l_log2(float x) { return log2f(x); }
+R2L_HD float r2l_exp2(float x) { return exp2f(x); }
+R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
+#define R2L_PHASE_BEGIN for (int tid = 0; tid < R2L_NT; ++tid) {
+#define R2L_PHASE_END }
+#define R2L_TREG_DECL(type, name) type name##_all[R2L_NT]
+#define R2L_TREG(name) name##_all[tid]
+#define R2L_PRAGMA_UNROLL
+#else
+#include <hip/hip_runtime.h>
+#define R2L_HD static __device__ __forceinline__
+#define R2L_BLOCKFN static __device__ __forceinline__
+typedef float4 r2l_f4;
+typedef float2 r2l_f2;
+// v_log_f32 / v_exp_f32 are base-2 and 1 ULP; inputs here are >= 1e-5 (or exactly 0) so the
+// denormal pre-scaling of logf()/expf() is not needed.  v_rcp_f32 is 1 ULP.
+R2L_HD float r2l_log2(float x) { return __builtin_amdgcn_logf(x); }
+R2L_HD float r2l_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+R2L_HD float r2l_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#define R2L_PHASE_BEGIN \
+  {                     \
+    const int tid = threadIdx.x;
+#define R2L_PHASE_END \
+  }                   \
+  __syncthreads();
+#define R2L_TREG_DECL(type, name) type name
+#define R2L_TREG(name) name
+#define R2L_PRAGMA_UNROLL _Pragma("unroll")
+#endif
+
+#define R2L_LN2 0.69314718055994530942
+
+// torch 'reflect' (mirror without repeating the edge: c b | a b c), clamped for far-out indices
+R2L_HD int r2l_mirror(int i, int n) {
+  i = i < 0 ? -i : i;
+  i = i >= n ? 2 * (n - 1) - i : i;
+  i = i < 0 ? 0 : i;
+  return i > n - 1 ? n - 1 : i;
+}
+// scipy 'reflect' (symmetric: b a | a b), clamped
+R2L_HD int r2l_symmetric(int i, int n) {
+  i = i < 0 ? -1 - i : i;
+  i = i >= n ? 2 * n - 1 - i : i;
+  i = i < 0 ? 0 : i;
+  return i > n - 1 ? n - 1 : i;
+}
+// channel of the RGGB site with row/column parities (py,px): R=0, G1=G2=1, B=2
+// (pipeline_torch.py:256-259, :274-277)
+R2L_HD int r2l_site_channel(int py, int px) { return (py & 1) + (px & 1); }
+
+// ---- folded parameters -------------------------------------------------------------------------
+// The chain  mosaic -> Debayer conv -> white balance -> CCM -> RGB->YUV  (pipeline_torch.py:183-194)
+// is linear in the black-level-corrected raw value v: because each mosaic plane is non-zero only on
+// its own Bayer sites, YUV[k](p) = sum_t A[k][parity(p)][t] * v(p+t) over the 3x3 taps t, with
+//   A[k][par][t] = sum_j T[k][j] * debayer.weight[j][channel(site(par,t))][t],
+//   T = M_RGB_2_YUV * colour_correction * diag(white_balance).
+// A tiny prologue kernel computes the block below (in float64) from the packed parameters on the
+// device, so parameters never visit the host.
+struct R2LFolded {
+  float bl[4];  // black level per RGGB site
+  float AY[4][9];  // [parity = (y&1)*2 + (x&1)][tap = (dy+1)*3 + (dx+1)]
+  float AU[4][9];
+  float AV[4][9];
+  float sharp[9];
+  float blur[25];
+  float M2[9];  // M_YUV_2_RGB [k][c]
+  float inv_gamma;
+  float gamma;
+  float pad[2];
+};
+
+// The kernels read the folded block through the CONSTANT address space so that every weight is a
+// scalar load (s_load -> SGPR operand of v_fma), never a per-lane VGPR.
+#ifdef R2L_EMUL
+typedef const R2LFolded& R2LFoldedRef;
+#define R2L_FOLDED_REF(ptr) (*(ptr))
+#else
+typedef const __attribute__((address_space(4))) R2LFolded& R2LFoldedRef;
+#define R2L_FOLDED_REF(ptr) (*(const __attribute__((address_space(4))) R2LFolded*)(ptr))
+#endif
+
+R2L_HD void r2l_fold_params(const float* P, R2LFolded* F) {
+  double T[3][3];
+  for (int k = 0; k < 3; ++k)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int j = 0; j < 3; ++j)
+        s += (double)P[R2L_P_M_RGB2YUV + k * 3 + j] * (double)P[R2L_P_CCM + j * 3 + c];
+      T[k][c] = s * (double)P[R2L_P_WHITE_BALANCE + c];
+    }
+  for (int s = 0; s < 4; ++s) F->bl[s] = P[R2L_P_BLACK_LEVEL + s];
+  for (int par = 0; par < 4; ++par)
+    for (int t = 0; t < 9; ++t) {
+      const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
+      const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
+      double a[3];
+      for (int k = 0; k < 3; ++k) {
+        double s = 0;
+        for (int j = 0; j < 3; ++j) s += T[k][j] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
+        a[k] = s;
+      }
+      F->AY[par][t] = (float)a[0];
+      F->AU[par][t] = (float)a[1];
+      F->AV[par][t] = (float)a[2];
+    }
+  for (int i = 0; i < 9; ++i) F->sharp[i] = P[R2L_P_SHARPEN + i];
+  for (int i = 0; i < 25; ++i) F->blur[i] = P[R2L_P_BLUR + i];
+  for (int i = 0; i < 9; ++i) F->M2[i] = P[R2L_P_M_YUV2RGB + i];
+  F->gamma = P[R2L_P_GAMMA];
+  F->inv_gamma = (float)(1.0 / (double)P[R2L_P_GAMMA]);
+  F->pad[0] = F->pad[1] = 0.f;
+}
+
+// ---- reduction slots of the backward kernels ----------------------------------------------------
+// B1 (pixel kernel): sums over pixels p of the tile interior
+enum {
+  R2L_B1_GBLUR = 0,   // [25]  sum gY''(p) * Y'_ext(p+t)           -> d/d gaussian_blur.weight
+  R2L_B1_GAU = 25,    // [4][9] sum_{par(p)} gU(p) * v_ext(p+t)      -> folded debayer/CCM/WB grads
+  R2L_B1_GAV = 61,    // [4][9]
+  R2L_B1_SU = 97,     // [4]   sum_{par(p)} gU(p)                   -> black level
+  R2L_B1_SV = 101,    // [4]
+  R2L_B1_GGAM = 105,  // [1]   sum g * x^(1/gamma) * log2(x_clipped) -> gamma_correct
+  R2L_B1_NACC = 106
+};
+// B2 (luma adjoint kernel)
+enum {
+  R2L_B2_GSHARP = 0,  // [9]   sum gY'(p) * Y_zero_ext(p+t)         -> d/d sharpening_filter.weight
+  R2L_B2_GAY = 9,     // [4][9] sum_{par(p)} gY(p) * v_ext(p+t)
+  R2L_B2_SY = 45,     // [4]
+  R2L_B2_NACC = 49
+};
+#define R2L_NSUMS (R2L_B1_NACC + R2L_B2_NACC)
+
+// Unfold the reduced sums into gradients of the 132 trainable parameters (float64 throughout).
+R2L_HD void r2l_unfold_grads(const float* P, const double* S, float* gp) {
+  const double* b1 = S;
+  const double* b2 = S + R2L_B1_NACC;
+  double T[3][3], M1[3][3], ccm[3][3], wb[3];
+  for (int c = 0; c < 3; ++c) wb[c] = P[R2L_P_WHITE_BALANCE + c];
+  for (int k = 0; k < 3; ++k)
+    for (int c = 0; c < 3; ++c) {
+      M1[k][c] = P[R2L_P_M_RGB2YUV + k * 3 + c];
+      ccm[k][c] = P[R2L_P_CCM + k * 3 + c];
+    }
+  for (int k = 0; k < 3; ++k)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int j = 0; j < 3; ++j) s += M1[k][j] * ccm[j][c];
+      T[k][c] = s * wb[c];
+    }
+  double gdeb[81], gT[3][3], gbl[4];
+  for (int i = 0; i < 81; ++i) gdeb[i] = 0;
+  for (int k = 0; k < 3; ++k)
+    for (int j = 0; j < 3; ++j) gT[k][j] = 0;
+  for (int s = 0; s < 4; ++s) gbl[s] = 0;
+  for (int k = 0; k < 3; ++k) {
+    const double* GA = (k == 0) ? (b2 + R2L_B2_GAY) : (k == 1 ? b1 + R2L_B1_GAU : b1 + R2L_B1_GAV);
+    const double* SS = (k == 0) ? (b2 + R2L_B2_SY) : (k == 1 ? b1 + R2L_B1_SU : b1 + R2L_B1_SV);
+    for (int par = 0; par < 4; ++par)
+      for (int t = 0; t < 9; ++t) {
+        const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
+        const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
+        const int site = ((py + dy + 2) & 1) * 2 + ((px + dx + 2) & 1);
+        const double ga = GA[par * 9 + t];
+        double a = 0;
+        for (int j = 0; j < 3; ++j) {
+          const double w = P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
+          gdeb[(j * 3 + c) * 9 + t] += T[k][j] * ga;
+          gT[k][j] += ga * w;
+          a += T[k][j] * w;
+        }
+        gbl[site] -= a * SS[par];
+      }
+  }
+  for (int s = 0; s < 4; ++s) gp[R2L_P_BLACK_LEVEL + s] = (float)gbl[s];
+  for (int c = 0; c < 3; ++c) {
+    double g = 0;
+    for (int k = 0; k < 3; ++k)
+      for (int j = 0; j < 3; ++j) g += gT[k][c] * M1[k][j] * ccm[j][c];
+    gp[R2L_P_WHITE_BALANCE + c] = (float)g;
+  }
+  for (int j = 0; j < 3; ++j)
+    for (int c = 0; c < 3; ++c) {
+      double g = 0;
+      for (int k = 0; k < 3; ++k) g += gT[k][c] * M1[k][j] * wb[c];
+      gp[R2L_P_CCM + j * 3 + c] = (float)g;
+    }
+  const double gamma = P[R2L_P_GAMMA];
+  gp[R2L_P_GAMMA] = (float)(-b1[R2L_B1_GGAM] * R2L_LN2 / (gamma * gamma));
+  for (int i = 0; i < 81; ++i) gp[R2L_P_DEBAYER + i] = (float)gdeb[i];
+  for (int i = 0; i < 9; ++i) gp[R2L_P_SHARPEN + i] = (float)b2[R2L_B2_GSHARP + i];
+  for (int i = 0; i < 25; ++i) gp[R2L_P_BLUR + i] = (float)b1[R2L_B1_GBLUR + i];
+}

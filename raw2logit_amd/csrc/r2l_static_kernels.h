@@ -1,0 +1,468 @@
+// r2l_static_kernels.h -- the static ("numpy semantics") pipeline, batched on the device.
+//
+// Replaces processing() (processing/pipeline_numpy.py:70-141) applied per image by
+// RawProcessingPipeline.__call__ (:55-67):
+//   remove_blacklv (:152-158) -> demosaicing_CFA_Bayer_bilinear | _Malvar2004 (:92-95; colour-demosaicing
+//   0.1.6: scipy.ndimage.convolve, mode 'reflect' == symmetric) -> white balance (:161-162) -> colour
+//   matrix (:165-167) -> [sharpening_filter (:180-191): rgb2yuv, convolve2d(Y, K, 'same', fill 0),
+//   yuv2rgb] -> [gaussian_denoising (:203-209): rgb2yuv, ndimage.gaussian_filter(Y, 0.5) (5 taps,
+//   symmetric), yuv2rgb] -> clip[0,1] (:138) -> x ** (1/gamma) (:241-244).
+// The reference computes all of this in float64 (dataset.py:87 hands it float64 frames); x**(1/gamma)
+// has an unbounded derivative at 0, so float32 round-off in the linear part would break the 1e-5
+// parity bar near black.  The linear part therefore runs in float64 here as well (MI355X: half the
+// f32 vector rate, still far below the HBM time); only log2/exp2 run in float32, whose RELATIVE error
+// is what matters for the power law.
+//
+// SHORT chain (no sharpening / denoising; BASELINE config C3): one LDS plane (raw tile + halo), one
+// read of raw (4 B/px), one write of RGB (12 B/px).
+// FULL chain: two more float64 LDS planes for the luma (zero-extended for the sharpen, symmetric-
+// extended for the blur), same structure as the parametrized kernel.
+#pragma once
+#include "r2l_param_kernels.h"
+
+typedef R2LGeom<64, 64> GStatic;
+#define R2L_STATIC_LDS_FLOATS (2 * GStatic::PAD + 5 * GStatic::PLANE)
+#define R2L_STATIC_SHORT_LDS_FLOATS (2 * GStatic::PAD + GStatic::PLANE)
+
+struct R2LStaticArgs {
+  const float* raw;
+  float* out;
+  int B, H, W;
+  int debayer, full, sharpen, denoise;
+  double bl[4];
+  double wbccm[9];  // colour_matrix * diag(white_balance): RGB_cc = wbccm * RGB_demosaic
+  double T[9];      // yuv_from_rgb * wbccm
+  double M2[9];     // rgb_from_yuv = inv(yuv_from_rgb)
+  double ksharp[9];
+  double gk[5];  // gaussian taps, sigma 0.5, radius 2
+  float inv_gamma;
+};
+
+static inline void r2l_inv3(const double* m, double* o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const double A = e * i - f * h, Bc = -(d * i - f * g), C = d * h - e * g;
+  const double det = a * A + b * Bc + c * C;
+  o[0] = A / det;
+  o[1] = -(b * i - c * h) / det;
+  o[2] = (b * f - c * e) / det;
+  o[3] = Bc / det;
+  o[4] = (a * i - c * g) / det;
+  o[5] = -(a * f - c * d) / det;
+  o[6] = C / det;
+  o[7] = -(a * h - b * g) / det;
+  o[8] = (a * e - b * d) / det;
+}
+
+static inline void r2l_static_setup(R2LStaticArgs& a, const float* raw, float* out, int B, int H, int W,
+                                    const double* cam, int debayer, int sharpening, int denoising,
+                                    double gamma) {
+  // skimage.color yuv_from_rgb (scikit-image 0.18.1); the reference's own copy is
+  // pipeline_torch.py:21-23
+  static const double M1[9] = {0.299,       0.587,       0.114,       -0.14714119, -0.28886916,
+                               0.43601035,  0.61497538,  -0.51496512, -0.10001026};
+  a.raw = raw;
+  a.out = out;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.debayer = debayer;
+  a.sharpen = sharpening;
+  a.denoise = denoising;
+  a.full = (sharpening != R2L_SHARPEN_NONE) || (denoising != R2L_DENOISE_NONE);
+  for (int s = 0; s < 4; ++s) a.bl[s] = cam[s];
+  for (int k = 0; k < 3; ++k)
+    for (int c = 0; c < 3; ++c) a.wbccm[k * 3 + c] = cam[7 + k * 3 + c] * cam[4 + c];
+  for (int k = 0; k < 3; ++k)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int j = 0; j < 3; ++j) s += M1[k * 3 + j] * a.wbccm[j * 3 + c];
+      a.T[k * 3 + c] = s;
+    }
+  r2l_inv3(M1, a.M2);
+  static const double KS[9] = {0, -1, 0, -1, 5, -1, 0, -1, 0};  // pipeline_numpy.py:180
+  static const double ID[9] = {0, 0, 0, 0, 1, 0, 0, 0, 0};
+  for (int i = 0; i < 9; ++i) a.ksharp[i] = (sharpening == R2L_SHARPEN_FILTER) ? KS[i] : ID[i];
+  if (denoising == R2L_DENOISE_GAUSSIAN) {  // scipy.ndimage.gaussian_filter(sigma=0.5): radius 2
+    double w[5], s = 0;
+    for (int i = 0; i < 5; ++i) {
+      const double x = i - 2;
+      w[i] = exp(-0.5 / (0.5 * 0.5) * x * x);
+      s += w[i];
+    }
+    for (int i = 0; i < 5; ++i) a.gk[i] = w[i] / s;
+  } else {
+    for (int i = 0; i < 5; ++i) a.gk[i] = (i == 2) ? 1.0 : 0.0;
+  }
+  a.inv_gamma = (float)(1.0 / gamma);
+}
+
+// ---- phase A: raw tile + halo, symmetric ('reflect' of scipy) coordinates, plain float32 -----------
+template <class G>
+R2L_HD void r2l_load_raw_sym(int tid, float* V, const float* rawb, int oy, int ox, int H, int W) {
+  constexpr int CPR = G::FW / 4;
+  const bool vec_ok = (W & 3) == 0;
+  for (int ci = tid; ci < CPR * G::FH; ci += R2L_NT) {
+    const int fy = ci / CPR, cx = ci - fy * CPR;
+    const int gy = r2l_symmetric(oy - 4 + fy, H);
+    const int gx0 = ox - 4 + 4 * cx;
+    const float* row = rawb + (size_t)gy * W;
+    r2l_f4 v;
+    if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
+      v = *(const r2l_f4*)(row + gx0);
+    } else {
+      v.x = row[r2l_symmetric(gx0, W)];
+      v.y = row[r2l_symmetric(gx0 + 1, W)];
+      v.z = row[r2l_symmetric(gx0 + 2, W)];
+      v.w = row[r2l_symmetric(gx0 + 3, W)];
+    }
+    *(r2l_f4*)(V + fy * G::FS + 4 * cx) = v;
+  }
+}
+
+// ---- demosaicing of one pixel -----------------------------------------------------------------------
+// Bilinear: three MASKED planes convolved with H_RB / H_G / H_RB.  n = black-level-corrected 3x3
+// neighbourhood, tpy/tpx = row / column parities of the taps' (symmetric-clamped) coordinates: for taps
+// inside the image that is the usual checkerboard; a tap mirrored back from outside keeps the site of
+// the pixel it was mirrored from.
+R2L_HD void r2l_bilinear_px(const double n[3][3], const int tpy[3], const int tpx[3], double d[3]) {
+  double dr = 0.0, dg = 0.0, db = 0.0;
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    const int ch = tpy[i] + tpx[j];
+    const double krb = ((i == 1) ? 2.0 : 1.0) * ((j == 1) ? 2.0 : 1.0) * 0.25;
+    const double t = krb * n[i][j];
+    dr += (ch == 0) ? t : 0.0;
+    db += (ch == 2) ? t : 0.0;
+    if (i == 1 || j == 1) {
+      const double kg = ((i == 1 && j == 1) ? 4.0 : 1.0) * 0.25;
+      dg += (ch == 1) ? kg * n[i][j] : 0.0;
+    }
+  }
+  d[0] = dr;
+  d[1] = dg;
+  d[2] = db;
+}
+
+// Malvar-He-Cutler 2004 (colour-demosaicing 0.1.6 coefficients), w = black-level-corrected 5x5
+// neighbourhood of the UNMASKED mosaic, (py,px) = parity of the output pixel.
+R2L_HD double r2l_malvar_gr_gb(const double w[5][5]) {
+  return (4.0 * w[2][2] + 2.0 * (w[1][2] + w[3][2] + w[2][1] + w[2][3]) -
+          (w[0][2] + w[4][2] + w[2][0] + w[2][4])) *
+         0.125;
+}
+R2L_HD double r2l_malvar_rg_rb(const double w[5][5]) {  // Rg_RB_Bg_BR (horizontal neighbours x4)
+  return (5.0 * w[2][2] + 4.0 * (w[2][1] + w[2][3]) - (w[1][1] + w[1][3] + w[3][1] + w[3][3]) -
+          (w[2][0] + w[2][4]) + 0.5 * (w[0][2] + w[4][2])) *
+         0.125;
+}
+R2L_HD double r2l_malvar_rg_br(const double w[5][5]) {  // its transpose (vertical neighbours x4)
+  return (5.0 * w[2][2] + 4.0 * (w[1][2] + w[3][2]) - (w[1][1] + w[1][3] + w[3][1] + w[3][3]) -
+          (w[0][2] + w[4][2]) + 0.5 * (w[2][0] + w[2][4])) *
+         0.125;
+}
+R2L_HD double r2l_malvar_rb_bb(const double w[5][5]) {
+  return (6.0 * w[2][2] + 2.0 * (w[1][1] + w[1][3] + w[3][1] + w[3][3]) -
+          1.5 * (w[0][2] + w[4][2] + w[2][0] + w[2][4])) *
+         0.125;
+}
+R2L_HD void r2l_malvar_px(const double w[5][5], int py, int px, double d[3]) {
+  if (py == 0 && px == 0) {  // R site
+    d[0] = w[2][2];
+    d[1] = r2l_malvar_gr_gb(w);
+    d[2] = r2l_malvar_rb_bb(w);
+  } else if (py == 0 && px == 1) {  // G in a red row, blue column
+    d[0] = r2l_malvar_rg_rb(w);
+    d[1] = w[2][2];
+    d[2] = r2l_malvar_rg_br(w);
+  } else if (py == 1 && px == 0) {  // G in a blue row, red column
+    d[0] = r2l_malvar_rg_br(w);
+    d[1] = w[2][2];
+    d[2] = r2l_malvar_rg_rb(w);
+  } else {  // B site
+    d[0] = r2l_malvar_rb_bb(w);
+    d[1] = r2l_malvar_gr_gb(w);
+    d[2] = w[2][2];
+  }
+}
+
+// black-level-corrected float64 window of N x N raw values whose element (i,j) sits at global
+// (gy0 - HALO + i, gx0 - HALO + j); rp/cp receive the site parities of the rows / columns.
+// PAR0 = parity of gy0 and of gx0 (known at compile time: tiles and micro-tiles start on even pixels)
+template <class G, int N, int HALO, bool BORDER, int PAR0>
+R2L_HD void r2l_static_window(const float* V, int fy0, int fx0, int gy0, int gx0,
+                              const R2LStaticArgs& a, double w[N][N], int rp[N], int cp[N]) {
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < N; ++i) {
+    rp[i] = BORDER ? (r2l_symmetric(gy0 - HALO + i, a.H) & 1) : ((PAR0 + i + HALO) & 1);
+    cp[i] = BORDER ? (r2l_symmetric(gx0 - HALO + i, a.W) & 1) : ((PAR0 + i + HALO) & 1);
+  }
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < N; ++i) {
+    const float* r = V + (fy0 - HALO + i) * G::FS + fx0 - HALO;
+    R2L_PRAGMA_UNROLL
+    for (int j = 0; j < N; ++j) {
+      double bl;
+      if (BORDER) {
+        const double b0 = rp[i] ? a.bl[2] : a.bl[0], b1 = rp[i] ? a.bl[3] : a.bl[1];
+        bl = cp[j] ? b1 : b0;
+      } else {
+        bl = a.bl[(((PAR0 + i + HALO) & 1) << 1) | ((PAR0 + j + HALO) & 1)];
+      }
+      w[i][j] = (double)r[j] - bl;
+    }
+  }
+}
+
+// demosaiced RGB (float64) of the 4x4 micro-tile at frame (fy0, fx0) / global (gy0, gx0)
+template <class G, bool BORDER>
+R2L_HD void r2l_static_demosaic_4x4(const float* V, int fy0, int fx0, int gy0, int gx0,
+                                    const R2LStaticArgs& a, double d[4][4][3]) {
+  if (a.debayer == R2L_DEBAYER_MALVAR2004) {
+    double w[8][8];
+    int rp[8], cp[8];
+    r2l_static_window<G, 8, 2, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
+    R2L_PRAGMA_UNROLL
+    for (int r = 0; r < 4; ++r)
+      R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      double n[5][5];
+      R2L_PRAGMA_UNROLL
+      for (int i = 0; i < 5; ++i)
+        R2L_PRAGMA_UNROLL
+      for (int j = 0; j < 5; ++j) n[i][j] = w[r + i][c + j];
+      r2l_malvar_px(n, r & 1, c & 1, d[r][c]);
+    }
+  } else {
+    double w[6][6];
+    int rp[6], cp[6];
+    r2l_static_window<G, 6, 1, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
+    R2L_PRAGMA_UNROLL
+    for (int r = 0; r < 4; ++r)
+      R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      double n[3][3];
+      int tpy[3], tpx[3];
+      R2L_PRAGMA_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        tpy[i] = rp[r + i];
+        tpx[i] = cp[c + i];
+        R2L_PRAGMA_UNROLL
+        for (int j = 0; j < 3; ++j) n[i][j] = w[r + i][c + j];
+      }
+      r2l_bilinear_px(n, tpy, tpx, d[r][c]);
+    }
+  }
+}
+
+R2L_HD bool r2l_static_touches_border(int gy0, int gx0, int halo, int H, int W) {
+  return gy0 - halo < 0 || gx0 - halo < 0 || gy0 + 3 + halo >= H || gx0 + 3 + halo >= W;
+}
+
+// ---- full chain, phase B: luma on frame [1, F-1) quads -> Y (float64, zero outside the image) -------
+template <class G, bool BORDER>
+R2L_HD void r2l_static_y_quad(const float* V, double* Y, int fy, int fx, int gy, int gx,
+                              const R2LStaticArgs& a) {
+  // 2x2 quad at ODD frame coordinates (fy, fx): window of 4x4 raw values (halo 1)
+  double w[4][4];
+  int rp[4], cp[4];
+  r2l_static_window<G, 4, 1, BORDER, 1>(V, fy, fx, gy, gx, a, w, rp, cp);
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 2; ++r)
+    R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 2; ++c) {
+    double n[3][3], d[3];
+    int tpy[3], tpx[3];
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i) {
+      tpy[i] = rp[r + i];
+      tpx[i] = cp[c + i];
+      R2L_PRAGMA_UNROLL
+      for (int j = 0; j < 3; ++j) n[i][j] = w[r + i][c + j];
+    }
+    r2l_bilinear_px(n, tpy, tpx, d);
+    const double y = a.T[0] * d[0] + a.T[1] * d[1] + a.T[2] * d[2];
+    const bool in = (unsigned)(gy + r) < (unsigned)a.H && (unsigned)(gx + c) < (unsigned)a.W;
+    Y[(fy + r) * G::FS + fx + c] = in ? y : 0.0;
+  }
+}
+template <class G>
+R2L_HD void r2l_static_compute_y(int tid, const float* V, double* Y, const R2LStaticArgs& a, int oy,
+                                 int ox) {
+  constexpr int QW = (G::FW - 2) / 2, QH = (G::FH - 2) / 2;
+  for (int q = tid; q < QW * QH; q += R2L_NT) {
+    const int fy = 1 + 2 * (q / QW), fx = 1 + 2 * (q % QW);
+    const int gy = oy - 4 + fy, gx = ox - 4 + fx;
+    const bool border = gy - 1 < 0 || gx - 1 < 0 || gy + 2 >= a.H || gx + 2 >= a.W;
+    if (border)
+      r2l_static_y_quad<G, true>(V, Y, fy, fx, gy, gx, a);
+    else
+      r2l_static_y_quad<G, false>(V, Y, fy, fx, gy, gx, a);
+  }
+}
+// phase C: YP = convolve2d(Y, K, 'same', fill 0) on frame [2, F-2)
+template <class G>
+R2L_HD void r2l_static_compute_yp(int tid, const double* Y, double* YP, const R2LStaticArgs& a) {
+  constexpr int NW = G::FW - 4, NH = G::FH - 4;
+  for (int i = tid; i < NW * NH; i += R2L_NT) {
+    const int fy = 2 + i / NW, fx = 2 + i % NW;
+    double s = 0.0;
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 3; ++p)
+      R2L_PRAGMA_UNROLL
+    for (int q = 0; q < 3; ++q)  // true convolution: flipped kernel (K is symmetric anyway)
+      s += a.ksharp[(2 - p) * 3 + (2 - q)] * Y[(fy - 1 + p) * G::FS + fx - 1 + q];
+    YP[fy * G::FS + fx] = s;
+  }
+}
+// phase C2 (border tiles): symmetric extension of YP outside the image
+template <class G>
+R2L_HD void r2l_static_fill_yp(int tid, double* YP, int oy, int ox, int H, int W) {
+  constexpr int NW = G::FW - 4, NH = G::FH - 4;
+  for (int i = tid; i < NW * NH; i += R2L_NT) {
+    const int fy = 2 + i / NW, fx = 2 + i % NW;
+    const int gy = oy - 4 + fy, gx = ox - 4 + fx;
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) continue;
+    const int my = r2l_symmetric(gy, H) - (oy - 4), mx = r2l_symmetric(gx, W) - (ox - 4);
+    if (my >= 2 && my < G::FH - 2 && mx >= 2 && mx < G::FW - 2) YP[fy * G::FS + fx] = YP[my * G::FS + mx];
+  }
+}
+
+// ---- pixel stage ---------------------------------------------------------------------------------
+template <class G, bool BORDER, bool FULL>
+R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, const R2LStaticArgs& a,
+                                   const R2LTile& t) {
+  const int tx = mt % G::TXN, ty = mt / G::TXN;
+  const int gy0 = t.oy + 4 * ty, gx0 = t.ox + 4 * tx;
+  const int fy0 = 4 * ty + 4, fx0 = 4 * tx + 4;
+  double d[4][4][3];
+  r2l_static_demosaic_4x4<G, BORDER>(V, fy0, fx0, gy0, gx0, a, d);
+  double ypp[4][4];
+  if (FULL) {
+    R2L_PRAGMA_UNROLL
+    for (int r = 0; r < 4; ++r)
+      R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) ypp[r][c] = 0.0;
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 8; ++i) {  // input row fy0-2+i contributes to output rows r = i-4 .. i
+      double row[8];
+      const double* rp = YP + (fy0 - 2 + i) * G::FS + fx0 - 2;
+      R2L_PRAGMA_UNROLL
+      for (int j = 0; j < 8; ++j) row[j] = rp[j];
+      R2L_PRAGMA_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        const int ki = i - r;
+        if (ki < 0 || ki > 4) continue;
+        R2L_PRAGMA_UNROLL
+        for (int c = 0; c < 4; ++c)
+          R2L_PRAGMA_UNROLL
+        for (int kj = 0; kj < 5; ++kj) ypp[r][c] += (a.gk[ki] * a.gk[kj]) * row[c + kj];
+      }
+    }
+  }
+  const size_t plane = (size_t)a.H * a.W;
+  const bool vec_ok = ((a.W & 3) == 0) && (gx0 + 3 < a.W);
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 4; ++r) {
+    const int gy = gy0 + r;
+    if (gy >= a.H) break;
+    float x[3][4];
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      double rgb[3];
+      if (FULL) {
+        const double u = a.T[3] * d[r][c][0] + a.T[4] * d[r][c][1] + a.T[5] * d[r][c][2];
+        const double v = a.T[6] * d[r][c][0] + a.T[7] * d[r][c][1] + a.T[8] * d[r][c][2];
+        R2L_PRAGMA_UNROLL
+        for (int k = 0; k < 3; ++k)
+          rgb[k] = a.M2[k * 3] * ypp[r][c] + a.M2[k * 3 + 1] * u + a.M2[k * 3 + 2] * v;
+      } else {
+        R2L_PRAGMA_UNROLL
+        for (int k = 0; k < 3; ++k)
+          rgb[k] = a.wbccm[k * 3] * d[r][c][0] + a.wbccm[k * 3 + 1] * d[r][c][1] +
+                   a.wbccm[k * 3 + 2] * d[r][c][2];
+      }
+      R2L_PRAGMA_UNROLL
+      for (int k = 0; k < 3; ++k) {
+        const float xf = (float)fmin(fmax(rgb[k], 0.0), 1.0);           // np.clip(img, 0, 1)  :138
+        x[k][c] = (xf > 0.f) ? r2l_exp2(r2l_log2(xf) * a.inv_gamma) : 0.f;  // img ** (1/gamma) :243
+      }
+    }
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      float* o = a.out + ((size_t)t.b * 3 + k) * plane + (size_t)gy * a.W + gx0;
+      if (vec_ok) {
+        r2l_f4 st;
+        st.x = x[k][0];
+        st.y = x[k][1];
+        st.z = x[k][2];
+        st.w = x[k][3];
+        *(r2l_f4*)o = st;
+      } else {
+        R2L_PRAGMA_UNROLL
+        for (int c = 0; c < 4; ++c)
+          if (gx0 + c < a.W) o[c] = x[k][c];
+      }
+    }
+  }
+}
+
+template <class G, bool FULL>
+R2L_HD void r2l_static_pixels(int tid, const float* V, const double* YP, const R2LStaticArgs& a,
+                              const R2LTile& t) {
+  const int tx = tid % G::TXN, ty = tid / G::TXN;
+  const int gy0 = t.oy + 4 * ty, gx0 = t.ox + 4 * tx;
+  if (gy0 >= a.H || gx0 >= a.W) return;
+  const int halo = (a.debayer == R2L_DEBAYER_MALVAR2004) ? 2 : 1;
+  if (r2l_static_touches_border(gy0, gx0, halo, a.H, a.W))
+    r2l_static_pixels_impl<G, true, FULL>(tid, V, YP, a, t);
+  else
+    r2l_static_pixels_impl<G, false, FULL>(tid, V, YP, a, t);
+}
+
+template <class G>
+R2L_BLOCKFN void r2l_static_block(const R2LStaticArgs& a, int bid, int nblk, float* lds) {
+  float* V = lds + G::PAD;
+  double* Y = (double*)(V + G::PLANE);
+  double* YP = Y + G::PLANE;
+  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
+  R2LTile t;
+  while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
+    const float* rawb = a.raw + (size_t)t.b * a.H * a.W;
+    R2L_PHASE_BEGIN
+    r2l_load_raw_sym<G>(tid, V, rawb, t.oy, t.ox, a.H, a.W);
+    R2L_PHASE_END
+    R2L_PHASE_BEGIN
+    r2l_static_compute_y<G>(tid, V, Y, a, t.oy, t.ox);
+    R2L_PHASE_END
+    R2L_PHASE_BEGIN
+    r2l_static_compute_yp<G>(tid, Y, YP, a);
+    R2L_PHASE_END
+    if (t.border) {
+      R2L_PHASE_BEGIN
+      r2l_static_fill_yp<G>(tid, YP, t.oy, t.ox, a.H, a.W);
+      R2L_PHASE_END
+    }
+    R2L_PHASE_BEGIN
+    r2l_static_pixels<G, true>(tid, V, YP, a, t);
+    R2L_PHASE_END
+  }
+}
+
+// short chain: demosaic -> WB -> CCM -> clip -> gamma; a single LDS plane
+template <class G>
+R2L_BLOCKFN void r2l_static_short_block(const R2LStaticArgs& a, int bid, int nblk, float* lds) {
+  float* V = lds + G::PAD;
+  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
+  R2LTile t;
+  while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
+    const float* rawb = a.raw + (size_t)t.b * a.H * a.W;
+    R2L_PHASE_BEGIN
+    r2l_load_raw_sym<G>(tid, V, rawb, t.oy, t.ox, a.H, a.W);
+    R2L_PHASE_END
+    R2L_PHASE_BEGIN
+    r2l_static_pixels<G, false>(tid, V, (const double*)nullptr, a, t);
+    R2L_PHASE_END
+  }
+}

@@ -1,0 +1,227 @@
+"""autograd-facing ops over the C ABI (include/r2l_isp.h).  PyTorch is plumbing here: it owns device
+memory, streams and torch.distributed; all image arithmetic happens in the HIP kernels."""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import ptr
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name} must be float32, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _workspace(lib, like, B, H, W):
+    n = lib.r2l_isp_workspace_bytes(B, H, W)
+    return torch.empty(n, dtype=torch.uint8, device=like.device), n
+
+
+def _group_size(group):
+    if group is None or not dist.is_available() or not dist.is_initialized():
+        return 1
+    return dist.get_world_size(group)
+
+
+# --------------------------------------------------------------------------------------------------
+# raw2rgb (pipeline_torch.py:240-283)
+# --------------------------------------------------------------------------------------------------
+class _Raw2Rgb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, black_level, reduce_size, out_channels):
+        raw = _f32c(raw, 'raw')
+        B, H, W = raw.shape
+        lib, stream = _lib.library_for(raw)
+        bl = None
+        if black_level is not None:
+            bl = _f32c(black_level.to(device=raw.device, dtype=torch.float32).reshape(-1), 'black_level')
+            assert bl.numel() == 4
+        if reduce_size:
+            out = torch.empty((B, out_channels, H // 2, W // 2), dtype=torch.float32, device=raw.device)
+        else:
+            out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=raw.device)
+        lib.check(lib.r2l_raw2rgb_fwd(ptr(raw), ptr(bl), ptr(out), B, H, W, int(reduce_size),
+                                      int(out_channels), stream), 'r2l_raw2rgb_fwd')
+        ctx.dims = (B, H, W, bool(reduce_size), int(out_channels))
+        ctx.has_bl = black_level is not None
+        ctx.bl_shape = None if black_level is None else tuple(black_level.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        B, H, W, reduce_size, oc = ctx.dims
+        gout = _f32c(gout, 'grad_out')
+        lib, stream = _lib.library_for(gout)
+        need_raw = ctx.needs_input_grad[0]
+        need_bl = ctx.has_bl and ctx.needs_input_grad[1]
+        graw = torch.empty((B, H, W), dtype=torch.float32, device=gout.device) if need_raw else None
+        gbl = ws = None
+        nws = 0
+        if need_bl:
+            gbl = torch.empty(4, dtype=torch.float64, device=gout.device)
+            nws = lib.r2l_raw2rgb_bwd_workspace_bytes(B, H, W)
+            ws = torch.empty(nws, dtype=torch.uint8, device=gout.device)
+        if need_raw or need_bl:
+            lib.check(lib.r2l_raw2rgb_bwd(ptr(gout), ptr(graw), ptr(gbl), ptr(ws), nws, B, H, W,
+                                          int(reduce_size), oc, stream), 'r2l_raw2rgb_bwd')
+        if gbl is not None:
+            gbl = gbl.to(torch.float32).reshape(ctx.bl_shape)
+        return graw, gbl, None, None
+
+
+def raw2rgb(raw, black_level=None, reduce_size=True, out_channels=3):
+    """drop-in for processing.pipeline_torch.raw2rgb (:240-283)."""
+    assert out_channels in [3, 4]
+    if black_level is not None and not torch.is_tensor(black_level):
+        black_level = torch.as_tensor(black_level, dtype=torch.float32, device=raw.device)
+    return _Raw2Rgb.apply(raw, black_level, reduce_size, out_channels)
+
+
+# --------------------------------------------------------------------------------------------------
+# fused parametrized ISP (ParametrizedProcessing.forward, pipeline_torch.py:175-225)
+# --------------------------------------------------------------------------------------------------
+BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
+
+
+def batch_moments(stats, n_local, group=None):
+    """(sum(x-.5)[3], sum((x-.5)^2)[3]) of this rank -> global batch mean and biased variance.
+
+    With several ranks the 7-vectors (sums, n) are all-gathered over RCCL/xGMI and added in rank order,
+    so every rank gets bit-identical statistics equal to the single-GPU statistics of the global batch."""
+    vec = torch.cat([stats, torch.tensor([float(n_local)], dtype=torch.float64, device=stats.device)])
+    if _group_size(group) > 1:
+        gathered = [torch.empty_like(vec) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(gathered, vec, group=group)
+        vec = torch.stack(gathered, 0).sum(0)
+    n = vec[6]
+    m1 = vec[:3] / n
+    mean = m1 + 0.5
+    var = (vec[3:6] / n - m1 * m1).clamp_min_(0.0)
+    return mean, var, n
+
+
+class _IspFused(torch.autograd.Function):
+    """out, batch_mean, batch_var = f(raw, packed_params, additive | None, ...).
+
+    packed_params: float32[150] in the layout of include/r2l_isp.h (built with torch.cat from the
+    module's nn.Parameters, so autograd scatters the 132-float gradient back by itself)."""
+
+    @staticmethod
+    def forward(ctx, raw, packed, additive, bn_mode, running_mean, running_var, eps, group):
+        raw = _f32c(raw, 'raw')
+        packed = _f32c(packed, 'packed')
+        if packed.numel() != _lib.R2L_P_COUNT:
+            raise ValueError(f'packed parameter block must have {_lib.R2L_P_COUNT} floats')
+        B, H, W = raw.shape
+        lib, stream = _lib.library_for(raw)
+        if additive is not None:
+            additive = _f32c(additive, 'additive_layer')
+            if tuple(additive.shape) != (1, 3, H, W):
+                raise RuntimeError(f'additive_layer {tuple(additive.shape)} does not broadcast to '
+                                   f'frames of {H}x{W}')      # same failure the reference has (:213)
+        ws, nws = _workspace(lib, raw, B, H, W)
+        dev = raw.device
+        bn = None
+        mean = var = None
+        if bn_mode == BN_TRAIN:
+            stats = torch.empty(6, dtype=torch.float64, device=dev)
+            lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(packed), ptr(additive), None, None, ptr(stats),
+                                      ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream),
+                      'r2l_isp_fwd(stats)')
+            mean, var, n_total = batch_moments(stats, B * H * W, group)
+            ctx.n_total = n_total
+        elif bn_mode == BN_EVAL:
+            mean = running_mean.detach().to(device=dev, dtype=torch.float64)
+            var = running_var.detach().to(device=dev, dtype=torch.float64)
+        if bn_mode != BN_NONE:
+            istd = torch.rsqrt(var + eps)
+            bn = torch.cat([mean, istd]).to(torch.float32)
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(out), None,
+                                  ptr(ws), nws, B, H, W, 0, stream), 'r2l_isp_fwd')
+        ctx.bn_mode = bn_mode
+        ctx.group = group
+        ctx.has_additive = additive is not None
+        ctx.save_for_backward(raw, packed, additive, bn, out)
+        if mean is None:
+            mean = var = torch.zeros(3, dtype=torch.float64, device=dev)
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, gout, _gm, _gv):
+        raw, packed, additive, bn, out = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise _lib.R2LError(
+                'the fused ISP kernels do not produce d/d raw; gradients w.r.t. the raw frames are '
+                'only defined on the staged path (track_stages=True)')
+        gout = _f32c(gout, 'grad_out')
+        B, H, W = raw.shape
+        lib, stream = _lib.library_for(raw)
+        ws, nws = _workspace(lib, raw, B, H, W)
+        bn_bwd = None
+        if ctx.bn_mode == BN_TRAIN:
+            sums = torch.empty(6, dtype=torch.float64, device=raw.device)
+            lib.check(lib.r2l_bn_bwd_reduce(ptr(gout), ptr(out), ptr(sums), ptr(ws), nws, B, H, W,
+                                            stream), 'r2l_bn_bwd_reduce')
+            if _group_size(ctx.group) > 1:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
+            bn_bwd = (sums / ctx.n_total).to(torch.float32)
+        gpacked = None
+        if ctx.needs_input_grad[1]:
+            gp = torch.empty(_lib.R2L_P_NTRAIN, dtype=torch.float32, device=raw.device)
+            lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(bn_bwd),
+                                      ptr(gout), ptr(gp), None, ptr(ws), nws, B, H, W, 0, stream),
+                      'r2l_isp_bwd')
+            gpacked = torch.cat([gp, gp.new_zeros(_lib.R2L_P_COUNT - _lib.R2L_P_NTRAIN)])
+        gadd = None
+        if ctx.has_additive and ctx.needs_input_grad[2]:
+            gadd = torch.empty_like(additive)
+            lib.check(lib.r2l_additive_bwd(ptr(gout), ptr(out), ptr(bn), ptr(bn_bwd), ptr(gadd), B, H,
+                                           W, stream), 'r2l_additive_bwd')
+        return None, gpacked, gadd, None, None, None, None, None
+
+
+def isp_fused(raw, packed, additive=None, bn_mode=BN_NONE, running_mean=None, running_var=None,
+              eps=1e-5, group=None):
+    return _IspFused.apply(raw, packed, additive, bn_mode, running_mean, running_var, eps, group)
+
+
+# --------------------------------------------------------------------------------------------------
+# static pipeline (processing(), pipeline_numpy.py:70-141), batched
+# --------------------------------------------------------------------------------------------------
+_DEBAYER = {'bilinear': 0, 'malvar2004': 1}
+_SHARPEN = {'sharpening_filter': 1}
+_DENOISE = {'gaussian_denoising': 1}
+
+
+def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
+                    denoising='gaussian_denoising', gamma=2.2):
+    """(B,H,W) float32 raw on the GPU -> (B,3,H,W) float32, numpy semantics of the reference.
+
+    Like the reference's if-chains (pipeline_numpy.py:110-122) a sharpening / denoising string that
+    names no algorithm means "skip that stage"; algorithms the reference has but this library does not
+    build (menon2007, unsharp_masking, median/fft/... denoising) raise instead of silently differing."""
+    raw = _f32c(raw, 'raw')
+    assert raw.ndim == 3, f"needs dims (B, H, W), got {raw.shape}"
+    known_sharp = {'sharpening_filter', 'unsharp_masking'}
+    known_den = {'median_denoising', 'gaussian_denoising', 'fft_denoising', 'tv_chambolle', 'tv_bregman',
+                 'bilateral'}
+    if debayer not in _DEBAYER:
+        raise NotImplementedError(f"debayer '{debayer}' is not built for the GPU (have: {list(_DEBAYER)})")
+    if sharpening in known_sharp and sharpening not in _SHARPEN:
+        raise NotImplementedError(f"sharpening '{sharpening}' is not built for the GPU")
+    if denoising in known_den and denoising not in _DENOISE:
+        raise NotImplementedError(f"denoising '{denoising}' is not built for the GPU")
+    bl, wb, ccm = camera_parameters
+    cam = (ctypes.c_double * 16)(*[float(v) for v in list(bl) + list(wb) + list(ccm)])
+    B, H, W = raw.shape
+    lib, stream = _lib.library_for(raw)
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=raw.device)
+    lib.check(lib.r2l_static_fwd(ptr(raw), ptr(out), B, H, W, cam, _DEBAYER[debayer],
+                                 _SHARPEN.get(sharpening, 0), _DENOISE.get(denoising, 0), float(gamma),
+                                 stream), 'r2l_static_fwd')
+    return out

@@ -1,0 +1,96 @@
+"""Drop-in for the reference's ``processing/pipeline_numpy.py`` (static pipeline) on MI355X.
+
+``processing(img, black_level, white_balance, colour_matrix, debayer=..., sharpening=..., denoising=...)``
+and ``RawProcessingPipeline`` keep the reference's signatures and return types
+(/root/reference/processing/pipeline_numpy.py:36-141) but run the batched static kernel of libr2l_isp.so
+(float64 linear part, numpy semantics: symmetric borders, clip to [0,1], gamma 2.2).
+
+The reference applies this per image inside DataLoader worker processes (train.py:164-171, :318); a GPU
+context cannot live in forked workers, so the batched form ``StaticProcessing`` (an nn.Module to use as
+the ``processor`` on device batches) is the fast path, and the per-image callables below are the
+API-compatible wrappers for the main process (figures/ABtesting.py:135-173, app.py:13-35)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as F_
+
+
+def _device():
+    if torch.cuda.is_available():
+        return torch.device('cuda')
+    return torch.device('cpu')      # only usable under the test emulation; _lib raises otherwise
+
+
+def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear",
+               sharpening="unsharp_masking", sharp_radius=1.0, sharp_amount=1.0,
+               denoising="median_filter", median_kernel_size=3, gaussian_sigma=0.5, fft_fraction=0.3,
+               weight_chambolle=0.01, weight_bregman=100, sigma_bilateral=0.6, gamma=2.2, bits=16):
+    """reference :70-141.  img (H,W) float ndarray -> (H,W,3) float64 ndarray.
+
+    As in the reference, `img` has its black level removed IN PLACE (:152-158) and option strings that
+    name no algorithm skip their stage (the signature default denoising="median_filter" is one)."""
+    if gaussian_sigma != 0.5 and denoising == 'gaussian_denoising':
+        raise NotImplementedError('only gaussian_sigma=0.5 (the reference default) is built')
+    raw = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None].to(_device())
+    out = F_.static_pipeline(raw, (black_level, white_balance, colour_matrix), debayer=debayer,
+                             sharpening=sharpening, denoising=denoising, gamma=gamma)
+    img[0::2, 0::2] -= black_level[0]      # side effect of remove_blacklv on the caller's array
+    img[0::2, 1::2] -= black_level[1]
+    img[1::2, 0::2] -= black_level[2]
+    img[1::2, 1::2] -= black_level[3]
+    return out[0].permute(1, 2, 0).cpu().numpy().astype(np.float64)
+
+
+class RawProcessingPipeline(object):
+    """reference :36-67: callable transform, (H,W) ndarray -> (3,H,W) float32 tensor."""
+
+    def __init__(self, camera_parameters, debayer='bilinear', sharpening='unsharp_masking', denoising='gaussian'):
+        self.camera_parameters = camera_parameters
+
+        self.debayer = debayer
+        self.sharpening = sharpening
+        self.denoising = denoising
+
+    def __call__(self, img):
+        black_level, white_balance, colour_matrix = self.camera_parameters
+        img = processing(img, black_level, white_balance, colour_matrix,
+                         debayer=self.debayer, sharpening=self.sharpening, denoising=self.denoising)
+        img = img.transpose(2, 0, 1)
+
+        return torch.Tensor(img)
+
+
+class StaticProcessing(nn.Module):
+    """Batched static pipeline as a ``processor`` module: (B,H,W) raw on the GPU -> (B,3,H,W).
+
+    Equals RawProcessingPipeline applied to every frame followed by the optional T.Normalize(mean, std)
+    of train.py:157-171.  No trainable parameters, no gradient."""
+
+    def __init__(self, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
+                 denoising='gaussian_denoising', gamma=2.2, mean=None, std=None):
+        super().__init__()
+        self.camera_parameters = tuple(list(map(float, p)) for p in camera_parameters)
+        self.debayer = debayer
+        self.sharpening = sharpening
+        self.denoising = denoising
+        self.gamma = gamma
+        self.stages = None
+        self.buffer = None
+        if mean is not None:
+            self.register_buffer('mean', torch.as_tensor(mean, dtype=torch.float32).reshape(1, 3, 1, 1))
+            self.register_buffer('std', torch.as_tensor(std, dtype=torch.float32).reshape(1, 3, 1, 1))
+        else:
+            self.mean = self.std = None
+
+    @torch.no_grad()
+    def forward(self, raw):
+        assert raw.ndim == 3, f"needs dims (B, H, W), got {raw.shape}"
+        self.stages = {}
+        self.buffer = {}
+        rgb = F_.static_pipeline(raw, self.camera_parameters, self.debayer, self.sharpening,
+                                 self.denoising, self.gamma)
+        if self.mean is not None:
+            rgb = (rgb - self.mean) / self.std
+        self.buffer['processed_rgb'] = rgb
+        return rgb

@@ -1,0 +1,253 @@
+"""Drop-in for the reference's ``processing/pipeline_torch.py`` on MI355X.
+
+Same names, constructor arguments, parameter / buffer names (state_dict keys), attributes read by the
+callers (``stages``, ``buffer``, ``track_stages``, ``additive_layer``) and error behaviour as
+/root/reference/processing/pipeline_torch.py, so that ``train.py`` (:194-203) and ``model.py`` (:77-83)
+use it unchanged -- but ``forward`` enqueues hand-written gfx950 kernels through libr2l_isp.so instead
+of ~20 ATen ops.  Modules stay deep-copyable and picklable (train.py:248, utils/base.py:249-264): they
+hold tensors only; the shared library is loaded lazily at module level."""
+import torch
+import torch.nn as nn
+
+from .. import functional as F_
+from ..functional import raw2rgb  # noqa: F401  (re-exported: reference :240-283)
+
+# constants, reference :13-40
+K_G = torch.Tensor([[0, 1, 0],
+                    [1, 4, 1],
+                    [0, 1, 0]]) / 4
+
+K_RB = torch.Tensor([[1, 2, 1],
+                     [2, 4, 2],
+                     [1, 2, 1]]) / 4
+
+M_RGB_2_YUV = torch.Tensor([[0.299, 0.587, 0.114],
+                            [-0.14714119, -0.28886916, 0.43601035],
+                            [0.61497538, -0.51496512, -0.10001026]])
+M_YUV_2_RGB = torch.Tensor([[1.0000000000e+00, -4.1827794561e-09, 1.1398830414e+00],
+                            [1.0000000000e+00, -3.9464232326e-01, -5.8062183857e-01],
+                            [1.0000000000e+00, 2.0320618153e+00, -1.2232658220e-09]])
+
+K_BLUR = torch.Tensor([[6.9625e-08, 2.8089e-05, 2.0755e-04, 2.8089e-05, 6.9625e-08],
+                       [2.8089e-05, 1.1332e-02, 8.3731e-02, 1.1332e-02, 2.8089e-05],
+                       [2.0755e-04, 8.3731e-02, 6.1869e-01, 8.3731e-02, 2.0755e-04],
+                       [2.8089e-05, 1.1332e-02, 8.3731e-02, 1.1332e-02, 2.8089e-05],
+                       [6.9625e-08, 2.8089e-05, 2.0755e-04, 2.8089e-05, 6.9625e-08]])
+K_SHARP = torch.Tensor([[0, -1, 0],
+                        [-1, 5, -1],
+                        [0, -1, 0]])
+DEFAULT_CAMERA_PARAMS = (
+    [0., 0., 0., 0.],
+    [1., 1., 1.],
+    [1., 0., 0., 0., 1., 0., 0., 0., 1.],
+)
+
+
+class RawToRGB(nn.Module):
+    """reference :43-80 -- raw (B,H,W) -> packed / zero-filled RGB via the raw2rgb kernel."""
+
+    def __init__(self, reduce_size=True, out_channels=3, track_stages=False, normalize_mosaic=None):
+        super().__init__()
+        self.stages = None
+        self.buffer = None
+        self.reduce_size = reduce_size
+        self.out_channels = out_channels
+        self.track_stages = track_stages
+        self.normalize_mosaic = normalize_mosaic
+
+    def forward(self, raw):
+        self.stages = {}
+        self.buffer = {}
+
+        rgb = raw2rgb(raw, reduce_size=self.reduce_size, out_channels=self.out_channels)
+        self.stages['demosaic'] = rgb
+        if self.normalize_mosaic:
+            rgb = self.normalize_mosaic(rgb)
+
+        if self.track_stages and raw.requires_grad:
+            for stage in self.stages.values():
+                stage.retain_grad()
+
+        self.buffer['processed_rgb'] = rgb
+
+        return rgb
+
+
+class NNProcessing(nn.Module):
+    """reference :83-126.  Only the raw2rgb front end is on this library's hot path; the U-Net++ body
+    is the third-party segmentation_models_pytorch model the reference uses (SURVEY.md section 8a, a12:
+    out of scope) and must be installed for this class to be constructed."""
+
+    def __init__(self, track_stages=False, normalize_mosaic=None, batch_norm_output=True):
+        super().__init__()
+        try:
+            import segmentation_models_pytorch as smp
+        except ImportError as e:  # pragma: no cover - smp is absent from the build image
+            raise ImportError('NNProcessing needs segmentation_models_pytorch (reference :11, :97)') from e
+        self.stages = None
+        self.buffer = None
+        self.track_stages = track_stages
+        self.model = smp.UnetPlusPlus(
+            encoder_name='resnet34',
+            encoder_depth=3,
+            decoder_channels=[256, 128, 64],
+            in_channels=3,
+            classes=3,
+        )
+        self.batch_norm = None if not batch_norm_output else nn.BatchNorm2d(3, affine=False)
+        self.normalize_mosaic = normalize_mosaic
+
+    def forward(self, raw):
+        self.stages = {}
+        self.buffer = {}
+
+        rgb = raw2rgb(raw)
+        if self.normalize_mosaic:
+            rgb = self.normalize_mosaic(rgb)
+        self.stages['demosaic'] = rgb
+        rgb = self.model(rgb)
+        if self.batch_norm is not None:
+            rgb = self.batch_norm(rgb)
+        self.stages['rgb'] = rgb
+
+        if self.track_stages and raw.requires_grad:
+            for stage in self.stages.values():
+                stage.retain_grad()
+
+        self.buffer['processed_rgb'] = rgb
+
+        return rgb
+
+
+def append_additive_layer(processor):
+    """reference :129-131."""
+    device = processor.gamma_correct.device if hasattr(processor, 'gamma_correct') else None
+    processor.additive_layer = nn.Parameter(torch.zeros((1, 3, 256, 256), device=device))
+
+
+class Debayer(nn.Conv2d):
+    """reference :228-237: trainable 3->3 3x3 conv, mirror ('reflect') padding, bilinear initial weights.
+
+    Inside ParametrizedProcessing only its ``weight`` is read: the fused kernel folds the 81 weights with
+    the white balance, colour matrix and RGB->YUV matrix into per-Bayer-parity 3x3 stencils."""
+
+    def __init__(self):
+        super().__init__(3, 3, kernel_size=3, padding=1, padding_mode='reflect', bias=False)
+        self.weight.data.fill_(0)
+        self.weight.data[0, 0] = K_RB.clone()
+        self.weight.data[1, 1] = K_G.clone()
+        self.weight.data[2, 2] = K_RB.clone()
+
+
+class ParametrizedProcessing(nn.Module):
+    """Differentiable processing pipeline, reference :134-225, as fused gfx950 kernels.
+
+    Args:
+        camera_parameters (tuple(list), optional): (black_level, white_balance, colour_matrix)
+        track_stages (bool, optional): whether or not to retain intermediary steps in processing
+        batch_norm_output (bool, optional): adds a BatchNorm layer to the end of the processing
+
+    Extra attribute (not in the reference): ``process_group`` -- when set to a torch.distributed group of
+    more than one rank, BatchNorm batch statistics (forward) and their backward sums are exchanged over
+    RCCL so that every rank normalises with the statistics of the GLOBAL batch, which is what the
+    single-GPU reference computes for that batch."""
+
+    def __init__(self, camera_parameters=None, track_stages=False, batch_norm_output=True):
+        super().__init__()
+        self.stages = None
+        self.buffer = None
+        self.track_stages = track_stages
+
+        if camera_parameters is None:
+            camera_parameters = DEFAULT_CAMERA_PARAMS
+
+        black_level, white_balance, colour_matrix = camera_parameters
+
+        self.black_level = nn.Parameter(torch.as_tensor(black_level))
+        self.white_balance = nn.Parameter(torch.as_tensor(white_balance).reshape(1, 3))
+        self.colour_correction = nn.Parameter(torch.as_tensor(colour_matrix).reshape(3, 3))
+
+        self.gamma_correct = nn.Parameter(torch.Tensor([2.2]))
+
+        self.debayer = Debayer()
+
+        self.sharpening_filter = nn.Conv2d(1, 1, kernel_size=3, padding=1, bias=False)
+        self.sharpening_filter.weight.data[0][0] = K_SHARP.clone()
+
+        self.gaussian_blur = nn.Conv2d(1, 1, kernel_size=5, padding=2, padding_mode='reflect', bias=False)
+        self.gaussian_blur.weight.data[0][0] = K_BLUR.clone()
+
+        self.batch_norm = nn.BatchNorm2d(3, affine=False) if batch_norm_output else None
+
+        self.register_buffer('M_RGB_2_YUV', M_RGB_2_YUV.clone())
+        self.register_buffer('M_YUV_2_RGB', M_YUV_2_RGB.clone())
+
+        self.additive_layer = None  # this can be added in later
+
+        self.process_group = None
+
+    # -- packed parameter block of the C ABI (include/r2l_isp.h, R2L_P_*) -----------------------------
+    def packed_parameters(self):
+        return torch.cat([
+            self.black_level.reshape(-1), self.white_balance.reshape(-1),
+            self.colour_correction.reshape(-1), self.gamma_correct.reshape(-1),
+            self.debayer.weight.reshape(-1), self.sharpening_filter.weight.reshape(-1),
+            self.gaussian_blur.weight.reshape(-1),
+            self.M_RGB_2_YUV.reshape(-1), self.M_YUV_2_RGB.reshape(-1)]).to(torch.float32)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['process_group'] = None      # communicators are neither picklable nor deep-copyable
+        state['stages'] = None
+        state['buffer'] = None
+        return state
+
+    def forward(self, raw):
+        assert raw.ndim == 3, f"needs dims (B, H, W), got {raw.shape}"
+
+        self.stages = {}
+        self.buffer = {}
+
+        if self.track_stages:
+            from ..staged import staged_forward
+            rgb = staged_forward(self, raw)
+        else:
+            rgb = self._fused_forward(raw)
+
+        if self.track_stages and raw.requires_grad:
+            for stage in self.stages.values():
+                stage.retain_grad()
+
+        self.buffer['processed_rgb'] = rgb
+
+        return rgb
+
+    def _fused_forward(self, raw):
+        bn = self.batch_norm
+        if bn is None:
+            mode = F_.BN_NONE
+        elif bn.training or (bn.running_mean is None):
+            mode = F_.BN_TRAIN
+        else:
+            mode = F_.BN_EVAL
+        rm = bn.running_mean if bn is not None else None
+        rv = bn.running_var if bn is not None else None
+        eps = bn.eps if bn is not None else 1e-5
+        out, mean, var = F_.isp_fused(raw, self.packed_parameters(), self.additive_layer, mode, rm, rv,
+                                      eps, self.process_group)
+        if mode == F_.BN_TRAIN and bn.track_running_stats and bn.running_mean is not None:
+            self._update_running_stats(bn, mean, var, raw)
+        return out
+
+    def _update_running_stats(self, bn, mean, var, raw):
+        # nn.BatchNorm2d bookkeeping: biased variance normalises, unbiased goes to running_var
+        with torch.no_grad():
+            n = raw.shape[0] * raw.shape[1] * raw.shape[2] * F_._group_size(self.process_group)
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                m = 1.0 / bn.num_batches_tracked.to(torch.float64)
+            else:
+                m = bn.momentum
+            unbiased = var * (n / max(n - 1, 1))
+            bn.running_mean.mul_(1 - m).add_((m * mean).to(bn.running_mean.dtype))
+            bn.running_var.mul_(1 - m).add_((m * unbiased).to(bn.running_var.dtype))
