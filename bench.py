@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- ISP Mpix/s (fwd+bwd) of the fused parametrized pipeline on 512x512 raw batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): ParametrizedProcessing, Drone camera
+parameters, batch_norm_output=True in train mode, 64 x 512 x 512 synthetic 12-bit RGGB frames PER GPU
+(weak scaling: the batch shards over ranks; BatchNorm batch statistics and their backward sums are
+exchanged over RCCL, the 132-float ISP gradient is all-reduced).  One step = forward + backward with a
+fixed random cotangent, inputs resident in HBM.  Pixels are raw Bayer pixels (B*H*W).
+
+The JSON line also carries
+  roofline      the dominant kernel's algorithmic HBM bytes / its average duration (HIP events on the
+                launch stream, collected by the library's timing hooks in a second, instrumented pass of
+                the same K steps) against the 8 TB/s HBM3E peak;
+  cpu_baseline  the numpy oracle (a port of the reference's pipeline_torch.py forward + backward) timed on
+                the host on a bounded sample of the same workload (rank 0, N == 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# algorithmic HBM bytes per raw pixel of each kernel (DESIGN.md section "bytes per pixel")
+ALGO_BYTES_PER_PX = {
+    'r2l_launch_fwd_kernel': 16.0,        # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0)
+    'r2l_launch_bwd1_kernel': 20.0,       # raw 4 + grad_out 12 in, dL/dY'' 4 out
+    'r2l_launch_bwd2_kernel': 8.0,        # raw 4 + dL/dY'' 4 in
+    'r2l_launch_bn_reduce_kernel': 24.0,  # grad_out 12 + saved output 12 in
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='frames per GPU')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(size):
+    """numpy oracle (port of pipeline_torch.py fwd + hand-written bwd), float32, one host thread,
+    BatchNorm train mode, on 2 frames of the workload's size; repeated until ~10 s have passed."""
+    import numpy as np
+    from oracle import isp_oracle as orc
+    B = 2
+    raw = orc.synth_raw(B, size, size, seed=0, kind='uniform')
+    cot = np.random.default_rng(1).standard_normal((B, 3, size, size)).astype(np.float32)
+    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        bn = dict(training=True, running_mean=np.zeros(3), running_var=np.ones(3))
+        _, _, c = orc.parametrized_forward(raw, P, bn=bn)
+        orc.parametrized_backward(P, c, cot)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or n >= 20:
+            break
+    return {'value': round(n * B * size * size / dt / 1e6, 3), 'unit': 'Mpix/s', 'cores': 1,
+            'kind': 'port',
+            'sample': f'{n} x (fwd+bwd of {B}x{size}x{size} frames, BN train), numpy oracle float32, '
+                      f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import numpy as np
+    from oracle import isp_oracle as orc           # synthetic inputs only (and cpu_baseline)
+    from raw2logit_amd import _lib
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    lib = _lib.device_library()                     # raises if the HIP extension is missing
+
+    B, S = args.batch, args.size
+    raw = torch.from_numpy(orc.synth_raw(B, S, S, seed=rank, kind='uniform')).to(dev)
+    cot = torch.randn((B, 3, S, S), device=dev, generator=torch.Generator(dev).manual_seed(1 + rank))
+    model = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, track_stages=False, batch_norm_output=True)
+    model = model.to(dev).train()
+    if world > 1:
+        model.process_group = dist.group.WORLD
+    params = list(model.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        y = model(raw)
+        y.backward(cot)
+        if world > 1:                                # data-parallel sum of the 132-float ISP gradient
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    px_per_step = world * B * S * S
+    value = px_per_step * args.steps / dt / 1e6
+
+    roofline = None
+    kernels = {}
+    if not args.no_roofline:
+        # second pass of the same K steps with the library's per-kernel HIP-event hooks switched on
+        lib.r2l_timing_enable(1)
+        for _ in range(args.steps):
+            step()
+        barrier()
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.r2l_timing_report(buf, len(buf))
+        lib.r2l_timing_enable(0)
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            kernels[name] = {'launches': int(cnt), 'avg_us': round(1e3 * float(ms) / int(cnt), 2)}
+        cand = {k: v for k, v in kernels.items() if k in ALGO_BYTES_PER_PX}
+        if cand:
+            total = {k: v['launches'] * v['avg_us'] for k, v in cand.items()}
+            dom = max(total, key=total.get)
+            avg_us = cand[dom]['avg_us']
+            bpp = ALGO_BYTES_PER_PX[dom]
+            if dom == 'r2l_launch_fwd_kernel':
+                # two launches per step: stats-only (4 B/px) and apply (16 B/px): average bytes
+                bpp = (4.0 + 16.0) / 2
+            achieved = B * S * S * bpp / (avg_us * 1e-6) / 1e9
+            roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
+                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                        'traffic': None, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
+
+    if rank == 0:
+        out = {
+            'metric': 'ISP Mpix/s (fwd+bwd) on 512x512 raw batches', 'value': round(value, 1),
+            'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'parametrized ISP fwd+bwd, BatchNorm train, {B}x{S}x{S} 12-bit RGGB '
+                                   f'frames per GPU, Drone camera parameters',
+                       'global_batch': world * B, 'frame': [S, S],
+                       'parallelism': f'batch shard x{world}' if world > 1 else 'single GPU',
+                       'step': 'forward + backward' + (' + 132-float grad all-reduce' if world > 1 else '')},
+            'roofline': roofline, 'kernels': kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -60,6 +60,12 @@ const char *r2l_last_error(void);
  * kernels (tests/_build/libr2l_emul.so), which the product loader refuses. */
 int r2l_is_device_build(void);
 
+/* Profiling aid for bench.py: with timing enabled every kernel launch is bracketed by hipEvents on the
+ * launch stream; r2l_timing_report() waits for them, writes "kernel_name count total_ms\n" lines into
+ * buf (NUL-terminated, truncated to n) and clears the log.  Returns the text length.               */
+void r2l_timing_enable(int on);
+int r2l_timing_report(char *buf, size_t n);
+
 /* ---- raw2rgb (processing/pipeline_torch.py:240-283; RawToRGB :43-80, NNProcessing front end :111)
  * black_level: 4 floats (R,G1,G2,B) or NULL.  out: (B,out_channels,H,W) if !reduce_size (zero-filled
  * mosaic) else (B,out_channels,H/2,W/2); out_channels in {3,4}.                                  */

@@ -384,11 +384,16 @@ def parametrized_forward(raw, P, track_stages=False, bn=None):
     return x, stages, c
 
 
-def parametrized_backward(P, c, grad_out, stage_grads=False):
+def parametrized_backward(P, c, grad_out, stage_grads=False, clip_shift=0.0):
     """Reverse pass of parametrized_forward: one VJP per forward op, in reverse order (what autograd
     does for pipeline_torch.py:183-217).  Returns (param_grads by state_dict name, grad_raw,
     stage_grads dict or None).  Stage gradients are d loss / d stages[name] as retain_grad() would
-    leave them in ``.grad`` (model.py:249-254)."""
+    leave them in ``.grad`` (model.py:249-254).
+
+    clip_shift: test aid.  torch.clip's gradient is a step function of the pre-clip value, so a pixel
+    whose pre-clip value is within float32 round-off of 1e-5 or 1 may fall on either side.  clip_shift=d
+    narrows (d>0) or widens (d<0) the pass band to [1e-5+d, 1-d]; the spread between the two bounds what
+    such pixels can contribute to any gradient."""
     dt = P.dtype
     g = np.asarray(grad_out).astype(dt)
     sg = {}
@@ -414,7 +419,7 @@ def parametrized_backward(P, c, grad_out, stage_grads=False):
     g = g * c['gam'] * inv / c['clipped']
     sg['clipped'] = g
     # torch.clip passes the gradient where min <= x <= max
-    g = g * ((c['rgb'] >= dt(1e-5)) & (c['rgb'] <= dt(1))).astype(dt)
+    g = g * ((c['rgb'] >= dt(1e-5) + dt(clip_shift)) & (c['rgb'] <= dt(1) - dt(clip_shift))).astype(dt)
     sg['gaussian'] = g
     g_yuv2 = _mix(g, P.M_YUV_2_RGB.T)
     gy, gw = conv2d_vjp(c['yuv1b'][:, :1], P.blur, 'mirror', g_yuv2[:, :1])

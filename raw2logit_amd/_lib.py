@@ -28,6 +28,8 @@ _SIGNATURES = {
     'r2l_abi_version': (ctypes.c_int, []),
     'r2l_last_error': (ctypes.c_char_p, []),
     'r2l_is_device_build': (ctypes.c_int, []),
+    'r2l_timing_enable': (None, [ctypes.c_int]),
+    'r2l_timing_report': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     'r2l_raw2rgb_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'r2l_raw2rgb_bwd_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),

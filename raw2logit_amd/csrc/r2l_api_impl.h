@@ -29,13 +29,40 @@ static int r2l_fail(int code, const std::string& msg) {
     return 0;                                                                \
   }
 #else
+// Optional per-kernel timing (bench.py's roofline leg): when enabled, every launch is bracketed by
+// hipEvents recorded on the stream the kernel is launched on; r2l_timing_report() synchronises the
+// events and returns "name count total_ms" lines.  Off by default; costs one branch per launch.
+#include <map>
+#include <mutex>
+struct R2LTimedLaunch {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+static std::mutex r2l_timing_mutex;
+static bool r2l_timing_on = false;
+static std::vector<R2LTimedLaunch> r2l_timed;
+static void r2l_time_begin(const char* name, hipStream_t s, R2LTimedLaunch& t) {
+  t.name = name;
+  hipEventCreate(&t.e0);
+  hipEventCreate(&t.e1);
+  hipEventRecord(t.e0, s);
+}
+static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
+  hipEventRecord(t.e1, s);
+  std::lock_guard<std::mutex> g(r2l_timing_mutex);
+  r2l_timed.push_back(t);
+}
 #define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS)                                           \
   __global__ __launch_bounds__(R2L_NT) void name##_kernel(const ArgsT a) {                     \
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];                             \
     blockfn(a, (int)blockIdx.x, (int)gridDim.x, lds);                                          \
   }                                                                                            \
   static int name(const ArgsT& a, int grid, void* stream) {                                    \
+    R2LTimedLaunch t_;                                                                         \
+    const bool timed_ = r2l_timing_on;                                                         \
+    if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                      \
     hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(R2L_NT), 0, (hipStream_t)stream, a);   \
+    if (timed_) r2l_time_end((hipStream_t)stream, t_);                                         \
     const hipError_t e = hipGetLastError();                                                    \
     if (e != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(e)); \
     return 0;                                                                                  \
@@ -131,6 +158,44 @@ int r2l_is_device_build(void) {
 #else
   return 1;
 #endif
+}
+
+void r2l_timing_enable(int on) {
+#ifndef R2L_EMUL
+  std::lock_guard<std::mutex> g(r2l_timing_mutex);
+  r2l_timing_on = on != 0;
+#else
+  (void)on;
+#endif
+}
+
+int r2l_timing_report(char* buf, size_t n) {
+  std::string out;
+#ifndef R2L_EMUL
+  std::vector<R2LTimedLaunch> v;
+  {
+    std::lock_guard<std::mutex> g(r2l_timing_mutex);
+    v.swap(r2l_timed);
+  }
+  std::map<std::string, std::pair<int, double>> acc;
+  for (auto& t : v) {
+    hipEventSynchronize(t.e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, t.e0, t.e1);
+    hipEventDestroy(t.e0);
+    hipEventDestroy(t.e1);
+    auto& a = acc[t.name];
+    a.first += 1;
+    a.second += ms;
+  }
+  for (auto& kv : acc)
+    out += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
+#endif
+  if (!buf || n == 0) return (int)out.size();
+  const size_t m = out.size() < n - 1 ? out.size() : n - 1;
+  memcpy(buf, out.data(), m);
+  buf[m] = 0;
+  return (int)m;
 }
 
 size_t r2l_isp_workspace_bytes(int B, int H, int W) {

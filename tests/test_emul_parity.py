@@ -1,0 +1,29 @@
+"""CPU-only: the REAL kernel source (raw2logit_amd/csrc/*.h), compiled by g++ as a host emulation
+(tests/emul/r2l_emul.cpp), driven through the product's Python modules and C ABI, against the oracle and
+the reference's golden vectors.  This pins tiling, halo, border, reduction and autograd-glue logic
+without a GPU; tests/test_gpu_parity.py repeats the same checks on the gfx950 build."""
+import pytest
+
+from oracle.golden_cases import PARAM_CASES, STATIC_CASES
+import parity_checks as pc
+
+DEVICE_STATIC = [c for c in STATIC_CASES if c['denoising'] != 'median_denoising'
+                 and not (c['debayer'] == 'malvar2004' and c['sharpening'] == 'sharpening_filter')]
+
+
+@pytest.mark.parametrize('case', PARAM_CASES, ids=[c['name'] for c in PARAM_CASES])
+def test_fused_parametrized(case, golden, emulation):
+    pc.check_param_case(case, golden, 'cpu')
+
+
+def test_raw2rgb(golden, emulation):
+    pc.check_raw2rgb(golden, 'cpu')
+
+
+@pytest.mark.parametrize('case', DEVICE_STATIC, ids=[c['name'] for c in DEVICE_STATIC])
+def test_static(case, golden, emulation):
+    pc.check_static_case(case, golden, 'cpu')
+
+
+def test_properties(emulation):
+    pc.check_ragged_and_properties('cpu')
