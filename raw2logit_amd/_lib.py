@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, 'libr2l_isp.so')
+LIB_PATH = os.environ.get('R2L_LIB_PATH') or os.path.join(_HERE, 'libr2l_isp.so')   # override: kernel A/B builds
 CSRC = os.path.join(_HERE, 'csrc')
 
 R2L_P_COUNT = 150

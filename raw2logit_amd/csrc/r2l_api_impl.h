@@ -20,6 +20,15 @@ static int r2l_fail(int code, const std::string& msg) {
 }
 
 #ifdef R2L_EMUL
+#define R2L_KERNEL_V(name, ArgsT, LDS_FLOATS, W, ...)                        \
+  static int name(const ArgsT& a, int grid, void* stream) {                  \
+    (void)stream;                                                            \
+    std::vector<float> buf((size_t)(LDS_FLOATS) + 8);                        \
+    float* lds = (float*)(((uintptr_t)buf.data() + 15) & ~(uintptr_t)15);    \
+    for (int b = 0; b < grid; ++b) __VA_ARGS__(a, b, grid, lds);             \
+    return 0;                                                                \
+  }
+#define R2L_KERNEL_OCC(name, ArgsT, blockfn, LDS_FLOATS, W) R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS)
 #define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS)                         \
   static int name(const ArgsT& a, int grid, void* stream) {                  \
     (void)stream;                                                            \
@@ -52,8 +61,24 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
   std::lock_guard<std::mutex> g(r2l_timing_mutex);
   r2l_timed.push_back(t);
 }
-#define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS)                                           \
-  __global__ __launch_bounds__(R2L_NT) void name##_kernel(const ArgsT a) {                     \
+#define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS) R2L_KERNEL_OCC(name, ArgsT, blockfn, LDS_FLOATS, 1)
+#define R2L_KERNEL_V(name, ArgsT, LDS_FLOATS, WAVES_PER_SIMD, ...)                             \
+  __global__ __launch_bounds__(R2L_NT, WAVES_PER_SIMD) void name##_kernel(const ArgsT a) {     \
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];                             \
+    __VA_ARGS__(a, (int)blockIdx.x, (int)gridDim.x, lds);                                      \
+  }                                                                                            \
+  static int name(const ArgsT& a, int grid, void* stream) {                                    \
+    R2LTimedLaunch t_;                                                                         \
+    const bool timed_ = r2l_timing_on;                                                         \
+    if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                      \
+    hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(R2L_NT), 0, (hipStream_t)stream, a);   \
+    if (timed_) r2l_time_end((hipStream_t)stream, t_);                                         \
+    const hipError_t e = hipGetLastError();                                                    \
+    if (e != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(e)); \
+    return 0;                                                                                  \
+  }
+#define R2L_KERNEL_OCC(name, ArgsT, blockfn, LDS_FLOATS, WAVES_PER_SIMD)                       \
+  __global__ __launch_bounds__(R2L_NT, WAVES_PER_SIMD) void name##_kernel(const ArgsT a) {                     \
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];                             \
     blockfn(a, (int)blockIdx.x, (int)gridDim.x, lds);                                          \
   }                                                                                            \
@@ -73,17 +98,31 @@ typedef R2LGeom<64, 64> GFwd;
 typedef R2LGeom<64, 64> GBwd1;
 typedef R2LGeom<64, 64> GBwd2;
 
-#define R2L_LDS3(G) (2 * G::PAD + 3 * G::PLANE)
-#define R2L_LDS4(G) (2 * G::PAD + 4 * G::PLANE)
+#define R2L_LDS3(G) (R2L_FOLDED_FLOATS + 2 * G::PAD + 3 * G::PLANE)
+#define R2L_LDS4(G) (R2L_FOLDED_FLOATS + 2 * G::PAD + 4 * G::PLANE)
 static_assert(R2L_LDS3(GFwd) >= R2L_RED_FLOATS, "reduction scratch must fit");
-static_assert(R2L_LDS4(GBwd2) >= R2L_RED_FLOATS, "reduction scratch must fit");
+static_assert(R2L_LDS3(GBwd2) >= R2L_RED_FLOATS, "reduction scratch must fit");
 
 R2L_KERNEL(r2l_launch_fold, R2LFoldArgs, r2l_fold_block, 4)
 R2L_KERNEL(r2l_launch_unfold, R2LUnfoldArgs, r2l_unfold_block, 4)
 R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 * R2L_NT)
-R2L_KERNEL(r2l_launch_fwd, R2LFwdArgs, r2l_fwd_block<GFwd>, R2L_LDS3(GFwd))
-R2L_KERNEL(r2l_launch_bwd1, R2LBwd1Args, r2l_bwd1_block<GBwd1>, R2L_LDS3(GBwd1))
-R2L_KERNEL(r2l_launch_bwd2, R2LBwd2Args, r2l_bwd2_block<GBwd2>, R2L_LDS4(GBwd2))
+#ifndef R2L_OCC_FWD
+#define R2L_OCC_FWD 2
+#endif
+#ifndef R2L_OCC_BWD1
+#define R2L_OCC_BWD1 1
+#endif
+#ifndef R2L_OCC_BWD2
+#define R2L_OCC_BWD2 1
+#endif
+// hot instantiation (frames that tile exactly, no additive layer) + the general ones
+R2L_KERNEL_V(r2l_launch_fwd, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false>)
+R2L_KERNEL_V(r2l_launch_fwd_ragged, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true>)
+R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, true, true>)
+R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false>)
+R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true>)
+R2L_KERNEL_OCC(r2l_launch_bwd2, R2LBwd2Args, r2l_bwd2_block<GBwd2>, R2L_LDS3(GBwd2), R2L_OCC_BWD2)
 R2L_KERNEL(r2l_launch_bn_reduce, R2LBnReduceArgs, r2l_bn_reduce_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_add_bwd, R2LAddBwdArgs, r2l_add_bwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_fwd, R2LRaw2RgbArgs, r2l_raw2rgb_fwd_block, 4)
@@ -144,6 +183,7 @@ static int r2l_check_dims(int B, int H, int W) {
   if (B < 1) return r2l_fail(-1, "B must be >= 1");
   if (H < 4 || W < 4 || (H & 1) || (W & 1))
     return r2l_fail(-1, "H and W must be even and >= 4 (Bayer quads; 5x5 mirror padding)");
+  if ((size_t)H * W > ((size_t)1 << 29)) return r2l_fail(-1, "frames above 2^29 pixels are not supported");
   if ((size_t)B * H * W > ((size_t)1 << 40)) return r2l_fail(-1, "batch too large");
   return 0;
 }
@@ -229,7 +269,10 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
   a.B = B;
   a.H = H;
   a.W = W;
-  if (int e = r2l_launch_fwd(a, grid, stream)) return e;
+  const bool exact = (H % GFwd::TH == 0) && (W % GFwd::TW == 0);
+  if (int e = additive ? r2l_launch_fwd_add(a, grid, stream)
+                       : (exact ? r2l_launch_fwd(a, grid, stream) : r2l_launch_fwd_ragged(a, grid, stream)))
+    return e;
   if (stats) {
     R2LReduceRowsArgs r{ws.part_small, stats, grid, 1.0};
     if (int e = r2l_launch_reduce_rows(r, 6, stream)) return e;
@@ -283,9 +326,12 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   a1.B = B;
   a1.H = H;
   a1.W = W;
-  if (int e = r2l_launch_bwd1(a1, g1, stream)) return e;
+  const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
+  if (int e = additive ? r2l_launch_bwd1_add(a1, g1, stream)
+                       : (exact ? r2l_launch_bwd1(a1, g1, stream) : r2l_launch_bwd1_ragged(a1, g1, stream)))
+    return e;
   const int ntiles2 = B * ((H + GBwd2::TH - 1) / GBwd2::TH) * ((W + GBwd2::TW - 1) / GBwd2::TW);
-  const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", 256));
+  const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", 512));
   R2LBwd2Args a2;
   a2.raw = raw;
   a2.F = ws.folded;

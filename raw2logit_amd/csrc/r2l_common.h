@@ -13,10 +13,11 @@
 
 #include "../../include/r2l_isp.h"
 
-#define R2L_NT 256  // threads per workgroup: 4 wavefronts of 64
+#define R2L_NT 512  // threads per workgroup: 8 wavefronts of 64 (two per SIMD)
 
 #ifdef R2L_EMUL
 #define R2L_HD static inline
+#define R2L_MEMBER inline
 #define R2L_BLOCKFN static inline
 struct alignas(16) r2l_f4 {
   float x, y, z, w;
@@ -32,9 +33,12 @@ R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
 #define R2L_TREG_DECL(type, name) type name##_all[R2L_NT]
 #define R2L_TREG(name) name##_all[tid]
 #define R2L_PRAGMA_UNROLL
+#define R2L_PRAGMA_NOUNROLL
+#define R2L_SCHED_FENCE()
 #else
 #include <hip/hip_runtime.h>
 #define R2L_HD static __device__ __forceinline__
+#define R2L_MEMBER __device__ __forceinline__
 #define R2L_BLOCKFN static __device__ __forceinline__
 typedef float4 r2l_f4;
 typedef float2 r2l_f2;
@@ -46,12 +50,41 @@ R2L_HD float r2l_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #define R2L_PHASE_BEGIN \
   {                     \
     const int tid = threadIdx.x;
-#define R2L_PHASE_END \
-  }                   \
-  __syncthreads();
+// A phase boundary only orders LDS traffic between the waves of the workgroup.  __syncthreads() would
+// also wait for every outstanding global store (s_waitcnt vmcnt(0)), i.e. expose the full HBM write
+// latency of the previous tile's output at every barrier; the raw barrier below waits for LDS only.
+// (Global loads feeding a ds_write are waited for by the compiler at the ds_write itself.)
+#define R2L_PHASE_END                                               \
+  }                                                                 \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define R2L_TREG_DECL(type, name) type name
 #define R2L_TREG(name) name
 #define R2L_PRAGMA_UNROLL _Pragma("unroll")
+#define R2L_PRAGMA_NOUNROLL _Pragma("unroll 1")
+// keeps the scheduler from hoisting the scalar loads of LATER weights above this point (their live
+// ranges would overflow the SGPR file and be spilled to VGPR lanes)
+#define R2L_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// 128-bit LDS read that stays one ds_read_b128: without the empty asm hipcc scalarises the vector load
+// (it is only used element-wise), then re-merges the pieces with neighbouring scalar reads into
+// ds_read2_b32 / ds_read_b96 groups whose lane stride of 16 B is a 4-way bank conflict (measured:
+// SQ_LDS_BANK_CONFLICT = 68 % of SQ_LDS_IDX_ACTIVE).
+#ifdef R2L_EMUL
+R2L_HD r2l_f4 r2l_lds_f4(const float* p) { return *(const r2l_f4*)p; }
+#else
+typedef float r2l_v4 __attribute__((ext_vector_type(4)));
+R2L_HD r2l_f4 r2l_lds_f4(const float* p) {
+  // volatile: the access may neither be split nor merged with neighbours, but several of them can
+  // still be in flight together (an asm pin on the value would serialise load -> wait -> load)
+  const r2l_v4 v = *(const volatile __attribute__((address_space(3))) r2l_v4*)p;
+  r2l_f4 o;
+  o.x = v.x;
+  o.y = v.y;
+  o.z = v.z;
+  o.w = v.w;
+  return o;
+}
 #endif
 
 #define R2L_LN2 0.69314718055994530942
@@ -96,7 +129,10 @@ struct R2LFolded {
 };
 
 // The kernels read the folded block through the CONSTANT address space so that every weight is a
-// scalar load (s_load -> SGPR operand of v_fma), never a per-lane VGPR.
+// scalar load (s_load -> SGPR operand of v_fmac), never a per-lane VGPR.  The SGPR file holds ~100
+// values, fewer than the ~150 weights: the pixel code therefore works one output row at a time and
+// launders the pointer (r2l_opaque) per row, so that hipcc re-issues the scalar loads of that row's
+// weights instead of hoisting all of them to the top and spilling SGPRs into VGPR lanes.
 #ifdef R2L_EMUL
 typedef const R2LFolded& R2LFoldedRef;
 #define R2L_FOLDED_REF(ptr) (*(ptr))
@@ -104,6 +140,13 @@ typedef const R2LFolded& R2LFoldedRef;
 typedef const __attribute__((address_space(4))) R2LFolded& R2LFoldedRef;
 #define R2L_FOLDED_REF(ptr) (*(const __attribute__((address_space(4))) R2LFolded*)(ptr))
 #endif
+#define R2L_FOLDED_FLOATS 0
+R2L_HD const R2LFolded* r2l_opaque(const R2LFolded* p) {
+#ifndef R2L_EMUL
+  asm volatile("" : "+s"(p));
+#endif
+  return p;
+}
 
 R2L_HD void r2l_fold_params(const float* P, R2LFolded* F) {
   double T[3][3];

@@ -22,18 +22,29 @@ struct R2LGeom {
   static constexpr int FS = ((FW + 2 + 15) / 16) * 16;
   static constexpr int PLANE = FH * FS;
   static constexpr int PAD = 16;  // leading floats so that index -1 of plane 0 stays inside LDS
-  static constexpr int TXN = TW / 4, TYN = TH / 4;  // micro-tiles per tile row / column
-  static_assert(TXN * TYN == R2L_NT, "one 4x4 micro-tile per thread");
+  // Pixel phase: each thread owns 4 columns x 2 rows OF THE SAME BAYER ROW PARITY (rows r and r+2).
+  // A wavefront is 16 threads across x 4 down; its 16-lane groups sit 4 pixel rows apart, so with FS a
+  // multiple of 16 floats their 128-bit LDS reads fall on distinct banks.  The row parity is uniform per
+  // wavefront, which halves the per-thread accumulators of the parity-indexed weight gradients.
+  static constexpr int TXN = TW / 4;
+  static_assert(TW == 64 && TH == 64 && R2L_NT == 512, "thread -> micro-tile map");
+  static R2L_MEMBER void thread_tile(int tid, int& tx, int& row0, int& py) {
+    tx = tid & 15;
+    const int q = (tid >> 4) & 3, w = tid >> 6;
+    py = w & 1;
+    row0 = 16 * (w >> 1) + 4 * q + py;  // second row: row0 + 2
+  }
 };
 
 template <class G, int NPLANES>
 constexpr size_t r2l_lds_bytes() {
-  return sizeof(float) * (size_t)(2 * G::PAD + NPLANES * G::PLANE);
+  return sizeof(float) * (size_t)(R2L_FOLDED_FLOATS + 2 * G::PAD + NPLANES * G::PLANE);
 }
 
 struct R2LTile {
   int b, oy, ox;  // image index, tile origin (global coordinates of tile pixel (0,0))
-  bool border;    // the frame leaves the image somewhere
+  bool border;    // the frame leaves the image somewhere (loads / extensions need the padding rules)
+  bool ragged;    // the tile itself leaves the image, or W % 4 != 0 (stores need per-pixel predicates)
 };
 
 // XCD-aware tile walk: workgroup ids are dealt round-robin over the 8 XCDs (each with a private L2),
@@ -63,74 +74,135 @@ R2L_HD bool r2l_walk_next(R2LTileWalk& w, int H, int W, int TW, int TH, R2LTile&
     t.b = r / w.nty;
     t.oy = (r % w.nty) * TH;
     t.ox = tx * TW;
-    t.border = (t.oy < 4) || (t.ox < 4) || (t.oy + TH + 4 > H) || (t.ox + TW + 4 > W);
+    t.border = (t.oy < 4) || (t.ox < 4) || (t.oy + TH + 4 > H) || (t.ox + TW + 4 > W) || ((W & 3) != 0);
+    t.ragged = (t.oy + TH > H) || (t.ox + TW > W) || ((W & 3) != 0);
     return true;
   }
   return false;
 }
 
 // ---- phase A: raw tile + halo -> V -------------------------------------------------------------
+// Work item = one float4 chunk of the frame; item ids tid, tid+256, ... are walked with incremental
+// (row, chunk) updates instead of a division per item.
 template <class G>
+struct R2LChunkWalk {
+  static constexpr int CPR = G::FW / 4;            // chunks per frame row
+  static constexpr int DROW = R2L_NT / CPR, DCOL = R2L_NT % CPR;
+  int fy, cx;
+  R2L_MEMBER void init(int tid) {
+    fy = tid / CPR;
+    cx = tid - fy * CPR;
+  }
+  R2L_MEMBER void next() {
+    fy += DROW;
+    cx += DCOL;
+    if (cx >= CPR) {
+      cx -= CPR;
+      fy += 1;
+    }
+  }
+};
+
+template <class G, bool BORDER>
 R2L_HD void r2l_load_v(int tid, float* V, const float* rawb, R2LFoldedRef F, int oy, int ox, int H,
                        int W) {
-  constexpr int CPR = G::FW / 4;
+  R2LChunkWalk<G> w;
+  w.init(tid);
+  constexpr int NIT = (R2LChunkWalk<G>::CPR * G::FH + R2L_NT - 1) / R2L_NT;
   const bool vec_ok = (W & 3) == 0;
-  for (int ci = tid; ci < CPR * G::FH; ci += R2L_NT) {
-    const int fy = ci / CPR, cx = ci - fy * CPR;
-    const int gy = r2l_mirror(oy - 4 + fy, H);
-    const int gx0 = ox - 4 + 4 * cx;
-    const float* row = rawb + (size_t)gy * W;
-    r2l_f4 v;
-    if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
-      v = *(const r2l_f4*)(row + gx0);
-    } else {
-      v.x = row[r2l_mirror(gx0, W)];
-      v.y = row[r2l_mirror(gx0 + 1, W)];
-      v.z = row[r2l_mirror(gx0 + 2, W)];
-      v.w = row[r2l_mirror(gx0 + 3, W)];
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < NIT; ++it) {
+    if (w.fy < G::FH) {
+      const int fy = w.fy, cx = w.cx;
+      const int gx0 = ox - 4 + 4 * cx;
+      r2l_f4 v;
+      if (!BORDER) {
+        v = *(const r2l_f4*)(rawb + (size_t)(oy - 4 + fy) * W + gx0);
+      } else {
+        const int gy = r2l_mirror(oy - 4 + fy, H);
+        const float* row = rawb + (size_t)gy * W;
+        if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
+          v = *(const r2l_f4*)(row + gx0);
+        } else {
+          v.x = row[r2l_mirror(gx0, W)];
+          v.y = row[r2l_mirror(gx0 + 1, W)];
+          v.z = row[r2l_mirror(gx0 + 2, W)];
+          v.w = row[r2l_mirror(gx0 + 3, W)];
+        }
+      }
+      // mirror padding keeps the Bayer parity, so the site follows from the frame coordinates
+      const float b0 = (fy & 1) ? F.bl[2] : F.bl[0], b1 = (fy & 1) ? F.bl[3] : F.bl[1];
+      v.x -= b0;
+      v.y -= b1;
+      v.z -= b0;
+      v.w -= b1;
+      *(r2l_f4*)(V + fy * G::FS + 4 * cx) = v;
     }
-    // mirror padding keeps the Bayer parity, so the site follows from the frame coordinates
-    const float b0 = F.bl[(fy & 1) * 2], b1 = F.bl[(fy & 1) * 2 + 1];
-    v.x -= b0;
-    v.y -= b1;
-    v.z -= b0;
-    v.w -= b1;
-    *(r2l_f4*)(V + fy * G::FS + 4 * cx) = v;
+    w.next();
   }
 }
 
 // a plane of the frame from a (B,H,W) global plane, ZERO outside the image, stored shifted by +2
-template <class G>
+template <class G, bool BORDER>
 R2L_HD void r2l_load_plane_zero_s2(int tid, float* Pl, const float* gb, int oy, int ox, int H, int W) {
-  constexpr int CPR = G::FW / 4;
+  R2LChunkWalk<G> w;
+  w.init(tid);
+  constexpr int NIT = (R2LChunkWalk<G>::CPR * G::FH + R2L_NT - 1) / R2L_NT;
   const bool vec_ok = (W & 3) == 0;
-  for (int ci = tid; ci < CPR * G::FH; ci += R2L_NT) {
-    const int fy = ci / CPR, cx = ci - fy * CPR;
-    const int gy = oy - 4 + fy;
-    const int gx0 = ox - 4 + 4 * cx;
-    r2l_f4 v;
-    v.x = v.y = v.z = v.w = 0.f;
-    if ((unsigned)gy < (unsigned)H) {
-      const float* row = gb + (size_t)gy * W;
-      if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
-        v = *(const r2l_f4*)(row + gx0);
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < NIT; ++it) {
+    if (w.fy < G::FH) {
+      const int fy = w.fy, cx = w.cx;
+      const int gy = oy - 4 + fy;
+      const int gx0 = ox - 4 + 4 * cx;
+      r2l_f4 v;
+      if (!BORDER) {
+        v = *(const r2l_f4*)(gb + (size_t)gy * W + gx0);
       } else {
-        if ((unsigned)(gx0) < (unsigned)W) v.x = row[gx0];
-        if ((unsigned)(gx0 + 1) < (unsigned)W) v.y = row[gx0 + 1];
-        if ((unsigned)(gx0 + 2) < (unsigned)W) v.z = row[gx0 + 2];
-        if ((unsigned)(gx0 + 3) < (unsigned)W) v.w = row[gx0 + 3];
+        v.x = v.y = v.z = v.w = 0.f;
+        if ((unsigned)gy < (unsigned)H) {
+          const float* row = gb + (size_t)gy * W;
+          if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
+            v = *(const r2l_f4*)(row + gx0);
+          } else {
+            if ((unsigned)(gx0) < (unsigned)W) v.x = row[gx0];
+            if ((unsigned)(gx0 + 1) < (unsigned)W) v.y = row[gx0 + 1];
+            if ((unsigned)(gx0 + 2) < (unsigned)W) v.z = row[gx0 + 2];
+            if ((unsigned)(gx0 + 3) < (unsigned)W) v.w = row[gx0 + 3];
+          }
+        }
       }
+      float* d = Pl + fy * G::FS + 4 * cx + 2;
+      r2l_f2 lo, hi;
+      lo.x = v.x;
+      lo.y = v.y;
+      hi.x = v.z;
+      hi.y = v.w;
+      *(r2l_f2*)d = lo;
+      *(r2l_f2*)(d + 2) = hi;
     }
-    float* d = Pl + fy * G::FS + 4 * cx + 2;
-    r2l_f2 lo, hi;
-    lo.x = v.x;
-    lo.y = v.y;
-    hi.x = v.z;
-    hi.y = v.w;
-    *(r2l_f2*)d = lo;
-    *(r2l_f2*)(d + 2) = hi;
+    w.next();
   }
 }
+
+// walk of work items laid out as NROW rows of CPR items, ids tid, tid+256, ...
+template <int CPR>
+struct R2LItemWalk {
+  static constexpr int DROW = R2L_NT / CPR, DCOL = R2L_NT % CPR;
+  int row, col;
+  R2L_MEMBER void init(int tid) {
+    row = tid / CPR;
+    col = tid - row * CPR;
+  }
+  R2L_MEMBER void next() {
+    row += DROW;
+    col += DCOL;
+    if (col >= CPR) {
+      col -= CPR;
+      row += 1;
+    }
+  }
+};
 
 // 4 rows x 6 columns window around a 4-wide x 2-tall item at (fy, fx): rows fy-1..fy+2,
 // columns fx-1..fx+4 of an UNSHIFTED plane
@@ -138,50 +210,64 @@ template <class G>
 R2L_HD void r2l_window_4x6(const float* Pl, int fy, int fx, float w[4][6]) {
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 4; ++i) {
-    const float* r = Pl + (fy - 1 + i) * G::FS + fx;
-    w[i][0] = r[-1];
-    const r2l_f4 m = *(const r2l_f4*)r;
+    const float* r = Pl + (fy - 1 + i) * G::FS + fx;  // three aligned 128-bit reads: cols fx-4..fx+7
+    const r2l_f4 l = r2l_lds_f4(r - 4);
+    const r2l_f4 m = r2l_lds_f4(r);
+    const r2l_f4 h = r2l_lds_f4(r + 4);
+    w[i][0] = l.w;
     w[i][1] = m.x;
     w[i][2] = m.y;
     w[i][3] = m.z;
     w[i][4] = m.w;
-    w[i][5] = r[4];
+    w[i][5] = h.x;
   }
 }
 
 // ---- phase B: Y on frame rows/cols [1, F-1) ------------------------------------------------------
-template <class G>
+template <class G, bool BORDER>
 R2L_HD void r2l_compute_y(int tid, const float* V, float* Y, R2LFoldedRef F, int oy, int ox, int H,
                           int W) {
   constexpr int CPR = G::FW / 4, NRP = (G::FH - 2) / 2;
-  for (int it = tid; it < CPR * NRP; it += R2L_NT) {
-    const int rp = it / CPR, cx = it - rp * CPR;
-    const int fy = 1 + 2 * rp, fx = 4 * cx;  // fy is odd
-    float w[4][6];
-    r2l_window_4x6<G>(V, fy, fx, w);
-    R2L_PRAGMA_UNROLL
-    for (int r = 0; r < 2; ++r) {
-      const int gy = oy - 4 + fy + r;
-      const bool yin = (unsigned)gy < (unsigned)H;
-      float o[4];
+  constexpr int NIT = (CPR * NRP + R2L_NT - 1) / R2L_NT;
+  R2LItemWalk<CPR> iw;
+  iw.init(tid);
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < NIT; ++it) {
+    if (iw.row < NRP) {
+      const int fy = 1 + 2 * iw.row, fx = 4 * iw.col;  // fy is odd
+      float w[4][6];
+      r2l_window_4x6<G>(V, fy, fx, w);
       R2L_PRAGMA_UNROLL
-      for (int c = 0; c < 4; ++c) {
-        const int par = (((1 + r) & 1) << 1) | (c & 1);
-        float s = 0.f;
+      for (int r = 0; r < 2; ++r) {
+        float o[4];
         R2L_PRAGMA_UNROLL
-        for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 4; ++c) {
+          const int par = (((1 + r) & 1) << 1) | (c & 1);
+          float s = 0.f;
           R2L_PRAGMA_UNROLL
-        for (int j = 0; j < 3; ++j) s = fmaf(F.AY[par][i * 3 + j], w[r + i][c + j], s);
-        const int gx = ox - 4 + fx + c;
-        o[c] = (yin && (unsigned)gx < (unsigned)W) ? s : 0.f;  // zero padding of the sharpen conv
+          for (int i = 0; i < 3; ++i)
+            R2L_PRAGMA_UNROLL
+          for (int j = 0; j < 3; ++j) s = fmaf(F.AY[par][i * 3 + j], w[r + i][c + j], s);
+          o[c] = s;
+        }
+        if (BORDER) {  // zero padding of the sharpen conv: Y is 0 outside the image
+          const int gy = oy - 4 + fy + r;
+          const bool yin = (unsigned)gy < (unsigned)H;
+          R2L_PRAGMA_UNROLL
+          for (int c = 0; c < 4; ++c) {
+            const int gx = ox - 4 + fx + c;
+            o[c] = (yin && (unsigned)gx < (unsigned)W) ? o[c] : 0.f;
+          }
+        }
+        r2l_f4 st;
+        st.x = o[0];
+        st.y = o[1];
+        st.z = o[2];
+        st.w = o[3];
+        *(r2l_f4*)(Y + (fy + r) * G::FS + fx) = st;
       }
-      r2l_f4 st;
-      st.x = o[0];
-      st.y = o[1];
-      st.z = o[2];
-      st.w = o[3];
-      *(r2l_f4*)(Y + (fy + r) * G::FS + fx) = st;
     }
+    iw.next();
   }
 }
 
@@ -189,32 +275,38 @@ R2L_HD void r2l_compute_y(int tid, const float* V, float* Y, R2LFoldedRef F, int
 template <class G>
 R2L_HD void r2l_compute_yp(int tid, const float* Y, float* YP, R2LFoldedRef F) {
   constexpr int CPR = G::FW / 4, NRP = (G::FH - 4) / 2;
-  for (int it = tid; it < CPR * NRP; it += R2L_NT) {
-    const int rp = it / CPR, cx = it - rp * CPR;
-    const int fy = 2 + 2 * rp, fx = 4 * cx;
-    float w[4][6];
-    r2l_window_4x6<G>(Y, fy, fx, w);
-    R2L_PRAGMA_UNROLL
-    for (int r = 0; r < 2; ++r) {
-      float o[4];
+  constexpr int NIT = (CPR * NRP + R2L_NT - 1) / R2L_NT;
+  R2LItemWalk<CPR> iw;
+  iw.init(tid);
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < NIT; ++it) {
+    if (iw.row < NRP) {
+      const int fy = 2 + 2 * iw.row, fx = 4 * iw.col;
+      float w[4][6];
+      r2l_window_4x6<G>(Y, fy, fx, w);
       R2L_PRAGMA_UNROLL
-      for (int c = 0; c < 4; ++c) {
-        float s = 0.f;
+      for (int r = 0; r < 2; ++r) {
+        float o[4];
         R2L_PRAGMA_UNROLL
-        for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 4; ++c) {
+          float s = 0.f;
           R2L_PRAGMA_UNROLL
-        for (int j = 0; j < 3; ++j) s = fmaf(F.sharp[i * 3 + j], w[r + i][c + j], s);
-        o[c] = s;
+          for (int i = 0; i < 3; ++i)
+            R2L_PRAGMA_UNROLL
+          for (int j = 0; j < 3; ++j) s = fmaf(F.sharp[i * 3 + j], w[r + i][c + j], s);
+          o[c] = s;
+        }
+        float* d = YP + (fy + r) * G::FS + fx + 2;
+        r2l_f2 lo, hi;
+        lo.x = o[0];
+        lo.y = o[1];
+        hi.x = o[2];
+        hi.y = o[3];
+        *(r2l_f2*)d = lo;
+        *(r2l_f2*)(d + 2) = hi;
       }
-      float* d = YP + (fy + r) * G::FS + fx + 2;
-      r2l_f2 lo, hi;
-      lo.x = o[0];
-      lo.y = o[1];
-      hi.x = o[2];
-      hi.y = o[3];
-      *(r2l_f2*)d = lo;
-      *(r2l_f2*)(d + 2) = hi;
     }
+    iw.next();
   }
 }
 
@@ -232,15 +324,19 @@ R2L_HD void r2l_fill_yp_mirror(int tid, float* YP, int oy, int ox, int H, int W)
   }
 }
 
-// ---- phase D helpers: one 4x4 micro-tile per thread ----------------------------------------------
-// 8x8 window of YP (rows fy0-2..fy0+5, cols fx0-2..fx0+5; fx0 = 4*tx+4, plane shifted by +2)
+// ---- phase D helpers: each thread owns a 4x4 micro-tile and walks it ONE OUTPUT ROW AT A TIME -------
+// (a fully unrolled 4x4 body keeps all ~150 weights and a 8x8 + 6x6 window live at once, which hipcc
+// answers with SGPR->VGPR-lane spills; per row the working set is 5x8 + 3x6 values and <= 70 weights)
+
+// 5 rows x 8 columns of YP around output row `frow` (frame row of the output pixel row): rows
+// frow-2..frow+2, columns fx0-2..fx0+5 with fx0 = 4*tx+4 (the plane is stored shifted by +2)
 template <class G>
-R2L_HD void r2l_window_yp(const float* YP, int tx, int ty, float yw[8][8]) {
+R2L_HD void r2l_rows_yp(const float* YP, int tx, int frow, float yw[5][8]) {
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 8; ++i) {
-    const float* r = YP + (4 * ty + 2 + i) * G::FS + 4 * tx + 4;
-    const r2l_f4 a = *(const r2l_f4*)r;
-    const r2l_f4 b = *(const r2l_f4*)(r + 4);
+  for (int i = 0; i < 5; ++i) {
+    const float* r = YP + (frow - 2 + i) * G::FS + 4 * tx + 4;
+    const r2l_f4 a = r2l_lds_f4(r);
+    const r2l_f4 b = r2l_lds_f4(r + 4);
     yw[i][0] = a.x;
     yw[i][1] = a.y;
     yw[i][2] = a.z;
@@ -251,52 +347,55 @@ R2L_HD void r2l_window_yp(const float* YP, int tx, int ty, float yw[8][8]) {
     yw[i][7] = b.w;
   }
 }
-// 6x6 window of an unshifted plane (rows fy0-1..fy0+4, cols fx0-1..fx0+4)
+// 3 rows x 6 columns of an unshifted plane around output row `frow`: rows frow-1..frow+1, columns
+// fx0-1..fx0+4, fetched as three aligned 128-bit reads per row (cols fx0-4..fx0+7)
 template <class G>
-R2L_HD void r2l_window_6x6(const float* Pl, int tx, int ty, float w[6][6]) {
+R2L_HD void r2l_rows_3x6(const float* Pl, int tx, int frow, float w[3][6]) {
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 6; ++i) {
-    const float* r = Pl + (4 * ty + 3 + i) * G::FS + 4 * tx + 4;
-    w[i][0] = r[-1];
-    const r2l_f4 m = *(const r2l_f4*)r;
+  for (int i = 0; i < 3; ++i) {
+    const float* r = Pl + (frow - 1 + i) * G::FS + 4 * tx + 4;
+    const r2l_f4 l = r2l_lds_f4(r - 4);
+    const r2l_f4 m = r2l_lds_f4(r);
+    const r2l_f4 h = r2l_lds_f4(r + 4);
+    w[i][0] = l.w;
     w[i][1] = m.x;
     w[i][2] = m.y;
     w[i][3] = m.z;
     w[i][4] = m.w;
-    w[i][5] = r[4];
+    w[i][5] = h.x;
   }
 }
 
-R2L_HD void r2l_blur_4x4(const float yw[8][8], R2LFoldedRef F, float ypp[4][4]) {
+R2L_HD void r2l_blur_row(const float yw[5][8], R2LFoldedRef F, float ypp[4]) {
   R2L_PRAGMA_UNROLL
-  for (int r = 0; r < 4; ++r)
+  for (int c = 0; c < 4; ++c) ypp[c] = 0.f;
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 5; ++i)
     R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) {
-    float s = 0.f;
+  for (int j = 0; j < 5; ++j) {
+    const float w = F.blur[i * 5 + j];
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 5; ++i)
-      R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 5; ++j) s = fmaf(F.blur[i * 5 + j], yw[r + i][c + j], s);
-    ypp[r][c] = s;
+    for (int c = 0; c < 4; ++c) ypp[c] = fmaf(w, yw[i][c + j], ypp[c]);
   }
 }
 
-R2L_HD void r2l_chroma_4x4(const float vw[6][6], R2LFoldedRef F, float u[4][4], float v[4][4]) {
+// chroma of one output row with row parity PY (pixel column parity = c & 1)
+template <int PY>
+R2L_HD void r2l_chroma_row(const float vw[3][6], R2LFoldedRef F, float u[4], float v[4]) {
   R2L_PRAGMA_UNROLL
-  for (int r = 0; r < 4; ++r)
+  for (int c = 0; c < 4; ++c) u[c] = v[c] = 0.f;
+  R2L_PRAGMA_UNROLL
+  for (int px = 0; px < 2; ++px)
     R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) {
-    const int par = ((r & 1) << 1) | (c & 1);
-    float su = 0.f, sv = 0.f;
+  for (int i = 0; i < 3; ++i)
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 3; ++i)
-      R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 3; ++j) {
-      su = fmaf(F.AU[par][i * 3 + j], vw[r + i][c + j], su);
-      sv = fmaf(F.AV[par][i * 3 + j], vw[r + i][c + j], sv);
+  for (int j = 0; j < 3; ++j) {
+    const float wu = F.AU[PY * 2 + px][i * 3 + j], wv = F.AV[PY * 2 + px][i * 3 + j];
+    R2L_PRAGMA_UNROLL
+    for (int c = px; c < 4; c += 2) {
+      u[c] = fmaf(wu, vw[i][c + j], u[c]);
+      v[c] = fmaf(wv, vw[i][c + j], v[c]);
     }
-    u[r][c] = su;
-    v[r][c] = sv;
   }
 }
 
@@ -317,25 +416,78 @@ struct R2LFwdRegs {
   float acc[6];
 };
 
-template <class G>
+template <class G, int PY, bool RAGGED, bool ADD>
+R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, int tx, int frow, int gx0,
+                        unsigned off0, unsigned plane, float* ob, const float mean[3],
+                        const float istd[3], R2LFwdRegs& regs) {
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
+  float ypp[4], u[4], v[4];
+  {
+    float yw[5][8];
+    r2l_rows_yp<G>(YP, tx, frow, yw);
+    r2l_blur_row(yw, F, ypp);
+  }
+  {
+    float vw[3][6];
+    r2l_rows_3x6<G>(V, tx, frow, vw);
+    r2l_chroma_row<PY>(vw, F, u, v);
+  }
+  const bool vec_ok = !RAGGED || (((a.W & 3) == 0) && (gx0 + 3 < a.W));
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) {
+    float x[4];
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      float rgb = F.M2[k * 3] * ypp[c];
+      rgb = fmaf(F.M2[k * 3 + 1], u[c], rgb);
+      rgb = fmaf(F.M2[k * 3 + 2], v[c], rgb);
+      const float xc = fminf(fmaxf(rgb, 1e-5f), 1.0f);          // :206
+      x[c] = r2l_exp2(r2l_log2(xc) * F.inv_gamma);              // :209
+    }
+    const unsigned off = (unsigned)k * plane + off0;
+    if (ADD) {                                                 // :213 (H == W == 256)
+      R2L_PRAGMA_UNROLL
+      for (int c = 0; c < 4; ++c)
+        if (!RAGGED || gx0 + c < a.W) x[c] += a.additive[off + c];
+    }
+    if (a.stat_partial) {
+      R2L_PRAGMA_UNROLL
+      for (int c = 0; c < 4; ++c)
+        if (!RAGGED || gx0 + c < a.W) {
+          const float d = x[c] - 0.5f;
+          regs.acc[k] += d;
+          regs.acc[3 + k] = fmaf(d, d, regs.acc[3 + k]);
+        }
+    }
+    if (ob) {
+      R2L_PRAGMA_UNROLL
+      for (int c = 0; c < 4; ++c) x[c] = (x[c] - mean[k]) * istd[k];  // :217
+      if (vec_ok) {
+        r2l_f4 st;
+        st.x = x[0];
+        st.y = x[1];
+        st.z = x[2];
+        st.w = x[3];
+        *(r2l_f4*)(ob + off) = st;
+      } else {
+        R2L_PRAGMA_UNROLL
+        for (int c = 0; c < 4; ++c)
+          if (gx0 + c < a.W) ob[off + c] = x[c];
+      }
+    }
+  }
+}
+
+template <class G, bool RAGGED, bool ADD>
 R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFwdArgs& a,
-                           R2LFoldedRef F, const R2LTile& t, R2LFwdRegs& regs) {
-  const int tx = tid % G::TXN, ty = tid / G::TXN;
-  const int gy0 = t.oy + 4 * ty, gx0 = t.ox + 4 * tx;
-  if (gy0 >= a.H || gx0 >= a.W) return;  // micro-tile entirely outside a ragged image edge
-  float ypp[4][4], u[4][4], v[4][4];
-  {
-    float yw[8][8];
-    r2l_window_yp<G>(YP, tx, ty, yw);
-    r2l_blur_4x4(yw, F, ypp);
-  }
-  {
-    float vw[6][6];
-    r2l_window_6x6<G>(V, tx, ty, vw);
-    r2l_chroma_4x4(vw, F, u, v);
-  }
-  const size_t plane = (size_t)a.H * a.W;
-  const bool vec_ok = ((a.W & 3) == 0) && (gx0 + 3 < a.W);
+                           const R2LTile& t, R2LFwdRegs& regs) {
+  int tx, row0, py;
+  G::thread_tile(tid, tx, row0, py);
+  const int gy0 = t.oy + row0, gx0 = t.ox + 4 * tx;
+  if (RAGGED && (gy0 >= a.H || gx0 >= a.W)) return;  // micro-tile entirely outside a ragged image edge
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;           // < 2^29 (checked by the ABI)
+  float* ob = a.out ? a.out + (size_t)t.b * 3 * plane : nullptr;  // wave-uniform image base
+  const unsigned pix0 = (unsigned)gy0 * (unsigned)a.W + (unsigned)gx0;
   float mean[3] = {0.f, 0.f, 0.f}, istd[3] = {1.f, 1.f, 1.f};
   if (a.bn) {
     R2L_PRAGMA_UNROLL
@@ -344,110 +496,104 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
       istd[k] = a.bn[3 + k];
     }
   }
-  R2L_PRAGMA_UNROLL
-  for (int r = 0; r < 4; ++r) {
-    const int gy = gy0 + r;
-    if (gy >= a.H) break;
-    R2L_PRAGMA_UNROLL
-    for (int k = 0; k < 3; ++k) {
-      float x[4];
-      R2L_PRAGMA_UNROLL
-      for (int c = 0; c < 4; ++c) {
-        float rgb = F.M2[k * 3] * ypp[r][c];
-        rgb = fmaf(F.M2[k * 3 + 1], u[r][c], rgb);
-        rgb = fmaf(F.M2[k * 3 + 2], v[r][c], rgb);
-        const float xc = fminf(fmaxf(rgb, 1e-5f), 1.0f);          // :206
-        x[c] = r2l_exp2(r2l_log2(xc) * F.inv_gamma);              // :209
-      }
-      if (a.additive) {                                          // :213 (H == W == 256)
-        const float* ad = a.additive + ((size_t)k * a.H + gy) * a.W + gx0;
-        R2L_PRAGMA_UNROLL
-        for (int c = 0; c < 4; ++c)
-          if (gx0 + c < a.W) x[c] += ad[c];
-      }
-      if (a.stat_partial) {
-        R2L_PRAGMA_UNROLL
-        for (int c = 0; c < 4; ++c)
-          if (gx0 + c < a.W) {
-            const float d = x[c] - 0.5f;
-            regs.acc[k] += d;
-            regs.acc[3 + k] = fmaf(d, d, regs.acc[3 + k]);
-          }
-      }
-      if (a.out) {
-        R2L_PRAGMA_UNROLL
-        for (int c = 0; c < 4; ++c) x[c] = (x[c] - mean[k]) * istd[k];  // :217
-        float* o = a.out + ((size_t)t.b * 3 + k) * plane + (size_t)gy * a.W + gx0;
-        if (vec_ok) {
-          r2l_f4 st;
-          st.x = x[0];
-          st.y = x[1];
-          st.z = x[2];
-          st.w = x[3];
-          *(r2l_f4*)o = st;
-        } else {
-          R2L_PRAGMA_UNROLL
-          for (int c = 0; c < 4; ++c)
-            if (gx0 + c < a.W) o[c] = x[c];
-        }
-      }
-    }
+  R2L_PRAGMA_NOUNROLL
+  for (int rr = 0; rr < 4; rr += 2) {  // rows row0 and row0 + 2
+    if (RAGGED && gy0 + rr >= a.H) break;
+    const unsigned off0 = pix0 + (unsigned)rr * (unsigned)a.W;
+    if (py)
+      r2l_fwd_row<G, 1, RAGGED, ADD>(V, YP, a, tx, row0 + 4 + rr, gx0, off0, plane, ob, mean, istd, regs);
+    else
+      r2l_fwd_row<G, 0, RAGGED, ADD>(V, YP, a, tx, row0 + 4 + rr, gx0, off0, plane, ob, mean, istd, regs);
   }
 }
 
 // per-thread accumulators -> one partial per slot per workgroup, in a fixed order (bitwise
-// reproducible): slots go through LDS 32 at a time, thread s < 32 adds the 256 values of slot s.
-#define R2L_RED_FLOATS (32 * 257)
-#define R2L_BLOCK_REDUCE(NACC, regs, lds, partial, bid, nblk)                               \
+// reproducible): slots go through LDS 32 at a time, thread s < 32 adds the R2L_NT values of slot s.
+#define R2L_RED_FLOATS (32 * (R2L_NT + 1))
+#define R2L_ACC_DIRECT(regs, i) R2L_TREG(regs).acc[i]
+#define R2L_BLOCK_REDUCE(NACC, regs, lds, partial, bid, nblk) \
+  R2L_BLOCK_REDUCE_F(NACC, R2L_ACC_DIRECT, regs, lds, partial, bid, nblk)
+#define R2L_BLOCK_REDUCE_F(NACC, VAL, regs, lds, partial, bid, nblk)                        \
   R2L_PRAGMA_UNROLL                                                                         \
   for (int base_ = 0; base_ < (NACC); base_ += 32) {                                        \
     R2L_PHASE_BEGIN                                                                         \
     R2L_PRAGMA_UNROLL                                                                       \
     for (int i_ = 0; i_ < 32; ++i_)                                                         \
-      if (base_ + i_ < (NACC)) (lds)[i_ * 257 + tid] = R2L_TREG(regs).acc[base_ + i_];      \
+      if (base_ + i_ < (NACC)) (lds)[i_ * (R2L_NT + 1) + tid] = VAL(regs, base_ + i_);     \
     R2L_PHASE_END                                                                           \
     R2L_PHASE_BEGIN                                                                         \
     if (tid < 32 && base_ + tid < (NACC)) {                                                 \
       float s_ = 0.f;                                                                       \
-      for (int j_ = 0; j_ < R2L_NT; ++j_) s_ += (lds)[tid * 257 + j_];                      \
+      for (int j_ = 0; j_ < R2L_NT; ++j_) s_ += (lds)[tid * (R2L_NT + 1) + j_];                      \
       (partial)[(size_t)(base_ + tid) * (nblk) + (bid)] = s_;                               \
     }                                                                                       \
     R2L_PHASE_END                                                                           \
   }
 
-template <class G>
+template <class G, bool ADD, bool MAYBE_RAGGED>
 R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* lds) {
-  float* V = lds + G::PAD;
+  float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
+  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   float* Y = V + G::PLANE;
   float* YP = Y + G::PLANE;
-  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   R2L_TREG_DECL(R2LFwdRegs, regs);
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 6; ++i) R2L_TREG(regs).acc[i] = 0.f;
   R2L_PHASE_END
+#ifdef R2L_EXP_STAMPS
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0_ = __builtin_amdgcn_s_memtime(), t1_;
+#define R2L_STAMP(k) t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - t0_; t0_ = t1_;
+#else
+#define R2L_STAMP(k)
+#endif
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t;
   while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
     const float* rawb = a.raw + (size_t)t.b * a.H * a.W;
+#ifndef R2L_EXP_SKIP_LOAD
     R2L_PHASE_BEGIN
-    r2l_load_v<G>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
+    if (t.border)
+      r2l_load_v<G, true>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
+    else
+      r2l_load_v<G, false>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
+    R2L_STAMP(0)
+#endif
+#ifndef R2L_EXP_SKIP_BC
     R2L_PHASE_BEGIN
-    r2l_compute_y<G>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
+    if (t.border)
+      r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
+    else
+      r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
+    R2L_STAMP(1)
     R2L_PHASE_BEGIN
     r2l_compute_yp<G>(tid, Y, YP, F);
     R2L_PHASE_END
+    R2L_STAMP(2)
     if (t.border) {
       R2L_PHASE_BEGIN
       r2l_fill_yp_mirror<G>(tid, YP, t.oy, t.ox, a.H, a.W);
       R2L_PHASE_END
+      R2L_STAMP(3)
     }
+#endif
+#ifndef R2L_EXP_SKIP_PIX
     R2L_PHASE_BEGIN
-    r2l_fwd_pixels<G>(tid, V, YP, a, F, t, R2L_TREG(regs));
+    if (MAYBE_RAGGED && t.ragged)
+      r2l_fwd_pixels<G, MAYBE_RAGGED, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
+    else
+      r2l_fwd_pixels<G, false, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
+    R2L_STAMP(4)
+#endif
   }
+#ifdef R2L_EXP_STAMPS
+  if (threadIdx.x == 0 && a.out)
+    for (int k = 0; k < 8; ++k) a.out[(size_t)bid * 8 + k] = (float)st_[k];
+#endif
   if (a.stat_partial) {
     R2L_BLOCK_REDUCE(6, regs, lds, a.stat_partial, bid, nblk)
   }
@@ -468,175 +614,205 @@ struct R2LBwd1Args {
   int B, H, W;
 };
 
+// per-thread accumulators of B1: a thread only sees pixels of ONE row parity, so it keeps the two column
+// parities of its own row parity (18 of the 36 slots of each parity-indexed table)
+enum { R2L_L1_GBLUR = 0, R2L_L1_GAU = 25, R2L_L1_GAV = 43, R2L_L1_SU = 61, R2L_L1_SV = 63,
+       R2L_L1_GGAM = 65, R2L_L1_NACC = 66 };
 struct R2LBwd1Regs {
-  float acc[R2L_B1_NACC];
+  float acc[R2L_L1_NACC];
+  int py;
+};
+// value of global slot i (layout R2L_B1_*) held by a thread of row parity py
+R2L_HD float r2l_b1_slot(const R2LBwd1Regs& r, int i) {
+  if (i < R2L_B1_GAU) return r.acc[R2L_L1_GBLUR + i];
+  if (i < R2L_B1_SU) {
+    const int tbl = (i - R2L_B1_GAU) / 36, k = (i - R2L_B1_GAU) % 36, par = k / 9, t = k % 9;
+    const float v = r.acc[(tbl ? R2L_L1_GAV : R2L_L1_GAU) + (par & 1) * 9 + t];
+    return ((par >> 1) == r.py) ? v : 0.f;
+  }
+  if (i < R2L_B1_GGAM) {
+    const int tbl = (i - R2L_B1_SU) / 4, par = (i - R2L_B1_SU) % 4;
+    const float v = r.acc[(tbl ? R2L_L1_SV : R2L_L1_SU) + (par & 1)];
+    return ((par >> 1) == r.py) ? v : 0.f;
+  }
+  return r.acc[R2L_L1_GGAM];
+}
+#define R2L_ACC_B1(regs, i) r2l_b1_slot(R2L_TREG(regs), i)
+
+struct R2LBnConsts {
+  float mean[3], istd[3], mg[3], mgx[3];
 };
 
-template <class G>
-R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LBwd1Args& a,
-                            R2LFoldedRef F, const R2LTile& t, R2LBwd1Regs& regs) {
-  const int tx = tid % G::TXN, ty = tid / G::TXN;
-  const int gy0 = t.oy + 4 * ty, gx0 = t.ox + 4 * tx;
-  if (gy0 >= a.H || gx0 >= a.W) return;
-  float yw[8][8], vw[6][6];
-  float ypp[4][4], u[4][4], v[4][4];
-  r2l_window_yp<G>(YP, tx, ty, yw);
-  r2l_blur_4x4(yw, F, ypp);
-  r2l_window_6x6<G>(V, tx, ty, vw);
-  r2l_chroma_4x4(vw, F, u, v);
-  const size_t plane = (size_t)a.H * a.W;
-  const bool vec_ok = ((a.W & 3) == 0) && (gx0 + 3 < a.W);
-  float mean[3] = {0.f, 0.f, 0.f}, istd[3] = {1.f, 1.f, 1.f}, mg[3] = {0.f, 0.f, 0.f},
-        mgx[3] = {0.f, 0.f, 0.f};
-  if (a.bn) {
-    R2L_PRAGMA_UNROLL
-    for (int k = 0; k < 3; ++k) {
-      mean[k] = a.bn[k];
-      istd[k] = a.bn[3 + k];
-    }
-  }
-  if (a.bn_bwd) {
-    R2L_PRAGMA_UNROLL
-    for (int k = 0; k < 3; ++k) {
-      mg[k] = a.bn_bwd[k];
-      mgx[k] = a.bn_bwd[3 + k];
-    }
-  }
-  float gy2[4][4], gu[4][4], gv[4][4];  // d loss / d (Y'', U, V)
+// one output row (4 pixels of this thread) of kernel B1; PY = row parity
+template <class G, int PY, bool RAGGED, bool ADD>
+R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, int tx, int frow, int gx0,
+                         unsigned off0, unsigned plane, const float* gb, float* gyb,
+                         const R2LBnConsts& bc, R2LBwd1Regs& regs) {
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
+  float yw[5][8], vw[3][6];
+  float ypp[4], u[4], v[4];
+  r2l_rows_yp<G>(YP, tx, frow, yw);
+  r2l_blur_row(yw, F, ypp);
+  r2l_rows_3x6<G>(V, tx, frow, vw);
+  r2l_chroma_row<PY>(vw, F, u, v);
+  const bool vec_ok = !RAGGED || (((a.W & 3) == 0) && (gx0 + 3 < a.W));
+  float grgb[3][4];
   float ggam = 0.f;
   R2L_PRAGMA_UNROLL
-  for (int r = 0; r < 4; ++r) {
-    const int gy = gy0 + r;
-    const bool rowin = gy < a.H;
-    float grgb[3][4];
-    R2L_PRAGMA_UNROLL
-    for (int k = 0; k < 3; ++k) {
-      float g[4] = {0.f, 0.f, 0.f, 0.f};
-      if (rowin) {
-        const float* gp = a.gout + ((size_t)t.b * 3 + k) * plane + (size_t)gy * a.W + gx0;
-        if (vec_ok) {
-          const r2l_f4 q = *(const r2l_f4*)gp;
-          g[0] = q.x;
-          g[1] = q.y;
-          g[2] = q.z;
-          g[3] = q.w;
-        } else {
-          R2L_PRAGMA_UNROLL
-          for (int c = 0; c < 4; ++c)
-            if (gx0 + c < a.W) g[c] = gp[c];
-        }
-      }
+  for (int k = 0; k < 3; ++k) {
+    const unsigned off = (unsigned)k * plane + off0;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec_ok) {
+      const r2l_f4 q = *(const r2l_f4*)(gb + off);
+      g[0] = q.x;
+      g[1] = q.y;
+      g[2] = q.z;
+      g[3] = q.w;
+    } else {
       R2L_PRAGMA_UNROLL
-      for (int c = 0; c < 4; ++c) {
-        const bool valid = rowin && (gx0 + c < a.W);
-        float rgb = F.M2[k * 3] * ypp[r][c];
-        rgb = fmaf(F.M2[k * 3 + 1], u[r][c], rgb);
-        rgb = fmaf(F.M2[k * 3 + 2], v[r][c], rgb);
-        const float xc = fminf(fmaxf(rgb, 1e-5f), 1.0f);
-        const float lg = r2l_log2(xc);
-        const float og = r2l_exp2(lg * F.inv_gamma);
-        float gx = g[c];
-        if (a.bn) {
-          float x = og;
-          if (a.additive && valid) x += a.additive[((size_t)k * a.H + gy) * a.W + gx0 + c];
-          const float xhat = (x - mean[k]) * istd[k];
-          // BatchNorm2d backward, train mode: istd * (g - mean(g) - xhat * mean(g*xhat)); in eval
-          // mode mg = mgx = 0 and only the scaling remains
-          gx = istd[k] * (gx - mg[k] - xhat * mgx[k]);
-        }
-        gx = valid ? gx : 0.f;
-        ggam = fmaf(gx * og, lg, ggam);
-        const float gc = gx * og * F.inv_gamma * r2l_rcp(xc);
-        grgb[k][c] = (rgb >= 1e-5f && rgb <= 1.0f) ? gc : 0.f;  // torch.clip backward
-      }
+      for (int c = 0; c < 4; ++c)
+        if (gx0 + c < a.W) g[c] = gb[off + c];
     }
     R2L_PRAGMA_UNROLL
     for (int c = 0; c < 4; ++c) {
-      gy2[r][c] = F.M2[0] * grgb[0][c] + F.M2[3] * grgb[1][c] + F.M2[6] * grgb[2][c];
-      gu[r][c] = F.M2[1] * grgb[0][c] + F.M2[4] * grgb[1][c] + F.M2[7] * grgb[2][c];
-      gv[r][c] = F.M2[2] * grgb[0][c] + F.M2[5] * grgb[1][c] + F.M2[8] * grgb[2][c];
-    }
-    if (rowin) {
-      float* o = a.gypp + (size_t)t.b * plane + (size_t)gy * a.W + gx0;
-      if (vec_ok) {
-        r2l_f4 st;
-        st.x = gy2[r][0];
-        st.y = gy2[r][1];
-        st.z = gy2[r][2];
-        st.w = gy2[r][3];
-        *(r2l_f4*)o = st;
-      } else {
-        R2L_PRAGMA_UNROLL
-        for (int c = 0; c < 4; ++c)
-          if (gx0 + c < a.W) o[c] = gy2[r][c];
-      }
+      const bool valid = !RAGGED || (gx0 + c < a.W);
+      float rgb = F.M2[k * 3] * ypp[c];
+      rgb = fmaf(F.M2[k * 3 + 1], u[c], rgb);
+      rgb = fmaf(F.M2[k * 3 + 2], v[c], rgb);
+      const float xc = fminf(fmaxf(rgb, 1e-5f), 1.0f);
+      const float lg = r2l_log2(xc);
+      const float og = r2l_exp2(lg * F.inv_gamma);
+      float x = og;
+      if (ADD) x += valid ? a.additive[off + c] : 0.f;
+      const float xhat = (x - bc.mean[k]) * bc.istd[k];
+      // BatchNorm2d backward, train mode: istd * (g - mean(g) - xhat * mean(g*xhat)); in eval mode
+      // mg = mgx = 0 and only the scaling remains; without BatchNorm mean = 0, istd = 1 too, which
+      // leaves g unchanged (exactly)
+      float gx = bc.istd[k] * (g[c] - bc.mg[k] - xhat * bc.mgx[k]);
+      if (RAGGED) gx = valid ? gx : 0.f;
+      ggam = fmaf(gx * og, lg, ggam);
+      const float gc = gx * og * F.inv_gamma * r2l_rcp(xc);
+      grgb[k][c] = (rgb >= 1e-5f && rgb <= 1.0f) ? gc : 0.f;  // torch.clip backward
     }
   }
-  regs.acc[R2L_B1_GGAM] += ggam;
+  float gy2[4], gu[4], gv[4];  // d loss / d (Y'', U, V)
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) {
+    gy2[c] = F.M2[0] * grgb[0][c] + F.M2[3] * grgb[1][c] + F.M2[6] * grgb[2][c];
+    gu[c] = F.M2[1] * grgb[0][c] + F.M2[4] * grgb[1][c] + F.M2[7] * grgb[2][c];
+    gv[c] = F.M2[2] * grgb[0][c] + F.M2[5] * grgb[1][c] + F.M2[8] * grgb[2][c];
+  }
+  if (vec_ok) {
+    r2l_f4 st;
+    st.x = gy2[0];
+    st.y = gy2[1];
+    st.z = gy2[2];
+    st.w = gy2[3];
+    *(r2l_f4*)(gyb + off0) = st;
+  } else {
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c)
+      if (gx0 + c < a.W) gyb[off0 + c] = gy2[c];
+  }
+  R2L_SCHED_FENCE();
+  regs.acc[R2L_L1_GGAM] += ggam;
+#ifndef R2L_EXP_NO_GBLUR
   // d/d gaussian_blur.weight[i][j] = sum_p gY''(p) * YP_ext(p + (i-2, j-2))
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 5; ++i)
     R2L_PRAGMA_UNROLL
   for (int j = 0; j < 5; ++j) {
-    float s = 0.f;
+    float s = regs.acc[R2L_L1_GBLUR + i * 5 + j];
     R2L_PRAGMA_UNROLL
-    for (int r = 0; r < 4; ++r)
-      R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) s = fmaf(gy2[r][c], yw[r + i][c + j], s);
-    regs.acc[R2L_B1_GBLUR + i * 5 + j] += s;
+    for (int c = 0; c < 4; ++c) s = fmaf(gy2[c], yw[i][c + j], s);
+    regs.acc[R2L_L1_GBLUR + i * 5 + j] = s;
   }
+#endif
+#ifndef R2L_EXP_NO_GA
+  R2L_SCHED_FENCE();
   // folded chroma stencils: GA[par][t] = sum_{p of parity par} gU(p) * v_ext(p+t)
   R2L_PRAGMA_UNROLL
-  for (int par = 0; par < 4; ++par) {
-    const int r0 = par >> 1, c0 = par & 1;
+  for (int px = 0; px < 2; ++px) {
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 3; ++i)
       R2L_PRAGMA_UNROLL
     for (int j = 0; j < 3; ++j) {
-      float su = 0.f, sv = 0.f;
+      float su = regs.acc[R2L_L1_GAU + px * 9 + i * 3 + j];
+      float sv = regs.acc[R2L_L1_GAV + px * 9 + i * 3 + j];
       R2L_PRAGMA_UNROLL
-      for (int r = r0; r < 4; r += 2)
-        R2L_PRAGMA_UNROLL
-      for (int c = c0; c < 4; c += 2) {
-        su = fmaf(gu[r][c], vw[r + i][c + j], su);
-        sv = fmaf(gv[r][c], vw[r + i][c + j], sv);
+      for (int c = px; c < 4; c += 2) {
+        su = fmaf(gu[c], vw[i][c + j], su);
+        sv = fmaf(gv[c], vw[i][c + j], sv);
       }
-      regs.acc[R2L_B1_GAU + par * 9 + i * 3 + j] += su;
-      regs.acc[R2L_B1_GAV + par * 9 + i * 3 + j] += sv;
+      regs.acc[R2L_L1_GAU + px * 9 + i * 3 + j] = su;
+      regs.acc[R2L_L1_GAV + px * 9 + i * 3 + j] = sv;
     }
-    float tu = 0.f, tv = 0.f;
-    R2L_PRAGMA_UNROLL
-    for (int r = r0; r < 4; r += 2)
-      R2L_PRAGMA_UNROLL
-    for (int c = c0; c < 4; c += 2) {
-      tu += gu[r][c];
-      tv += gv[r][c];
-    }
-    regs.acc[R2L_B1_SU + par] += tu;
-    regs.acc[R2L_B1_SV + par] += tv;
+    regs.acc[R2L_L1_SU + px] += gu[px] + gu[px + 2];
+    regs.acc[R2L_L1_SV + px] += gv[px] + gv[px + 2];
+  }
+#endif
+}
+
+template <class G, bool RAGGED, bool ADD>
+R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LBwd1Args& a,
+                            const R2LTile& t, R2LBwd1Regs& regs) {
+  int tx, row0, py;
+  G::thread_tile(tid, tx, row0, py);
+  const int gy0 = t.oy + row0, gx0 = t.ox + 4 * tx;
+  if (RAGGED && (gy0 >= a.H || gx0 >= a.W)) return;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const float* gb = a.gout + (size_t)t.b * 3 * plane;
+  float* gyb = a.gypp + (size_t)t.b * plane;
+  const unsigned pix0 = (unsigned)gy0 * (unsigned)a.W + (unsigned)gx0;
+  R2LBnConsts bc;
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) {
+    bc.mean[k] = a.bn ? a.bn[k] : 0.f;
+    bc.istd[k] = a.bn ? a.bn[3 + k] : 1.f;
+    bc.mg[k] = a.bn_bwd ? a.bn_bwd[k] : 0.f;
+    bc.mgx[k] = a.bn_bwd ? a.bn_bwd[3 + k] : 0.f;
+  }
+  R2L_PRAGMA_NOUNROLL
+  for (int rr = 0; rr < 4; rr += 2) {
+    if (RAGGED && gy0 + rr >= a.H) break;
+    const unsigned off0 = pix0 + (unsigned)rr * (unsigned)a.W;
+    if (py)
+      r2l_bwd1_row<G, 1, RAGGED, ADD>(V, YP, a, tx, row0 + 4 + rr, gx0, off0, plane, gb, gyb, bc, regs);
+    else
+      r2l_bwd1_row<G, 0, RAGGED, ADD>(V, YP, a, tx, row0 + 4 + rr, gx0, off0, plane, gb, gyb, bc, regs);
   }
 }
 
-template <class G>
+template <class G, bool ADD, bool MAYBE_RAGGED>
 R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* lds) {
-  float* V = lds + G::PAD;
+  float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
+  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   float* Y = V + G::PLANE;
   float* YP = Y + G::PLANE;
-  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   R2L_TREG_DECL(R2LBwd1Regs, regs);
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < R2L_B1_NACC; ++i) R2L_TREG(regs).acc[i] = 0.f;
+  for (int i = 0; i < R2L_L1_NACC; ++i) R2L_TREG(regs).acc[i] = 0.f;
+  {
+    int tx_, row_;
+    G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
+  }
   R2L_PHASE_END
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t;
   while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
     const float* rawb = a.raw + (size_t)t.b * a.H * a.W;
     R2L_PHASE_BEGIN
-    r2l_load_v<G>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
+    if (t.border)
+      r2l_load_v<G, true>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
+    else
+      r2l_load_v<G, false>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
     R2L_PHASE_BEGIN
-    r2l_compute_y<G>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
+    if (t.border)
+      r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
+    else
+      r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
     R2L_PHASE_BEGIN
     r2l_compute_yp<G>(tid, Y, YP, F);
@@ -647,10 +823,13 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
       R2L_PHASE_END
     }
     R2L_PHASE_BEGIN
-    r2l_bwd1_pixels<G>(tid, V, YP, a, F, t, R2L_TREG(regs));
+    if (MAYBE_RAGGED && t.ragged)
+      r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
+    else
+      r2l_bwd1_pixels<G, false, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
   }
-  R2L_BLOCK_REDUCE(R2L_B1_NACC, regs, lds, a.partial, bid, nblk)
+  R2L_BLOCK_REDUCE_F(R2L_B1_NACC, R2L_ACC_B1, regs, lds, a.partial, bid, nblk)
 }
 
 // ================================================================================================
@@ -664,9 +843,21 @@ struct R2LBwd2Args {
   int B, H, W;
 };
 
+enum { R2L_L2_GSHARP = 0, R2L_L2_GAY = 9, R2L_L2_SY = 27, R2L_L2_NACC = 29 };
 struct R2LBwd2Regs {
-  float acc[R2L_B2_NACC];
+  float acc[R2L_L2_NACC];
+  int py;
 };
+R2L_HD float r2l_b2_slot(const R2LBwd2Regs& r, int i) {
+  if (i < R2L_B2_GAY) return r.acc[R2L_L2_GSHARP + i];
+  if (i < R2L_B2_SY) {
+    const int k = i - R2L_B2_GAY, par = k / 9, t = k % 9;
+    return ((par >> 1) == r.py) ? r.acc[R2L_L2_GAY + (par & 1) * 9 + t] : 0.f;
+  }
+  const int par = i - R2L_B2_SY;
+  return ((par >> 1) == r.py) ? r.acc[R2L_L2_SY + (par & 1)] : 0.f;
+}
+#define R2L_ACC_B2(regs, i) r2l_b2_slot(R2L_TREG(regs), i)
 
 // phase: HP(q') = sum_t blur[t] * G2_ext0(q' - t) on frame rows/cols [2, F-2); G2 is stored shifted
 template <class G>
@@ -679,8 +870,8 @@ R2L_HD void r2l_adjoint_blur(int tid, const float* G2, float* HP, R2LFoldedRef F
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 6; ++i) {
       const float* r = G2 + (fy - 2 + i) * G::FS + fx;  // (+2 shift) - 2
-      const r2l_f4 a = *(const r2l_f4*)r;
-      const r2l_f4 b = *(const r2l_f4*)(r + 4);
+      const r2l_f4 a = r2l_lds_f4(r);
+      const r2l_f4 b = r2l_lds_f4(r + 4);
       w[i][0] = a.x;
       w[i][1] = a.y;
       w[i][2] = a.z;
@@ -714,128 +905,151 @@ R2L_HD void r2l_adjoint_blur(int tid, const float* G2, float* HP, R2LFoldedRef F
 }
 
 // phase (border tiles): fold the contributions that the mirror padding sent outside the image back
-// onto their sources, and zero everything outside the image:  H2 <- fold(HP)
+// onto their sources, IN PLACE: an in-image position adds the values of its out-of-image mirror images
+// (which nobody writes in this phase).  Out-of-image entries keep their values; the pixel phase masks
+// them (the zero padding of the sharpen conv has no adjoint contribution there).
 template <class G>
-R2L_HD void r2l_fold_mirror(int tid, const float* HP, float* H2, int oy, int ox, int H, int W) {
+R2L_HD void r2l_fold_mirror(int tid, float* HP, int oy, int ox, int H, int W) {
   constexpr int NW = G::FW - 4, NH = G::FH - 4;
   for (int i = tid; i < NW * NH; i += R2L_NT) {
     const int fy = 2 + i / NW, fx = 2 + i % NW;
     const int gy = oy - 4 + fy, gx = ox - 4 + fx;
+    if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) continue;
+    int ey[3], ex[3];
+    ey[0] = fy;
+    ey[1] = (gy >= 1 && gy <= 2) ? fy - 2 * gy : -1;                    // image row -gy
+    ey[2] = (gy >= H - 3 && gy <= H - 2) ? fy + 2 * (H - 1 - gy) : -1;  // image row 2(H-1)-gy
+    ex[0] = fx;
+    ex[1] = (gx >= 1 && gx <= 2) ? fx - 2 * gx : -1;
+    ex[2] = (gx >= W - 3 && gx <= W - 2) ? fx + 2 * (W - 1 - gx) : -1;
     float s = 0.f;
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-      int ey[3], ex[3];
-      ey[0] = fy;
-      ey[1] = (gy >= 1 && gy <= 2) ? fy - 2 * gy : -1;                    // image row -gy
-      ey[2] = (gy >= H - 3 && gy <= H - 2) ? fy + 2 * (H - 1 - gy) : -1;  // image row 2(H-1)-gy
-      ex[0] = fx;
-      ex[1] = (gx >= 1 && gx <= 2) ? fx - 2 * gx : -1;
-      ex[2] = (gx >= W - 3 && gx <= W - 2) ? fx + 2 * (W - 1 - gx) : -1;
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 3; ++p)
       R2L_PRAGMA_UNROLL
-      for (int p = 0; p < 3; ++p)
-        R2L_PRAGMA_UNROLL
-      for (int q = 0; q < 3; ++q)
-        if (ey[p] >= 2 && ey[p] < G::FH - 2 && ex[q] >= 2 && ex[q] < G::FW - 2)
-          s += HP[ey[p] * G::FS + ex[q]];
-    }
-    H2[fy * G::FS + fx] = s;
+    for (int q = 0; q < 3; ++q)
+      if ((p | q) != 0 && ey[p] >= 2 && ey[p] < G::FH - 2 && ex[q] >= 2 && ex[q] < G::FW - 2)
+        s += HP[ey[p] * G::FS + ex[q]];
+    HP[fy * G::FS + fx] += s;
   }
 }
 
-template <class G>
-R2L_HD void r2l_bwd2_pixels(int tid, const float* V, const float* Y, const float* HS,
-                            const R2LBwd2Args& a, R2LFoldedRef F, const R2LTile& t,
-                            R2LBwd2Regs& regs) {
-  const int tx = tid % G::TXN, ty = tid / G::TXN;
-  const int gy0 = t.oy + 4 * ty, gx0 = t.ox + 4 * tx;
-  if (gy0 >= a.H || gx0 >= a.W) return;
-  float hw[6][6], yw[6][6], vw[6][6];
-  r2l_window_6x6<G>(HS, tx, ty, hw);
-  r2l_window_6x6<G>(Y, tx, ty, yw);
-  r2l_window_6x6<G>(V, tx, ty, vw);
-  float gy1[4][4];  // d loss / d Y (pre-sharpen luma), interior pixels
-  R2L_PRAGMA_UNROLL
-  for (int r = 0; r < 4; ++r)
+// one output row of kernel B2; PY = row parity; BORDER: mask adjoint values outside the image
+template <class G, int PY, bool BORDER>
+R2L_HD void r2l_bwd2_row(const float* V, const float* Y, const float* HP, const R2LBwd2Args& a, int tx,
+                         int frow, int gy, int gx0, R2LBwd2Regs& regs) {
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
+  float hw[3][6], yw[3][6], vw[3][6];
+  r2l_rows_3x6<G>(HP, tx, frow, hw);
+  r2l_rows_3x6<G>(Y, tx, frow, yw);
+  r2l_rows_3x6<G>(V, tx, frow, vw);
+  if (BORDER) {
     R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i) {
+      const bool rin = (unsigned)(gy - 1 + i) < (unsigned)a.H;
+      R2L_PRAGMA_UNROLL
+      for (int j = 0; j < 6; ++j)
+        hw[i][j] = (rin && (unsigned)(gx0 - 1 + j) < (unsigned)a.W) ? hw[i][j] : 0.f;
+    }
+  }
+  float gy1[4];  // d loss / d Y (pre-sharpen luma)
+  R2L_PRAGMA_UNROLL
   for (int c = 0; c < 4; ++c) {
-    const bool valid = (gy0 + r < a.H) && (gx0 + c < a.W);
     float s = 0.f;
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 3; ++i)
       R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 3; ++j)  // source q = p - (i-1, j-1) -> window index (r+2-i, c+2-j)
-      s = fmaf(F.sharp[i * 3 + j], hw[r + 2 - i][c + 2 - j], s);
-    gy1[r][c] = valid ? s : 0.f;
-    // outside the image gY' (hw centre) is already zero for border tiles; interior tiles are all valid
+    for (int j = 0; j < 3; ++j)  // source q = p - (i-1, j-1) -> window index (2-i, c+2-j)
+      s = fmaf(F.sharp[i * 3 + j], hw[2 - i][c + 2 - j], s);
+    const bool valid = !BORDER || ((unsigned)gy < (unsigned)a.H && (unsigned)(gx0 + c) < (unsigned)a.W);
+    gy1[c] = valid ? s : 0.f;
   }
-  // d/d sharpening_filter.weight[i][j] = sum_p gY'(p) * Y_zero_ext(p + (i-1, j-1))
+  // d/d sharpening_filter.weight[i][j] = sum_p gY'(p) * Y_zero_ext(p + (i-1, j-1)); gY'(p) = hw[1][c+1]
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 3; ++i)
     R2L_PRAGMA_UNROLL
   for (int j = 0; j < 3; ++j) {
-    float s = 0.f;
+    float s = regs.acc[R2L_L2_GSHARP + i * 3 + j];
     R2L_PRAGMA_UNROLL
-    for (int r = 0; r < 4; ++r)
-      R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) s = fmaf(hw[r + 1][c + 1], yw[r + i][c + j], s);
-    regs.acc[R2L_B2_GSHARP + i * 3 + j] += s;
+    for (int c = 0; c < 4; ++c) s = fmaf(hw[1][c + 1], yw[i][c + j], s);
+    regs.acc[R2L_L2_GSHARP + i * 3 + j] = s;
   }
   R2L_PRAGMA_UNROLL
-  for (int par = 0; par < 4; ++par) {
-    const int r0 = par >> 1, c0 = par & 1;
+  for (int px = 0; px < 2; ++px) {
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 3; ++i)
       R2L_PRAGMA_UNROLL
     for (int j = 0; j < 3; ++j) {
-      float s = 0.f;
+      float s = regs.acc[R2L_L2_GAY + px * 9 + i * 3 + j];
       R2L_PRAGMA_UNROLL
-      for (int r = r0; r < 4; r += 2)
-        R2L_PRAGMA_UNROLL
-      for (int c = c0; c < 4; c += 2) s = fmaf(gy1[r][c], vw[r + i][c + j], s);
-      regs.acc[R2L_B2_GAY + par * 9 + i * 3 + j] += s;
+      for (int c = px; c < 4; c += 2) s = fmaf(gy1[c], vw[i][c + j], s);
+      regs.acc[R2L_L2_GAY + px * 9 + i * 3 + j] = s;
     }
-    float ts = 0.f;
-    R2L_PRAGMA_UNROLL
-    for (int r = r0; r < 4; r += 2)
-      R2L_PRAGMA_UNROLL
-    for (int c = c0; c < 4; c += 2) ts += gy1[r][c];
-    regs.acc[R2L_B2_SY + par] += ts;
+    regs.acc[R2L_L2_SY + px] += gy1[px] + gy1[px + 2];
+  }
+}
+
+template <class G, bool BORDER>
+R2L_HD void r2l_bwd2_pixels(int tid, const float* V, const float* Y, const float* HP,
+                            const R2LBwd2Args& a, const R2LTile& t, R2LBwd2Regs& regs) {
+  int tx, row0, py;
+  G::thread_tile(tid, tx, row0, py);
+  const int gy0 = t.oy + row0, gx0 = t.ox + 4 * tx;
+  if (BORDER && (gy0 >= a.H || gx0 >= a.W)) return;
+  R2L_PRAGMA_NOUNROLL
+  for (int rr = 0; rr < 4; rr += 2) {
+    if (py)
+      r2l_bwd2_row<G, 1, BORDER>(V, Y, HP, a, tx, row0 + 4 + rr, gy0 + rr, gx0, regs);
+    else
+      r2l_bwd2_row<G, 0, BORDER>(V, Y, HP, a, tx, row0 + 4 + rr, gy0 + rr, gx0, regs);
   }
 }
 
 template <class G>
 R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* lds) {
-  float* V = lds + G::PAD;
-  float* Y = V + G::PLANE;
-  float* G2 = Y + G::PLANE;   // shifted; reused as H2 by border tiles
+  float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
+  float* G2 = V + G::PLANE;  // dL/dY'' (shifted); dead after the adjoint blur, then holds Y
   float* HP = G2 + G::PLANE;
+  float* Y = G2;
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   R2L_TREG_DECL(R2LBwd2Regs, regs);
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < R2L_B2_NACC; ++i) R2L_TREG(regs).acc[i] = 0.f;
+  for (int i = 0; i < R2L_L2_NACC; ++i) R2L_TREG(regs).acc[i] = 0.f;
+  {
+    int tx_, row_;
+    G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
+  }
   R2L_PHASE_END
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t;
   while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
     const size_t off = (size_t)t.b * a.H * a.W;
     R2L_PHASE_BEGIN
-    r2l_load_v<G>(tid, V, a.raw + off, F, t.oy, t.ox, a.H, a.W);
-    r2l_load_plane_zero_s2<G>(tid, G2, a.gypp + off, t.oy, t.ox, a.H, a.W);
+    if (t.border) {
+      r2l_load_v<G, true>(tid, V, a.raw + off, F, t.oy, t.ox, a.H, a.W);
+      r2l_load_plane_zero_s2<G, true>(tid, G2, a.gypp + off, t.oy, t.ox, a.H, a.W);
+    } else {
+      r2l_load_v<G, false>(tid, V, a.raw + off, F, t.oy, t.ox, a.H, a.W);
+      r2l_load_plane_zero_s2<G, false>(tid, G2, a.gypp + off, t.oy, t.ox, a.H, a.W);
+    }
     R2L_PHASE_END
     R2L_PHASE_BEGIN
-    r2l_compute_y<G>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     r2l_adjoint_blur<G>(tid, G2, HP, F);
     R2L_PHASE_END
-    const float* HS = HP;
-    if (t.border) {
-      R2L_PHASE_BEGIN
-      r2l_fold_mirror<G>(tid, HP, G2, t.oy, t.ox, a.H, a.W);
-      R2L_PHASE_END
-      HS = G2;
-    }
     R2L_PHASE_BEGIN
-    r2l_bwd2_pixels<G>(tid, V, Y, HS, a, F, t, R2L_TREG(regs));
+    if (t.border) {
+      r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
+      r2l_fold_mirror<G>(tid, HP, t.oy, t.ox, a.H, a.W);
+    } else {
+      r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
+    }
+    R2L_PHASE_END
+    R2L_PHASE_BEGIN
+    if (t.border)
+      r2l_bwd2_pixels<G, true>(tid, V, Y, HP, a, t, R2L_TREG(regs));
+    else
+      r2l_bwd2_pixels<G, false>(tid, V, Y, HP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
   }
-  R2L_BLOCK_REDUCE(R2L_B2_NACC, regs, lds, a.partial, bid, nblk)
+  R2L_BLOCK_REDUCE_F(R2L_B2_NACC, R2L_ACC_B2, regs, lds, a.partial, bid, nblk)
 }

@@ -67,7 +67,7 @@ struct R2LBnReduceArgs {
 struct R2LAcc6 {
   float acc[6];
 };
-#define R2L_SEG 4096  // floats per (plane, segment) work item: 4 x float4 per lane
+#define R2L_SEG (16 * R2L_NT)  // floats per (plane, segment) work item: 4 x float4 per lane
 R2L_HD void r2l_bn_reduce_item(int tid, const R2LBnReduceArgs& a, int item, int nsegpp, R2LAcc6& regs) {
   const int plane = item / nsegpp, seg = item - plane * nsegpp;
   const int k = plane % 3;

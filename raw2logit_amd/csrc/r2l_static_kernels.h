@@ -411,6 +411,7 @@ R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, con
 template <class G, bool FULL>
 R2L_HD void r2l_static_pixels(int tid, const float* V, const double* YP, const R2LStaticArgs& a,
                               const R2LTile& t) {
+  if (tid >= G::TXN * (G::TH / 4)) return;   // 4x4 micro-tiles: TW*TH/16 threads work in this phase
   const int tx = tid % G::TXN, ty = tid / G::TXN;
   const int gy0 = t.oy + 4 * ty, gx0 = t.ox + 4 * tx;
   if (gy0 >= a.H || gx0 >= a.W) return;

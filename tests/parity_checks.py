@@ -194,4 +194,4 @@ def check_ragged_and_properties(device, B=2, H=70, W=134):
         yt = mb(raw)
         mu = y.double().mean(dim=(0, 2, 3), keepdim=True)
         var = y.double().var(dim=(0, 2, 3), unbiased=False, keepdim=True)
-        assert torch.allclose(yt.double(), (y.double() - mu) * torch.rsqrt(var + 1e-5), rtol=0, atol=5e-6)
+        assert torch.allclose(yt.double(), (y.double() - mu) * torch.rsqrt(var + 1e-5), rtol=0, atol=2e-5)
