@@ -46,6 +46,8 @@ enum {
 /* flags for r2l_isp_fwd / r2l_isp_bwd */
 enum {
   R2L_F_STATS_ONLY = 1, /* fwd: do not write `out`, only the BatchNorm partial sums */
+  R2L_F_FOLDED_VALID = 2, /* fwd/bwd: `workspace` was last used by a call with these same `params`;
+                             skip re-deriving the folded weights (saves one small launch) */
 };
 
 /* static-pipeline selectors (processing/pipeline_numpy.py:92-122) */

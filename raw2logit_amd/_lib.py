@@ -22,6 +22,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 R2L_P_COUNT = 150
 R2L_P_NTRAIN = 132
 R2L_F_STATS_ONLY = 1
+R2L_F_FOLDED_VALID = 2
 
 _c_float_p = ctypes.c_void_p   # raw addresses from tensor.data_ptr()
 _SIGNATURES = {

@@ -255,8 +255,10 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
   if (!out && !stats) return r2l_fail(-1, "r2l_isp_fwd: nothing to compute (no out, no stats)");
   const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
   if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_fwd: workspace too small");
-  R2LFoldArgs fa{params, ws.folded};
-  if (int e = r2l_launch_fold(fa, 1, stream)) return e;
+  if (!(flags & R2L_F_FOLDED_VALID)) {
+    R2LFoldArgs fa{params, ws.folded};
+    if (int e = r2l_launch_fold(fa, 1, stream)) return e;
+  }
   const int ntiles = B * ((H + GFwd::TH - 1) / GFwd::TH) * ((W + GFwd::TW - 1) / GFwd::TW);
   const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_FWD", 512));
   R2LFwdArgs a;
@@ -299,7 +301,6 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
                 const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,
                 float* grad_params, float* grad_raw, void* workspace, size_t workspace_bytes, int B,
                 int H, int W, int flags, void* stream) {
-  (void)flags;
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (!raw || !params || !grad_out || !grad_params || !workspace)
     return r2l_fail(-1, "r2l_isp_bwd: null pointer");
@@ -310,8 +311,10 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
     return r2l_fail(-3, "r2l_isp_bwd: grad_raw is produced by the staged path, not the fused kernels");
   const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
   if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_bwd: workspace too small");
-  R2LFoldArgs fa{params, ws.folded};
-  if (int e = r2l_launch_fold(fa, 1, stream)) return e;
+  if (!(flags & R2L_F_FOLDED_VALID)) {
+    R2LFoldArgs fa{params, ws.folded};
+    if (int e = r2l_launch_fold(fa, 1, stream)) return e;
+  }
   const int ntiles = B * ((H + GBwd1::TH - 1) / GBwd1::TH) * ((W + GBwd1::TW - 1) / GBwd1::TW);
   const int g1 = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_BWD1", 512));
   R2LBwd1Args a1;

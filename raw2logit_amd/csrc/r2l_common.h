@@ -148,8 +148,8 @@ R2L_HD const R2LFolded* r2l_opaque(const R2LFolded* p) {
   return p;
 }
 
-R2L_HD void r2l_fold_params(const float* P, R2LFolded* F) {
-  double T[3][3];
+// T = M_RGB_2_YUV * colour_correction * diag(white_balance), float64
+R2L_HD void r2l_fold_T(const float* P, double T[3][3]) {
   for (int k = 0; k < 3; ++k)
     for (int c = 0; c < 3; ++c) {
       double s = 0;
@@ -157,28 +157,37 @@ R2L_HD void r2l_fold_params(const float* P, R2LFolded* F) {
         s += (double)P[R2L_P_M_RGB2YUV + k * 3 + j] * (double)P[R2L_P_CCM + j * 3 + c];
       T[k][c] = s * (double)P[R2L_P_WHITE_BALANCE + c];
     }
-  for (int s = 0; s < 4; ++s) F->bl[s] = P[R2L_P_BLACK_LEVEL + s];
-  for (int par = 0; par < 4; ++par)
-    for (int t = 0; t < 9; ++t) {
-      const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
-      const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
-      double a[3];
-      for (int k = 0; k < 3; ++k) {
-        double s = 0;
-        for (int j = 0; j < 3; ++j) s += T[k][j] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
-        a[k] = s;
-      }
-      F->AY[par][t] = (float)a[0];
-      F->AU[par][t] = (float)a[1];
-      F->AV[par][t] = (float)a[2];
-    }
-  for (int i = 0; i < 9; ++i) F->sharp[i] = P[R2L_P_SHARPEN + i];
-  for (int i = 0; i < 25; ++i) F->blur[i] = P[R2L_P_BLUR + i];
-  for (int i = 0; i < 9; ++i) F->M2[i] = P[R2L_P_M_YUV2RGB + i];
-  F->gamma = P[R2L_P_GAMMA];
-  F->inv_gamma = (float)(1.0 / (double)P[R2L_P_GAMMA]);
-  F->pad[0] = F->pad[1] = 0.f;
 }
+// element `idx` (float index into R2LFolded) of the folded block; one lane per element
+R2L_HD void r2l_fold_one(const float* P, R2LFolded* F, int idx) {
+  float* out = (float*)F;
+  const int o_ay = 4, o_sharp = 4 + 108, o_blur = o_sharp + 9, o_m2 = o_blur + 25, o_ig = o_m2 + 9;
+  if (idx < 4) {
+    out[idx] = P[R2L_P_BLACK_LEVEL + idx];
+  } else if (idx < o_sharp) {
+    const int e = idx - o_ay, k = e / 36, par = (e % 36) / 9, t = e % 9;
+    const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
+    const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
+    double T[3][3];
+    r2l_fold_T(P, T);
+    double s = 0;
+    for (int j = 0; j < 3; ++j) s += T[k][j] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
+    out[idx] = (float)s;
+  } else if (idx < o_blur) {
+    out[idx] = P[R2L_P_SHARPEN + idx - o_sharp];
+  } else if (idx < o_m2) {
+    out[idx] = P[R2L_P_BLUR + idx - o_blur];
+  } else if (idx < o_ig) {
+    out[idx] = P[R2L_P_M_YUV2RGB + idx - o_m2];
+  } else if (idx == o_ig) {
+    out[idx] = (float)(1.0 / (double)P[R2L_P_GAMMA]);
+  } else if (idx == o_ig + 1) {
+    out[idx] = P[R2L_P_GAMMA];
+  } else {
+    out[idx] = 0.f;
+  }
+}
+#define R2L_FOLDED_NFLOATS ((int)(sizeof(R2LFolded) / sizeof(float)))
 
 // ---- reduction slots of the backward kernels ----------------------------------------------------
 // B1 (pixel kernel): sums over pixels p of the tile interior
@@ -200,8 +209,9 @@ enum {
 };
 #define R2L_NSUMS (R2L_B1_NACC + R2L_B2_NACC)
 
-// Unfold the reduced sums into gradients of the 132 trainable parameters (float64 throughout).
-R2L_HD void r2l_unfold_grads(const float* P, const double* S, float* gp) {
+// Unfold the reduced sums into the gradient of trainable parameter `o` (index into the packed block);
+// float64 throughout, one lane per parameter.
+R2L_HD float r2l_unfold_one(const float* P, const double* S, int o) {
   const double* b1 = S;
   const double* b2 = S + R2L_B1_NACC;
   double T[3][3], M1[3][3], ccm[3][3], wb[3];
@@ -211,52 +221,64 @@ R2L_HD void r2l_unfold_grads(const float* P, const double* S, float* gp) {
       M1[k][c] = P[R2L_P_M_RGB2YUV + k * 3 + c];
       ccm[k][c] = P[R2L_P_CCM + k * 3 + c];
     }
-  for (int k = 0; k < 3; ++k)
-    for (int c = 0; c < 3; ++c) {
-      double s = 0;
-      for (int j = 0; j < 3; ++j) s += M1[k][j] * ccm[j][c];
-      T[k][c] = s * wb[c];
+  r2l_fold_T(P, T);
+  if (o >= R2L_P_SHARPEN && o < R2L_P_BLUR) return (float)b2[R2L_B2_GSHARP + o - R2L_P_SHARPEN];
+  if (o >= R2L_P_BLUR && o < R2L_P_NTRAIN) return (float)b1[R2L_B1_GBLUR + o - R2L_P_BLUR];
+  if (o == R2L_P_GAMMA) {
+    const double gamma = P[R2L_P_GAMMA];
+    return (float)(-b1[R2L_B1_GGAM] * R2L_LN2 / (gamma * gamma));
+  }
+  if (o >= R2L_P_DEBAYER && o < R2L_P_SHARPEN) {  // debayer.weight[j][c][t]
+    const int e = o - R2L_P_DEBAYER, j = e / 27, c = (e % 27) / 9, t = e % 9;
+    const int dy = t / 3 - 1, dx = t % 3 - 1;
+    double g = 0;
+    for (int k = 0; k < 3; ++k) {
+      const double* GA = (k == 0) ? (b2 + R2L_B2_GAY) : (k == 1 ? b1 + R2L_B1_GAU : b1 + R2L_B1_GAV);
+      for (int par = 0; par < 4; ++par)
+        if (r2l_site_channel((par >> 1) + dy + 2, (par & 1) + dx + 2) == c) g += T[k][j] * GA[par * 9 + t];
     }
-  double gdeb[81], gT[3][3], gbl[4];
-  for (int i = 0; i < 81; ++i) gdeb[i] = 0;
-  for (int k = 0; k < 3; ++k)
-    for (int j = 0; j < 3; ++j) gT[k][j] = 0;
-  for (int s = 0; s < 4; ++s) gbl[s] = 0;
+    return (float)g;
+  }
+  if (o < R2L_P_WHITE_BALANCE) {  // black_level[site]
+    double g = 0;
+    for (int k = 0; k < 3; ++k) {
+      const double* SS = (k == 0) ? (b2 + R2L_B2_SY) : (k == 1 ? b1 + R2L_B1_SU : b1 + R2L_B1_SV);
+      for (int par = 0; par < 4; ++par)
+        for (int t = 0; t < 9; ++t) {
+          const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
+          const int site = ((py + dy + 2) & 1) * 2 + ((px + dx + 2) & 1);
+          if (site != o) continue;
+          const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
+          double a = 0;
+          for (int j = 0; j < 3; ++j) a += T[k][j] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
+          g -= a * SS[par];
+        }
+    }
+    return (float)g;
+  }
+  // white balance / colour matrix: through gT[k][c] = sum_{par,t} GA[k][par][t] * deb[c][chan(par,t)][t]
+  double gT[3][3];
   for (int k = 0; k < 3; ++k) {
     const double* GA = (k == 0) ? (b2 + R2L_B2_GAY) : (k == 1 ? b1 + R2L_B1_GAU : b1 + R2L_B1_GAV);
-    const double* SS = (k == 0) ? (b2 + R2L_B2_SY) : (k == 1 ? b1 + R2L_B1_SU : b1 + R2L_B1_SV);
-    for (int par = 0; par < 4; ++par)
-      for (int t = 0; t < 9; ++t) {
-        const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
-        const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
-        const int site = ((py + dy + 2) & 1) * 2 + ((px + dx + 2) & 1);
-        const double ga = GA[par * 9 + t];
-        double a = 0;
-        for (int j = 0; j < 3; ++j) {
-          const double w = P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
-          gdeb[(j * 3 + c) * 9 + t] += T[k][j] * ga;
-          gT[k][j] += ga * w;
-          a += T[k][j] * w;
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+      for (int par = 0; par < 4; ++par)
+        for (int t = 0; t < 9; ++t) {
+          const int c = r2l_site_channel((par >> 1) + t / 3 + 1, (par & 1) + t % 3 + 1);
+          s += GA[par * 9 + t] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
         }
-        gbl[site] -= a * SS[par];
-      }
+      gT[k][j] = s;
+    }
   }
-  for (int s = 0; s < 4; ++s) gp[R2L_P_BLACK_LEVEL + s] = (float)gbl[s];
-  for (int c = 0; c < 3; ++c) {
+  if (o < R2L_P_CCM) {
+    const int c = o - R2L_P_WHITE_BALANCE;
     double g = 0;
     for (int k = 0; k < 3; ++k)
       for (int j = 0; j < 3; ++j) g += gT[k][c] * M1[k][j] * ccm[j][c];
-    gp[R2L_P_WHITE_BALANCE + c] = (float)g;
+    return (float)g;
   }
-  for (int j = 0; j < 3; ++j)
-    for (int c = 0; c < 3; ++c) {
-      double g = 0;
-      for (int k = 0; k < 3; ++k) g += gT[k][c] * M1[k][j] * wb[c];
-      gp[R2L_P_CCM + j * 3 + c] = (float)g;
-    }
-  const double gamma = P[R2L_P_GAMMA];
-  gp[R2L_P_GAMMA] = (float)(-b1[R2L_B1_GGAM] * R2L_LN2 / (gamma * gamma));
-  for (int i = 0; i < 81; ++i) gp[R2L_P_DEBAYER + i] = (float)gdeb[i];
-  for (int i = 0; i < 9; ++i) gp[R2L_P_SHARPEN + i] = (float)b2[R2L_B2_GSHARP + i];
-  for (int i = 0; i < 25; ++i) gp[R2L_P_BLUR + i] = (float)b1[R2L_B1_GBLUR + i];
+  const int j = (o - R2L_P_CCM) / 3, c = (o - R2L_P_CCM) % 3;
+  double g = 0;
+  for (int k = 0; k < 3; ++k) g += gT[k][c] * M1[k][j] * wb[c];
+  return (float)g;
 }

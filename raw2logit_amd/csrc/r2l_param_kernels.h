@@ -103,24 +103,34 @@ struct R2LChunkWalk {
   }
 };
 
-template <class G, bool BORDER>
-R2L_HD void r2l_load_v(int tid, float* V, const float* rawb, R2LFoldedRef F, int oy, int ox, int H,
-                       int W) {
+// Software pipeline of the tile loop: the raw chunks of the NEXT tile are fetched into registers at the
+// start of the current tile's pixel phase (their HBM latency hides behind ~1400 VALU instructions) and
+// written to LDS after the phase barrier.
+template <class G>
+struct R2LPrefetch {
+  static constexpr int NIT = (R2LChunkWalk<G>::CPR * G::FH + R2L_NT - 1) / R2L_NT;
+  r2l_f4 v[NIT];
+};
+
+// MODE 0: raw frame values with mirror coordinates outside the image (the V plane before black level)
+// MODE 1: plain plane, zero outside the image
+template <class G, bool BORDER, int MODE>
+R2L_HD void r2l_fetch_frame(int tid, const float* gb, int oy, int ox, int H, int W, R2LPrefetch<G>& pf) {
   R2LChunkWalk<G> w;
   w.init(tid);
-  constexpr int NIT = (R2LChunkWalk<G>::CPR * G::FH + R2L_NT - 1) / R2L_NT;
   const bool vec_ok = (W & 3) == 0;
   R2L_PRAGMA_UNROLL
-  for (int it = 0; it < NIT; ++it) {
+  for (int it = 0; it < R2LPrefetch<G>::NIT; ++it) {
+    r2l_f4 v;
+    v.x = v.y = v.z = v.w = 0.f;
     if (w.fy < G::FH) {
       const int fy = w.fy, cx = w.cx;
       const int gx0 = ox - 4 + 4 * cx;
-      r2l_f4 v;
       if (!BORDER) {
-        v = *(const r2l_f4*)(rawb + (size_t)(oy - 4 + fy) * W + gx0);
-      } else {
+        v = *(const r2l_f4*)(gb + (size_t)(oy - 4 + fy) * W + gx0);
+      } else if (MODE == 0) {
         const int gy = r2l_mirror(oy - 4 + fy, H);
-        const float* row = rawb + (size_t)gy * W;
+        const float* row = gb + (size_t)gy * W;
         if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
           v = *(const r2l_f4*)(row + gx0);
         } else {
@@ -129,37 +139,8 @@ R2L_HD void r2l_load_v(int tid, float* V, const float* rawb, R2LFoldedRef F, int
           v.z = row[r2l_mirror(gx0 + 2, W)];
           v.w = row[r2l_mirror(gx0 + 3, W)];
         }
-      }
-      // mirror padding keeps the Bayer parity, so the site follows from the frame coordinates
-      const float b0 = (fy & 1) ? F.bl[2] : F.bl[0], b1 = (fy & 1) ? F.bl[3] : F.bl[1];
-      v.x -= b0;
-      v.y -= b1;
-      v.z -= b0;
-      v.w -= b1;
-      *(r2l_f4*)(V + fy * G::FS + 4 * cx) = v;
-    }
-    w.next();
-  }
-}
-
-// a plane of the frame from a (B,H,W) global plane, ZERO outside the image, stored shifted by +2
-template <class G, bool BORDER>
-R2L_HD void r2l_load_plane_zero_s2(int tid, float* Pl, const float* gb, int oy, int ox, int H, int W) {
-  R2LChunkWalk<G> w;
-  w.init(tid);
-  constexpr int NIT = (R2LChunkWalk<G>::CPR * G::FH + R2L_NT - 1) / R2L_NT;
-  const bool vec_ok = (W & 3) == 0;
-  R2L_PRAGMA_UNROLL
-  for (int it = 0; it < NIT; ++it) {
-    if (w.fy < G::FH) {
-      const int fy = w.fy, cx = w.cx;
-      const int gy = oy - 4 + fy;
-      const int gx0 = ox - 4 + 4 * cx;
-      r2l_f4 v;
-      if (!BORDER) {
-        v = *(const r2l_f4*)(gb + (size_t)gy * W + gx0);
       } else {
-        v.x = v.y = v.z = v.w = 0.f;
+        const int gy = oy - 4 + fy;
         if ((unsigned)gy < (unsigned)H) {
           const float* row = gb + (size_t)gy * W;
           if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
@@ -172,7 +153,51 @@ R2L_HD void r2l_load_plane_zero_s2(int tid, float* Pl, const float* gb, int oy, 
           }
         }
       }
-      float* d = Pl + fy * G::FS + 4 * cx + 2;
+    }
+    pf.v[it] = v;
+    w.next();
+  }
+}
+template <class G, int MODE>
+R2L_HD void r2l_fetch_tile(int tid, const float* gb, const R2LTile& t, int H, int W, R2LPrefetch<G>& pf) {
+  const float* base = gb + (size_t)t.b * H * W;
+  if (t.border)
+    r2l_fetch_frame<G, true, MODE>(tid, base, t.oy, t.ox, H, W, pf);
+  else
+    r2l_fetch_frame<G, false, MODE>(tid, base, t.oy, t.ox, H, W, pf);
+}
+
+// registers -> V plane, black level removed (mirror padding keeps the Bayer parity, so the site follows
+// from the frame coordinates)
+template <class G>
+R2L_HD void r2l_store_v(int tid, float* V, R2LFoldedRef F, const R2LPrefetch<G>& pf) {
+  R2LChunkWalk<G> w;
+  w.init(tid);
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < R2LPrefetch<G>::NIT; ++it) {
+    if (w.fy < G::FH) {
+      const int fy = w.fy, cx = w.cx;
+      r2l_f4 v = pf.v[it];
+      const float b0 = (fy & 1) ? F.bl[2] : F.bl[0], b1 = (fy & 1) ? F.bl[3] : F.bl[1];
+      v.x -= b0;
+      v.y -= b1;
+      v.z -= b0;
+      v.w -= b1;
+      *(r2l_f4*)(V + fy * G::FS + 4 * cx) = v;
+    }
+    w.next();
+  }
+}
+// registers -> plane stored shifted by +2 columns
+template <class G>
+R2L_HD void r2l_store_plane_s2(int tid, float* Pl, const R2LPrefetch<G>& pf) {
+  R2LChunkWalk<G> w;
+  w.init(tid);
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < R2LPrefetch<G>::NIT; ++it) {
+    if (w.fy < G::FH) {
+      const r2l_f4 v = pf.v[it];
+      float* d = Pl + w.fy * G::FS + 4 * w.cx + 2;
       r2l_f2 lo, hi;
       lo.x = v.x;
       lo.y = v.y;
@@ -231,7 +256,7 @@ R2L_HD void r2l_compute_y(int tid, const float* V, float* Y, R2LFoldedRef F, int
   constexpr int NIT = (CPR * NRP + R2L_NT - 1) / R2L_NT;
   R2LItemWalk<CPR> iw;
   iw.init(tid);
-  R2L_PRAGMA_UNROLL
+  R2L_PRAGMA_NOUNROLL
   for (int it = 0; it < NIT; ++it) {
     if (iw.row < NRP) {
       const int fy = 1 + 2 * iw.row, fx = 4 * iw.col;  // fy is odd
@@ -278,7 +303,7 @@ R2L_HD void r2l_compute_yp(int tid, const float* Y, float* YP, R2LFoldedRef F) {
   constexpr int NIT = (CPR * NRP + R2L_NT - 1) / R2L_NT;
   R2LItemWalk<CPR> iw;
   iw.init(tid);
-  R2L_PRAGMA_UNROLL
+  R2L_PRAGMA_NOUNROLL
   for (int it = 0; it < NIT; ++it) {
     if (iw.row < NRP) {
       const int fy = 2 + 2 * iw.row, fx = 4 * iw.col;
@@ -312,16 +337,31 @@ R2L_HD void r2l_compute_yp(int tid, const float* Y, float* YP, R2LFoldedRef F) {
 
 // ---- phase C2 (border tiles): mirror-extend YP outside the image (padding_mode='reflect', :165) ---
 template <class G>
+R2L_HD void r2l_fill_yp_one(float* YP, int fy, int fx, int oy, int ox, int H, int W) {
+  const int gy = oy - 4 + fy, gx = ox - 4 + fx;
+  const int my = r2l_mirror(gy, H) - (oy - 4), mx = r2l_mirror(gx, W) - (ox - 4);
+  if (my >= 2 && my < G::FH - 2 && mx >= 2 && mx < G::FW - 2)
+    YP[fy * G::FS + fx + 2] = YP[my * G::FS + mx + 2];
+}
+R2L_HD int r2l_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// Only the strips outside the image are visited: columns [2,cl) u [cr,FW-2) over all rows, then rows
+// [2,rt) u [rb,FH-2) over the in-image columns [cl,cr).
+template <class G>
 R2L_HD void r2l_fill_yp_mirror(int tid, float* YP, int oy, int ox, int H, int W) {
-  constexpr int NW = G::FW - 4, NH = G::FH - 4;
-  for (int i = tid; i < NW * NH; i += R2L_NT) {
-    const int fy = 2 + i / NW, fx = 2 + i % NW;
-    const int gy = oy - 4 + fy, gx = ox - 4 + fx;
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) continue;
-    const int my = r2l_mirror(gy, H) - (oy - 4), mx = r2l_mirror(gx, W) - (ox - 4);
-    if (my >= 2 && my < G::FH - 2 && mx >= 2 && mx < G::FW - 2)
-      YP[fy * G::FS + fx + 2] = YP[my * G::FS + mx + 2];
-  }
+  const int cl = r2l_clampi(4 - ox, 2, G::FW - 2), cr = r2l_clampi(W - ox + 4, 2, G::FW - 2);
+  const int rt = r2l_clampi(4 - oy, 2, G::FH - 2), rb = r2l_clampi(H - oy + 4, 2, G::FH - 2);
+  const int wl = cl - 2, wa = wl + (G::FW - 2 - cr);
+  if (wa > 0)
+    for (int i = tid; i < wa * (G::FH - 4); i += R2L_NT) {
+      const int r = i / wa, k = i - r * wa;
+      r2l_fill_yp_one<G>(YP, 2 + r, k < wl ? 2 + k : cr + (k - wl), oy, ox, H, W);
+    }
+  const int ht = rt - 2, hb = ht + (G::FH - 2 - rb), wc = cr - cl;
+  if (hb > 0 && wc > 0)
+    for (int i = tid; i < hb * wc; i += R2L_NT) {
+      const int k = i / wc, c = i - k * wc;
+      r2l_fill_yp_one<G>(YP, k < ht ? 2 + k : rb + (k - ht), cl + c, oy, ox, H, W);
+    }
 }
 
 // ---- phase D helpers: each thread owns a 4x4 micro-tile and walks it ONE OUTPUT ROW AT A TIME -------
@@ -537,63 +577,44 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   float* Y = V + G::PLANE;
   float* YP = Y + G::PLANE;
   R2L_TREG_DECL(R2LFwdRegs, regs);
+  R2L_TREG_DECL(R2LPrefetch<G>, pre);
+  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
+  R2LTile t, tn;
+  bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 6; ++i) R2L_TREG(regs).acc[i] = 0.f;
+  if (have) r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   R2L_PHASE_END
-#ifdef R2L_EXP_STAMPS
-  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t0_ = __builtin_amdgcn_s_memtime(), t1_;
-#define R2L_STAMP(k) t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - t0_; t0_ = t1_;
-#else
-#define R2L_STAMP(k)
-#endif
-  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
-  R2LTile t;
-  while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
-    const float* rawb = a.raw + (size_t)t.b * a.H * a.W;
-#ifndef R2L_EXP_SKIP_LOAD
+  while (have) {
     R2L_PHASE_BEGIN
-    if (t.border)
-      r2l_load_v<G, true>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
-    else
-      r2l_load_v<G, false>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
+    r2l_store_v<G>(tid, V, F, R2L_TREG(pre));
     R2L_PHASE_END
-    R2L_STAMP(0)
-#endif
-#ifndef R2L_EXP_SKIP_BC
+    const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
     if (t.border)
       r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     else
       r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
-    R2L_STAMP(1)
     R2L_PHASE_BEGIN
     r2l_compute_yp<G>(tid, Y, YP, F);
     R2L_PHASE_END
-    R2L_STAMP(2)
     if (t.border) {
       R2L_PHASE_BEGIN
       r2l_fill_yp_mirror<G>(tid, YP, t.oy, t.ox, a.H, a.W);
       R2L_PHASE_END
-      R2L_STAMP(3)
     }
-#endif
-#ifndef R2L_EXP_SKIP_PIX
     R2L_PHASE_BEGIN
+    if (haven) r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));  // next tile, in flight
     if (MAYBE_RAGGED && t.ragged)
       r2l_fwd_pixels<G, MAYBE_RAGGED, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     else
       r2l_fwd_pixels<G, false, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
-    R2L_STAMP(4)
-#endif
+    t = tn;
+    have = haven;
   }
-#ifdef R2L_EXP_STAMPS
-  if (threadIdx.x == 0 && a.out)
-    for (int k = 0; k < 8; ++k) a.out[(size_t)bid * 8 + k] = (float)st_[k];
-#endif
   if (a.stat_partial) {
     R2L_BLOCK_REDUCE(6, regs, lds, a.stat_partial, bid, nblk)
   }
@@ -790,6 +811,10 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   float* Y = V + G::PLANE;
   float* YP = Y + G::PLANE;
   R2L_TREG_DECL(R2LBwd1Regs, regs);
+  R2L_TREG_DECL(R2LPrefetch<G>, pre);
+  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
+  R2LTile t, tn;
+  bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < R2L_L1_NACC; ++i) R2L_TREG(regs).acc[i] = 0.f;
@@ -797,17 +822,13 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     int tx_, row_;
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
   }
+  if (have) r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   R2L_PHASE_END
-  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
-  R2LTile t;
-  while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
-    const float* rawb = a.raw + (size_t)t.b * a.H * a.W;
+  while (have) {
     R2L_PHASE_BEGIN
-    if (t.border)
-      r2l_load_v<G, true>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
-    else
-      r2l_load_v<G, false>(tid, V, rawb, F, t.oy, t.ox, a.H, a.W);
+    r2l_store_v<G>(tid, V, F, R2L_TREG(pre));
     R2L_PHASE_END
+    const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
     if (t.border)
       r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
@@ -823,11 +844,14 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
       R2L_PHASE_END
     }
     R2L_PHASE_BEGIN
+    if (haven) r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
     if (MAYBE_RAGGED && t.ragged)
       r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     else
       r2l_bwd1_pixels<G, false, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
+    t = tn;
+    have = haven;
   }
   R2L_BLOCK_REDUCE_F(R2L_B1_NACC, R2L_ACC_B1, regs, lds, a.partial, bid, nblk)
 }
@@ -1012,6 +1036,11 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
   float* Y = G2;
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   R2L_TREG_DECL(R2LBwd2Regs, regs);
+  R2L_TREG_DECL(R2LPrefetch<G>, pre_v);
+  R2L_TREG_DECL(R2LPrefetch<G>, pre_g);
+  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
+  R2LTile t, tn;
+  bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < R2L_L2_NACC; ++i) R2L_TREG(regs).acc[i] = 0.f;
@@ -1019,20 +1048,17 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     int tx_, row_;
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
   }
+  if (have) {
+    r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre_v));
+    r2l_fetch_tile<G, 1>(tid, a.gypp, t, a.H, a.W, R2L_TREG(pre_g));
+  }
   R2L_PHASE_END
-  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
-  R2LTile t;
-  while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
-    const size_t off = (size_t)t.b * a.H * a.W;
+  while (have) {
     R2L_PHASE_BEGIN
-    if (t.border) {
-      r2l_load_v<G, true>(tid, V, a.raw + off, F, t.oy, t.ox, a.H, a.W);
-      r2l_load_plane_zero_s2<G, true>(tid, G2, a.gypp + off, t.oy, t.ox, a.H, a.W);
-    } else {
-      r2l_load_v<G, false>(tid, V, a.raw + off, F, t.oy, t.ox, a.H, a.W);
-      r2l_load_plane_zero_s2<G, false>(tid, G2, a.gypp + off, t.oy, t.ox, a.H, a.W);
-    }
+    r2l_store_v<G>(tid, V, F, R2L_TREG(pre_v));
+    r2l_store_plane_s2<G>(tid, G2, R2L_TREG(pre_g));
     R2L_PHASE_END
+    const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
     r2l_adjoint_blur<G>(tid, G2, HP, F);
     R2L_PHASE_END
@@ -1045,11 +1071,17 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     }
     R2L_PHASE_END
     R2L_PHASE_BEGIN
+    if (haven) {
+      r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre_v));
+      r2l_fetch_tile<G, 1>(tid, a.gypp, tn, a.H, a.W, R2L_TREG(pre_g));
+    }
     if (t.border)
       r2l_bwd2_pixels<G, true>(tid, V, Y, HP, a, t, R2L_TREG(regs));
     else
       r2l_bwd2_pixels<G, false>(tid, V, Y, HP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
+    t = tn;
+    have = haven;
   }
   R2L_BLOCK_REDUCE_F(R2L_B2_NACC, R2L_ACC_B2, regs, lds, a.partial, bid, nblk)
 }

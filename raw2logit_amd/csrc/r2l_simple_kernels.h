@@ -3,7 +3,7 @@
 #pragma once
 #include "r2l_param_kernels.h"
 
-// ---- fold / unfold (one lane; ~500 float64 FMAs) ------------------------------------------------
+// ---- fold / unfold (one lane per element, float64) ------------------------------------------------
 struct R2LFoldArgs {
   const float* params;
   R2LFolded* F;
@@ -13,7 +13,7 @@ R2L_BLOCKFN void r2l_fold_block(const R2LFoldArgs& a, int bid, int nblk, float* 
   (void)nblk;
   (void)lds;
   R2L_PHASE_BEGIN
-  if (tid == 0) r2l_fold_params(a.params, a.F);
+  if (tid < R2L_FOLDED_NFLOATS) r2l_fold_one(a.params, a.F, tid);
   R2L_PHASE_END
 }
 
@@ -27,7 +27,7 @@ R2L_BLOCKFN void r2l_unfold_block(const R2LUnfoldArgs& a, int bid, int nblk, flo
   (void)nblk;
   (void)lds;
   R2L_PHASE_BEGIN
-  if (tid == 0) r2l_unfold_grads(a.params, a.sums, a.grad_params);
+  if (tid < R2L_P_NTRAIN) a.grad_params[tid] = r2l_unfold_one(a.params, a.sums, tid);
   R2L_PHASE_END
 }
 

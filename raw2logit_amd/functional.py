@@ -141,11 +141,13 @@ class _IspFused(torch.autograd.Function):
             bn = torch.cat([mean, istd]).to(torch.float32)
         out = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(out), None,
-                                  ptr(ws), nws, B, H, W, 0, stream), 'r2l_isp_fwd')
+                                  ptr(ws), nws, B, H, W,
+                                  _lib.R2L_F_FOLDED_VALID if bn_mode == BN_TRAIN else 0, stream), 'r2l_isp_fwd')
         ctx.bn_mode = bn_mode
         ctx.group = group
         ctx.has_additive = additive is not None
         ctx.save_for_backward(raw, packed, additive, bn, out)
+        ctx.ws = ws           # holds the folded weights of `packed`: the backward skips re-folding
         if mean is None:
             mean = var = torch.zeros(3, dtype=torch.float64, device=dev)
         ctx.mark_non_differentiable(mean, var)
@@ -161,7 +163,7 @@ class _IspFused(torch.autograd.Function):
         gout = _f32c(gout, 'grad_out')
         B, H, W = raw.shape
         lib, stream = _lib.library_for(raw)
-        ws, nws = _workspace(lib, raw, B, H, W)
+        ws, nws = ctx.ws, ctx.ws.numel()
         bn_bwd = None
         if ctx.bn_mode == BN_TRAIN:
             sums = torch.empty(6, dtype=torch.float64, device=raw.device)
@@ -174,7 +176,8 @@ class _IspFused(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gp = torch.empty(_lib.R2L_P_NTRAIN, dtype=torch.float32, device=raw.device)
             lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(bn_bwd),
-                                      ptr(gout), ptr(gp), None, ptr(ws), nws, B, H, W, 0, stream),
+                                      ptr(gout), ptr(gp), None, ptr(ws), nws, B, H, W,
+                                      _lib.R2L_F_FOLDED_VALID, stream),
                       'r2l_isp_bwd')
             gpacked = torch.cat([gp, gp.new_zeros(_lib.R2L_P_COUNT - _lib.R2L_P_NTRAIN)])
         gadd = None
