@@ -101,6 +101,14 @@ int r2l_isp_fwd(const float *raw, const float *params, const float *additive,
                 const float *bn_mean_istd, float *out, double *stats, void *workspace,
                 size_t workspace_bytes, int B, int H, int W, int flags, void *stream);
 
+/* BatchNorm2d(3, affine=False) bookkeeping of train mode (:216-217) without a host round trip.
+ * totals double[7] = the `stats` vector of r2l_isp_fwd summed over all ranks, followed by the total pixel
+ * count per channel n.  Writes bn_mean_istd float[6] (for the apply pass), optionally moments double[6] =
+ * batch mean[3], biased variance[3], and optionally updates running_mean / running_var float[3] the way
+ * nn.BatchNorm2d does (momentum, unbiased variance).                                              */
+int r2l_bn_finalize(const double *totals, float *bn_mean_istd, double *moments, float *running_mean,
+                    float *running_var, double eps, double momentum, void *stream);
+
 /* BatchNorm backward reduction (nn.BatchNorm2d backward in train mode, :216-217):
  * sums double[6] = sum_c(g)[3], sum_c(g*xhat)[3] with xhat == the saved forward output.          */
 int r2l_bn_bwd_reduce(const float *grad_out, const float *out, double *sums, void *workspace,

@@ -41,6 +41,8 @@ _SIGNATURES = {
     'r2l_isp_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_bn_finalize': (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p,
+                                       ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
     'r2l_bn_bwd_reduce': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p]),
@@ -121,7 +123,9 @@ def ptr(t):
 
 
 def hipcc_command(out_path=LIB_PATH):
-    return ['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-shared', '-fPIC',
+    # -fno-slp-vectorize: the SLP vectoriser pairs the stencil FMAs into v_pk_fma_f32 at the price of
+    # register shuffles (v_pk_mov) and ~100 more live VGPRs in the backward kernel, which costs occupancy
+    return ['hipcc', '-O3', '-std=c++17', '-fno-slp-vectorize', '--offload-arch=gfx950', '-shared', '-fPIC',
             os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path]
 
 

@@ -105,15 +105,16 @@ static_assert(R2L_LDS3(GBwd2) >= R2L_RED_FLOATS, "reduction scratch must fit");
 
 R2L_KERNEL(r2l_launch_fold, R2LFoldArgs, r2l_fold_block, 4)
 R2L_KERNEL(r2l_launch_unfold, R2LUnfoldArgs, r2l_unfold_block, 4)
+R2L_KERNEL(r2l_launch_bn_finalize, R2LBnFinalizeArgs, r2l_bn_finalize_block, 4)
 R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 * R2L_NT)
 #ifndef R2L_OCC_FWD
-#define R2L_OCC_FWD 2
+#define R2L_OCC_FWD 4
 #endif
 #ifndef R2L_OCC_BWD1
-#define R2L_OCC_BWD1 1
+#define R2L_OCC_BWD1 2
 #endif
 #ifndef R2L_OCC_BWD2
-#define R2L_OCC_BWD2 1
+#define R2L_OCC_BWD2 2
 #endif
 // hot instantiation (frames that tile exactly, no additive layer) + the general ones
 R2L_KERNEL_V(r2l_launch_fwd, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false>)
@@ -282,6 +283,15 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
   return 0;
 }
 
+int r2l_bn_finalize(const double* totals, float* bn_mean_istd, double* moments, float* running_mean,
+                    float* running_var, double eps, double momentum, void* stream) {
+  if (!totals || !bn_mean_istd) return r2l_fail(-1, "r2l_bn_finalize: null pointer");
+  if ((running_mean == nullptr) != (running_var == nullptr))
+    return r2l_fail(-1, "r2l_bn_finalize: running_mean and running_var go together");
+  R2LBnFinalizeArgs a{totals, bn_mean_istd, moments, running_mean, running_var, eps, momentum};
+  return r2l_launch_bn_finalize(a, 1, stream);
+}
+
 int r2l_bn_bwd_reduce(const float* grad_out, const float* out, double* sums, void* workspace,
                       size_t workspace_bytes, int B, int H, int W, void* stream) {
   if (int e = r2l_check_dims(B, H, W)) return e;
@@ -348,7 +358,7 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
   R2LReduceRowsArgs r2{ws.part_b2, ws.sums + R2L_B1_NACC, g2, 1.0};
   if (int e = r2l_launch_reduce_rows(r2, R2L_B2_NACC, stream)) return e;
-  R2LUnfoldArgs ua{params, ws.sums, grad_params};
+  R2LUnfoldArgs ua{params, ws.sums, grad_params, 1.0f};
   return r2l_launch_unfold(ua, 1, stream);
 }
 

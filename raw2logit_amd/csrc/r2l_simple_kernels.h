@@ -21,13 +21,53 @@ struct R2LUnfoldArgs {
   const float* params;
   const double* sums;  // [R2L_NSUMS]
   float* grad_params;  // [R2L_P_NTRAIN]
+  float scale;
 };
 R2L_BLOCKFN void r2l_unfold_block(const R2LUnfoldArgs& a, int bid, int nblk, float* lds) {
   (void)bid;
   (void)nblk;
   (void)lds;
   R2L_PHASE_BEGIN
-  if (tid < R2L_P_NTRAIN) a.grad_params[tid] = r2l_unfold_one(a.params, a.sums, tid);
+  if (tid < R2L_P_NTRAIN) a.grad_params[tid] = r2l_unfold_one(a.params, a.sums, tid) * a.scale;
+  R2L_PHASE_END
+}
+
+// ---- BatchNorm bookkeeping on the device (no host round trip) ---------------------------------------
+// tot[7] = sum_c(x-.5)[3], sum_c((x-.5)^2)[3], n  (already summed over ranks)  ->
+//   bn[6]       = mean[3], 1/sqrt(var_biased + eps)[3]                (what the apply pass consumes)
+//   moments[6]  = mean[3], var_biased[3] (float64)
+//   running_mean / running_var (optional): nn.BatchNorm2d update with `momentum`, unbiased variance
+struct R2LBnFinalizeArgs {
+  const double* tot;
+  float* bn;
+  double* moments;
+  float* running_mean;
+  float* running_var;
+  double eps, momentum;
+};
+R2L_BLOCKFN void r2l_bn_finalize_block(const R2LBnFinalizeArgs& a, int bid, int nblk, float* lds) {
+  (void)bid;
+  (void)nblk;
+  (void)lds;
+  R2L_PHASE_BEGIN
+  if (tid < 3) {
+    const double n = a.tot[6];
+    const double m1 = a.tot[tid] / n;
+    double var = a.tot[3 + tid] / n - m1 * m1;
+    var = var < 0.0 ? 0.0 : var;
+    const double mean = m1 + 0.5;
+    a.bn[tid] = (float)mean;
+    a.bn[3 + tid] = (float)(1.0 / sqrt(var + a.eps));
+    if (a.moments) {
+      a.moments[tid] = mean;
+      a.moments[3 + tid] = var;
+    }
+    if (a.running_mean) {
+      const double unb = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+      a.running_mean[tid] = (float)((1.0 - a.momentum) * (double)a.running_mean[tid] + a.momentum * mean);
+      a.running_var[tid] = (float)((1.0 - a.momentum) * (double)a.running_var[tid] + a.momentum * unb);
+    }
+  }
   R2L_PHASE_END
 }
 

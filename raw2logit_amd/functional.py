@@ -85,34 +85,40 @@ def raw2rgb(raw, black_level=None, reduce_size=True, out_channels=3):
 # --------------------------------------------------------------------------------------------------
 BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
 
+# (name, offset, numel) of the trainable tensors inside the packed block (include/r2l_isp.h, R2L_P_*)
+PARAM_LAYOUT = (('black_level', 0, 4), ('white_balance', 4, 3), ('colour_correction', 7, 9),
+                ('gamma_correct', 16, 1), ('debayer.weight', 17, 81), ('sharpening_filter.weight', 98, 9),
+                ('gaussian_blur.weight', 107, 25))
 
-def batch_moments(stats, n_local, group=None):
-    """(sum(x-.5)[3], sum((x-.5)^2)[3]) of this rank -> global batch mean and biased variance.
 
-    With several ranks the 7-vectors (sums, n) are all-gathered over RCCL/xGMI and added in rank order,
-    so every rank gets bit-identical statistics equal to the single-GPU statistics of the global batch."""
-    vec = torch.cat([stats, torch.tensor([float(n_local)], dtype=torch.float64, device=stats.device)])
+def gather_totals(stats, n_local, group=None):
+    """(sum(x-.5)[3], sum((x-.5)^2)[3]) of this rank -> the same sums over all ranks + pixel count.
+
+    With several ranks the 7-vectors are all-gathered over RCCL/xGMI and added in rank order, so every rank
+    gets bit-identical statistics, equal to the single-GPU statistics of the global batch."""
+    vec = torch.empty(7, dtype=torch.float64, device=stats.device)
+    vec[:6] = stats
+    vec[6] = float(n_local)
     if _group_size(group) > 1:
         gathered = [torch.empty_like(vec) for _ in range(dist.get_world_size(group))]
         dist.all_gather(gathered, vec, group=group)
         vec = torch.stack(gathered, 0).sum(0)
-    n = vec[6]
-    m1 = vec[:3] / n
-    mean = m1 + 0.5
-    var = (vec[3:6] / n - m1 * m1).clamp_min_(0.0)
-    return mean, var, n
+    return vec
 
 
 class _IspFused(torch.autograd.Function):
-    """out, batch_mean, batch_var = f(raw, packed_params, additive | None, ...).
+    """out, batch_moments = f(raw, 7 parameter tensors, M_RGB_2_YUV, M_YUV_2_RGB, additive | None, ...).
 
-    packed_params: float32[150] in the layout of include/r2l_isp.h (built with torch.cat from the
-    module's nn.Parameters, so autograd scatters the 132-float gradient back by itself)."""
+    The parameters are packed into the float32[150] block of include/r2l_isp.h inside forward; backward
+    hands each parameter a view of the single 132-float gradient the kernels produce."""
 
     @staticmethod
-    def forward(ctx, raw, packed, additive, bn_mode, running_mean, running_var, eps, group):
+    def forward(ctx, raw, bl, wb, ccm, gamma, deb, sharp, blur, m1, m2, additive, bn_mode, bn_module, eps,
+                momentum, group):
         raw = _f32c(raw, 'raw')
-        packed = _f32c(packed, 'packed')
+        params = (bl, wb, ccm, gamma, deb, sharp, blur)
+        packed = torch.cat([p.detach().reshape(-1) for p in params] +
+                           [m1.reshape(-1), m2.reshape(-1)]).to(torch.float32)
         if packed.numel() != _lib.R2L_P_COUNT:
             raise ValueError(f'packed parameter block must have {_lib.R2L_P_COUNT} floats')
         B, H, W = raw.shape
@@ -125,36 +131,44 @@ class _IspFused(torch.autograd.Function):
         ws, nws = _workspace(lib, raw, B, H, W)
         dev = raw.device
         bn = None
-        mean = var = None
+        moments = torch.zeros(6, dtype=torch.float64, device=dev)
+        folded = 0
         if bn_mode == BN_TRAIN:
             stats = torch.empty(6, dtype=torch.float64, device=dev)
             lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(packed), ptr(additive), None, None, ptr(stats),
                                       ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream),
                       'r2l_isp_fwd(stats)')
-            mean, var, n_total = batch_moments(stats, B * H * W, group)
-            ctx.n_total = n_total
+            folded = _lib.R2L_F_FOLDED_VALID
+            totals = gather_totals(stats, B * H * W, group)
+            bn = torch.empty(6, dtype=torch.float32, device=dev)
+            rm = rv = None
+            if bn_module is not None and bn_module.track_running_stats and bn_module.running_mean is not None:
+                rm, rv = bn_module.running_mean, bn_module.running_var
+                bn_module.num_batches_tracked.add_(1)
+                if momentum is None:      # cumulative moving average
+                    momentum = 1.0 / float(bn_module.num_batches_tracked)
+            lib.check(lib.r2l_bn_finalize(ptr(totals), ptr(bn), ptr(moments), ptr(rm), ptr(rv), float(eps),
+                                          float(momentum if momentum is not None else 0.0), stream),
+                      'r2l_bn_finalize')
+            ctx.totals = totals
         elif bn_mode == BN_EVAL:
-            mean = running_mean.detach().to(device=dev, dtype=torch.float64)
-            var = running_var.detach().to(device=dev, dtype=torch.float64)
-        if bn_mode != BN_NONE:
-            istd = torch.rsqrt(var + eps)
-            bn = torch.cat([mean, istd]).to(torch.float32)
+            mean = bn_module.running_mean.detach().to(device=dev, dtype=torch.float64)
+            var = bn_module.running_var.detach().to(device=dev, dtype=torch.float64)
+            bn = torch.cat([mean, torch.rsqrt(var + eps)]).to(torch.float32)
         out = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(out), None,
-                                  ptr(ws), nws, B, H, W,
-                                  _lib.R2L_F_FOLDED_VALID if bn_mode == BN_TRAIN else 0, stream), 'r2l_isp_fwd')
+                                  ptr(ws), nws, B, H, W, folded, stream), 'r2l_isp_fwd')
         ctx.bn_mode = bn_mode
         ctx.group = group
         ctx.has_additive = additive is not None
+        ctx.shapes = [tuple(p.shape) for p in params]
         ctx.save_for_backward(raw, packed, additive, bn, out)
         ctx.ws = ws           # holds the folded weights of `packed`: the backward skips re-folding
-        if mean is None:
-            mean = var = torch.zeros(3, dtype=torch.float64, device=dev)
-        ctx.mark_non_differentiable(mean, var)
-        return out, mean, var
+        ctx.mark_non_differentiable(moments)
+        return out, moments
 
     @staticmethod
-    def backward(ctx, gout, _gm, _gv):
+    def backward(ctx, gout, _gm):
         raw, packed, additive, bn, out = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise _lib.R2LError(
@@ -171,26 +185,32 @@ class _IspFused(torch.autograd.Function):
                                             stream), 'r2l_bn_bwd_reduce')
             if _group_size(ctx.group) > 1:
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
-            bn_bwd = (sums / ctx.n_total).to(torch.float32)
-        gpacked = None
-        if ctx.needs_input_grad[1]:
+            bn_bwd = (sums / ctx.totals[6]).to(torch.float32)
+        grads = [None] * 7
+        if any(ctx.needs_input_grad[1:8]):
             gp = torch.empty(_lib.R2L_P_NTRAIN, dtype=torch.float32, device=raw.device)
             lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(bn_bwd),
                                       ptr(gout), ptr(gp), None, ptr(ws), nws, B, H, W,
-                                      _lib.R2L_F_FOLDED_VALID, stream),
-                      'r2l_isp_bwd')
-            gpacked = torch.cat([gp, gp.new_zeros(_lib.R2L_P_COUNT - _lib.R2L_P_NTRAIN)])
+                                      _lib.R2L_F_FOLDED_VALID, stream), 'r2l_isp_bwd')
+            for i, ((_, off, n), shape) in enumerate(zip(PARAM_LAYOUT, ctx.shapes)):
+                if ctx.needs_input_grad[1 + i]:
+                    grads[i] = gp[off:off + n].view(shape)
         gadd = None
-        if ctx.has_additive and ctx.needs_input_grad[2]:
+        if ctx.has_additive and ctx.needs_input_grad[10]:
             gadd = torch.empty_like(additive)
             lib.check(lib.r2l_additive_bwd(ptr(gout), ptr(out), ptr(bn), ptr(bn_bwd), ptr(gadd), B, H,
                                            W, stream), 'r2l_additive_bwd')
-        return None, gpacked, gadd, None, None, None, None, None
+        return (None, *grads, None, None, gadd, None, None, None, None, None)
 
 
-def isp_fused(raw, packed, additive=None, bn_mode=BN_NONE, running_mean=None, running_var=None,
-              eps=1e-5, group=None):
-    return _IspFused.apply(raw, packed, additive, bn_mode, running_mean, running_var, eps, group)
+def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
+    """fused forward of a ParametrizedProcessing-shaped module (parameters by the reference's names)."""
+    bn = module.batch_norm
+    return _IspFused.apply(raw, module.black_level, module.white_balance, module.colour_correction,
+                           module.gamma_correct, module.debayer.weight, module.sharpening_filter.weight,
+                           module.gaussian_blur.weight, module.M_RGB_2_YUV, module.M_YUV_2_RGB,
+                           module.additive_layer, bn_mode, bn, bn.eps if bn is not None else 1e-5,
+                           bn.momentum if bn is not None else None, group)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -227,27 +227,8 @@ class ParametrizedProcessing(nn.Module):
         if bn is None:
             mode = F_.BN_NONE
         elif bn.training or (bn.running_mean is None):
-            mode = F_.BN_TRAIN
+            mode = F_.BN_TRAIN      # batch statistics; running statistics are updated on the device
         else:
             mode = F_.BN_EVAL
-        rm = bn.running_mean if bn is not None else None
-        rv = bn.running_var if bn is not None else None
-        eps = bn.eps if bn is not None else 1e-5
-        out, mean, var = F_.isp_fused(raw, self.packed_parameters(), self.additive_layer, mode, rm, rv,
-                                      eps, self.process_group)
-        if mode == F_.BN_TRAIN and bn.track_running_stats and bn.running_mean is not None:
-            self._update_running_stats(bn, mean, var, raw)
+        out, _moments = F_.isp_fused(raw, self, mode, self.process_group)
         return out
-
-    def _update_running_stats(self, bn, mean, var, raw):
-        # nn.BatchNorm2d bookkeeping: biased variance normalises, unbiased goes to running_var
-        with torch.no_grad():
-            n = raw.shape[0] * raw.shape[1] * raw.shape[2] * F_._group_size(self.process_group)
-            bn.num_batches_tracked.add_(1)
-            if bn.momentum is None:
-                m = 1.0 / bn.num_batches_tracked.to(torch.float64)
-            else:
-                m = bn.momentum
-            unbiased = var * (n / max(n - 1, 1))
-            bn.running_mean.mul_(1 - m).add_((m * mean).to(bn.running_mean.dtype))
-            bn.running_var.mul_(1 - m).add_((m * unbiased).to(bn.running_var.dtype))

@@ -195,3 +195,27 @@ def check_ragged_and_properties(device, B=2, H=70, W=134):
         mu = y.double().mean(dim=(0, 2, 3), keepdim=True)
         var = y.double().var(dim=(0, 2, 3), unbiased=False, keepdim=True)
         assert torch.allclose(yt.double(), (y.double() - mu) * torch.rsqrt(var + 1e-5), rtol=0, atol=2e-5)
+
+
+def check_harness(golden, device):
+    """LitModel-style composition (processor -> classifier -> CE loss -> Adam step, model.py:77-146):
+    logits, loss and the ISP parameters after one optimiser step must match what the REFERENCE processor
+    produced with the same classifier (golden set G4)."""
+    from oracle import harness
+    g = golden['harness']
+    raw = torch.from_numpy(g['harness/raw']).to(device)
+    labels = torch.from_numpy(g['harness/labels']).to(device)
+    proc = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, track_stages=False, batch_norm_output=True)
+    proc = proc.to(device).train()
+    clf = harness.make_classifier().to(device)
+    logits, loss = harness.train_step(proc, clf, raw, labels)
+    assert np.abs(logits.cpu().numpy() - g['harness/logits']).max() < 2e-4
+    assert abs(float(loss) - float(g['harness/loss'])) < 1e-4
+    for k, ref in ((k[len('harness/after_step/'):], g[k]) for k in g.files if k.startswith('harness/after_step/')):
+        got = NAME2ATTR[k](proc).detach().cpu().numpy()
+        # one Adam step moves every parameter by ~lr = 1e-3 in the direction of the gradient's sign
+        assert np.abs(got - ref).max() < 2e-4, (k, np.abs(got - ref).max())
+    proc.eval()
+    with torch.no_grad():
+        le = clf(proc(raw)).cpu().numpy()
+    assert np.abs(le - g['harness/logits_eval_after']).max() < 5e-3

@@ -1,0 +1,70 @@
+"""Batch sharding over ranks on CPU: world_size 2, gloo, kernels served by the
+host emulation.  Each rank processes half of the batch; BatchNorm batch statistics (forward) and their
+backward sums cross ranks, the 132-float ISP gradient is summed; the result must equal the single-process
+result on the whole batch (which is what the single-GPU reference computes)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, emul_path, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from raw2logit_amd import _lib
+    _lib.enable_test_emulation(emul_path)
+    from oracle import isp_oracle as orc
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+    B, H, W = 4, 24, 40
+    raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=3, kind='scene'))
+    cot = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 3, H, W)).astype(np.float32))
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).train()
+    m.process_group = dist.group.WORLD
+    y = m(raw[lo:hi])
+    (y * cot[lo:hi]).sum().backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    dist.all_reduce(flat)                      # data-parallel sum of the ISP gradient
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), y=y.detach().numpy(), g=flat.numpy(),
+             rm=m.batch_norm.running_mean.numpy(), rv=m.batch_norm.running_var.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_equals_single_process(emulation, tmp_path):
+    from oracle import isp_oracle as orc
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+    import conftest
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), conftest.EMUL_LIB, str(tmp_path)), nprocs=world, join=True)
+    B, H, W = 4, 24, 40
+    raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=3, kind='scene'))
+    cot = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 3, H, W)).astype(np.float32))
+    m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).train()
+    y = m(raw)
+    (y * cot).sum().backward()
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()
+    r = [np.load(os.path.join(str(tmp_path), f'rank{k}.npz')) for k in range(world)]
+    y_sharded = np.concatenate([r[0]['y'], r[1]['y']])
+    assert np.abs(y_sharded - y.detach().numpy()).max() < 2e-5
+    assert np.array_equal(r[0]['g'], r[1]['g'])
+    assert np.abs(r[0]['g'] - g).max() <= 2e-4 * (np.abs(g).max() + 1e-6)
+    for k in range(world):
+        np.testing.assert_allclose(r[k]['rm'], m.batch_norm.running_mean.numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(r[k]['rv'], m.batch_norm.running_var.numpy(), rtol=1e-5, atol=1e-7)

@@ -27,3 +27,7 @@ def test_static(case, golden, emulation):
 
 def test_properties(emulation):
     pc.check_ragged_and_properties('cpu')
+
+
+def test_harness_logits_and_adam_step(golden, emulation):
+    pc.check_harness(golden, 'cpu')

@@ -110,3 +110,7 @@ def test_full_size_static_config3_slice(dev):
     outm = F_.static_pipeline(raw[:2], orc.DRONE_CAMERA_PARAMS, 'malvar2004', 'none', 'none')
     refm = orc.static_batch(raw_np[:1], orc.DRONE_CAMERA_PARAMS, 'malvar2004', 'none', 'none')
     assert np.abs(outm[:1].cpu().numpy() - refm).max() <= 1e-5
+
+
+def test_harness_logits_and_adam_step(golden, dev):
+    pc.check_harness(golden, dev)
