@@ -12,6 +12,7 @@
 
 #include "r2l_simple_kernels.h"
 #include "r2l_static_kernels.h"
+#include "r2l_static_stream.h"
 
 static thread_local std::string r2l_err;
 static int r2l_fail(int code, const std::string& msg) {
@@ -129,6 +130,7 @@ R2L_KERNEL(r2l_launch_add_bwd, R2LAddBwdArgs, r2l_add_bwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_fwd, R2LRaw2RgbArgs, r2l_raw2rgb_fwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_bwd, R2LRaw2RgbArgs, r2l_raw2rgb_bwd_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L_STATIC_LDS_FLOATS)
+R2L_KERNEL_OCC(r2l_launch_static_stream, R2LStaticStreamArgs, r2l_static_stream_block, 4, 2)
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
 
@@ -157,6 +159,7 @@ struct R2LWorkspace {
   float* part_small;
   double* sums;
   float* gypp;
+  float* debug;  // 3 x [R2L_MAX_BLOCKS][8] floats: per-phase cycle stamps of diagnostic builds (fwd, bwd1, bwd2)
   size_t total;
 };
 static size_t r2l_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -174,6 +177,8 @@ static R2LWorkspace r2l_carve(void* base, int B, int H, int W) {
   off += r2l_align_up(sizeof(float) * 8 * R2L_MAX_BLOCKS);
   w.sums = (double*)(p + off);
   off += r2l_align_up(sizeof(double) * R2L_NSUMS);
+  w.debug = (float*)(p + off);
+  off += r2l_align_up(sizeof(float) * 3 * 8 * R2L_MAX_BLOCKS);
   w.gypp = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * (size_t)B * H * W);
   w.total = off;
@@ -272,6 +277,7 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
   a.B = B;
   a.H = H;
   a.W = W;
+  a.debug = ws.debug;
   const bool exact = (H % GFwd::TH == 0) && (W % GFwd::TW == 0);
   if (int e = additive ? r2l_launch_fwd_add(a, grid, stream)
                        : (exact ? r2l_launch_fwd(a, grid, stream) : r2l_launch_fwd_ragged(a, grid, stream)))
@@ -339,6 +345,7 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   a1.B = B;
   a1.H = H;
   a1.W = W;
+  a1.debug = ws.debug + 8 * R2L_MAX_BLOCKS;
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
   if (int e = additive ? r2l_launch_bwd1_add(a1, g1, stream)
                        : (exact ? r2l_launch_bwd1(a1, g1, stream) : r2l_launch_bwd1_ragged(a1, g1, stream)))
@@ -353,6 +360,7 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   a2.B = B;
   a2.H = H;
   a2.W = W;
+  a2.debug = ws.debug + 16 * R2L_MAX_BLOCKS;
   if (int e = r2l_launch_bwd2(a2, g2, stream)) return e;
   R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0};
   if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
@@ -433,6 +441,24 @@ int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const doub
   if (a.full) {
     const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC_FULL", 256));
     return r2l_launch_static_full(a, grid, stream);
+  }
+  if ((W & 3) == 0 && !r2l_env_int("R2L_STATIC_TILED", 0)) {
+    // row-streaming kernel: one wavefront per (image, 256-column strip, row band); enough bands for
+    // ~16 wavefronts per CU, at least 16 rows each so the 2-4 halo rows re-read per band stay cheap
+    R2LStaticStreamArgs sa;
+    sa.s = a;
+    sa.nseg = (W + 255) / 256;
+    const long want = 256L * 16 * 2;
+    long nband = (want + (long)B * sa.nseg - 1) / ((long)B * sa.nseg);
+    if (nband > H / 16) nband = H / 16;
+    if (nband < 1) nband = 1;
+    sa.band_h = (int)((H + nband - 1) / nband);
+    sa.nband = (H + sa.band_h - 1) / sa.band_h;
+    const long nitems = (long)B * sa.nseg * sa.nband;
+    if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_static_fwd: batch too large");
+    sa.nitems = (int)nitems;
+    const int wpb = R2L_NT / 64;
+    return r2l_launch_static_stream(sa, (int)((nitems + wpb - 1) / wpb), stream);
   }
   const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC", 1024));
   return r2l_launch_static_short(a, grid, stream);

@@ -13,6 +13,17 @@
 #pragma once
 #include "r2l_common.h"
 
+// diagnostic builds only (-DR2L_EXP_STAMPS): per-phase s_memtime totals of each workgroup's wave 0
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+#define R2L_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime(), t1_;
+#define R2L_STAMP(k) t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - t0_; t0_ = t1_;
+#define R2L_STAMP_FLUSH(dbg, bid) if (threadIdx.x == 0 && (dbg)) for (int k_ = 0; k_ < 8; ++k_) (dbg)[(size_t)(bid) * 8 + k_] = (float)st_[k_];
+#else
+#define R2L_STAMP_DECL
+#define R2L_STAMP(k)
+#define R2L_STAMP_FLUSH(dbg, bid)
+#endif
+
 template <int TW_, int TH_>
 struct R2LGeom {
   static constexpr int TW = TW_, TH = TH_;
@@ -450,6 +461,7 @@ struct R2LFwdArgs {
   float* out;           // (B,3,H,W) or null (stats only)
   float* stat_partial;  // [6][nblk] or null
   int B, H, W;
+  float* debug;  // diagnostic builds
 };
 
 struct R2LFwdRegs {
@@ -586,10 +598,12 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   for (int i = 0; i < 6; ++i) R2L_TREG(regs).acc[i] = 0.f;
   if (have) r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   R2L_PHASE_END
+  R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN
     r2l_store_v<G>(tid, V, F, R2L_TREG(pre));
     R2L_PHASE_END
+    R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
     if (t.border)
@@ -597,13 +611,16 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
     else
       r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
+    R2L_STAMP(1)
     R2L_PHASE_BEGIN
     r2l_compute_yp<G>(tid, Y, YP, F);
     R2L_PHASE_END
+    R2L_STAMP(2)
     if (t.border) {
       R2L_PHASE_BEGIN
       r2l_fill_yp_mirror<G>(tid, YP, t.oy, t.ox, a.H, a.W);
       R2L_PHASE_END
+    R2L_STAMP(3)
     }
     R2L_PHASE_BEGIN
     if (haven) r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));  // next tile, in flight
@@ -612,9 +629,11 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
     else
       r2l_fwd_pixels<G, false, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
+    R2L_STAMP(4)
     t = tn;
     have = haven;
   }
+  R2L_STAMP_FLUSH(a.debug, bid)
   if (a.stat_partial) {
     R2L_BLOCK_REDUCE(6, regs, lds, a.stat_partial, bid, nblk)
   }
@@ -633,6 +652,7 @@ struct R2LBwd1Args {
   float* gypp;          // (B,H,W): d loss / d Y'' (blurred luma)
   float* partial;       // [R2L_B1_NACC][nblk]
   int B, H, W;
+  float* debug;
 };
 
 // per-thread accumulators of B1: a thread only sees pixels of ONE row parity, so it keeps the two column
@@ -824,10 +844,12 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   }
   if (have) r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   R2L_PHASE_END
+  R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN
     r2l_store_v<G>(tid, V, F, R2L_TREG(pre));
     R2L_PHASE_END
+    R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
     if (t.border)
@@ -835,13 +857,16 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     else
       r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
+    R2L_STAMP(1)
     R2L_PHASE_BEGIN
     r2l_compute_yp<G>(tid, Y, YP, F);
     R2L_PHASE_END
+    R2L_STAMP(2)
     if (t.border) {
       R2L_PHASE_BEGIN
       r2l_fill_yp_mirror<G>(tid, YP, t.oy, t.ox, a.H, a.W);
       R2L_PHASE_END
+    R2L_STAMP(3)
     }
     R2L_PHASE_BEGIN
     if (haven) r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
@@ -850,9 +875,11 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     else
       r2l_bwd1_pixels<G, false, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
+    R2L_STAMP(4)
     t = tn;
     have = haven;
   }
+  R2L_STAMP_FLUSH(a.debug, bid)
   R2L_BLOCK_REDUCE_F(R2L_B1_NACC, R2L_ACC_B1, regs, lds, a.partial, bid, nblk)
 }
 
@@ -865,6 +892,7 @@ struct R2LBwd2Args {
   const float* gypp;  // (B,H,W) from B1
   float* partial;     // [R2L_B2_NACC][nblk]
   int B, H, W;
+  float* debug;
 };
 
 enum { R2L_L2_GSHARP = 0, R2L_L2_GAY = 9, R2L_L2_SY = 27, R2L_L2_NACC = 29 };
@@ -1053,15 +1081,18 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     r2l_fetch_tile<G, 1>(tid, a.gypp, t, a.H, a.W, R2L_TREG(pre_g));
   }
   R2L_PHASE_END
+  R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN
     r2l_store_v<G>(tid, V, F, R2L_TREG(pre_v));
     r2l_store_plane_s2<G>(tid, G2, R2L_TREG(pre_g));
     R2L_PHASE_END
+    R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
     r2l_adjoint_blur<G>(tid, G2, HP, F);
     R2L_PHASE_END
+    R2L_STAMP(1)
     R2L_PHASE_BEGIN
     if (t.border) {
       r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
@@ -1070,6 +1101,7 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
       r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     }
     R2L_PHASE_END
+    R2L_STAMP(2)
     R2L_PHASE_BEGIN
     if (haven) {
       r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre_v));
@@ -1080,8 +1112,10 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     else
       r2l_bwd2_pixels<G, false>(tid, V, Y, HP, a, t, R2L_TREG(regs));
     R2L_PHASE_END
+    R2L_STAMP(3)
     t = tn;
     have = haven;
   }
+  R2L_STAMP_FLUSH(a.debug, bid)
   R2L_BLOCK_REDUCE_F(R2L_B2_NACC, R2L_ACC_B2, regs, lds, a.partial, bid, nblk)
 }

@@ -1,14 +1,37 @@
-import os, torch
-os.environ['R2L_LIB_PATH'] = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_build', 'lib_stamps.so')
-import sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Diagnostic: per-phase cycle totals (s_memtime) of the tile kernels, from a -DR2L_EXP_STAMPS build."""
+import os, sys, ctypes, torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ['R2L_LIB_PATH'] = os.path.join(HERE, '_build', 'lib_stamps.so')
+sys.path.insert(0, os.path.dirname(HERE))
 from oracle import isp_oracle as orc
-from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
-raw = torch.from_numpy(orc.synth_raw(64, 512, 512, seed=0)).cuda()
-m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=False).cuda()
-with torch.no_grad():
-    for _ in range(3): y = m(raw)
-    torch.cuda.synchronize()
-st = y.flatten()[:512 * 8].view(512, 8).double().cpu()
-names = ['load', 'Y', 'YP', 'fill', 'pixels']
-print('per-workgroup s_memtime ticks per phase, mean over 512 WGs (8 tiles each); 100 MHz ticks? ->', st[:, :5].sum(1).mean().item())
-for i, n in enumerate(names): print(f'  {n:8s} mean {st[:, i].mean().item():10.0f}  min {st[:, i].min().item():10.0f}  max {st[:, i].max().item():10.0f}')
+from raw2logit_amd import _lib
+from raw2logit_amd._lib import ptr
+lib = _lib.device_library()
+B, H, W = 64, 512, 512
+dev = 'cuda'
+raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=0)).to(dev)
+P = torch.from_numpy(orc.IspParams(orc.DRONE_CAMERA_PARAMS).pack()).to(dev)
+n = lib.r2l_isp_workspace_bytes(B, H, W)
+ws = torch.zeros(n, dtype=torch.uint8, device=dev)
+out = torch.empty((B, 3, H, W), device=dev)
+gout = torch.randn((B, 3, H, W), device=dev)
+gp = torch.empty(132, device=dev)
+bn = torch.tensor([0.4, 0.4, 0.4, 5., 5., 5.], device=dev)
+bnb = torch.tensor([0.01, 0.01, 0.01, 0.02, 0.02, 0.02], device=dev)
+s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+for _ in range(3):
+    lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(P), None, ptr(bn), ptr(out), None, ptr(ws), n, B, H, W, 0, s), 'fwd')
+    lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(P), None, ptr(bn), ptr(bnb), ptr(gout), ptr(gp), None, ptr(ws), n, B, H, W, 0, s), 'bwd')
+torch.cuda.synchronize()
+off = 768 + 106 * 1024 * 4 + 49 * 1024 * 4 + 8 * 1024 * 4 + 1280
+dbg = ws[off:off + 3 * 8 * 1024 * 4].view(torch.float32).view(3, 1024, 8).double().cpu()
+names = {0: ['store', 'Y', 'YP', 'fill', 'pixels'], 1: ['store', 'Y', 'YP', 'fill', 'pixels'],
+         2: ['store', 'adjblur', 'Y+fold', 'pixels']}
+for k, kn in enumerate(['fwd', 'bwd1', 'bwd2']):
+    d = dbg[k]
+    nb = int((d.sum(1) > 0).sum())
+    d = d[:nb]
+    tot = d.sum(1).mean().item()
+    print(f'{kn}: {nb} workgroups, mean total {tot:,.0f} cycles = {tot/2.4e3:.1f} us @2.4GHz')
+    for i, nm in enumerate(names[k]):
+        print(f'   {nm:8s} mean {d[:, i].mean().item():10,.0f}  ({100*d[:, i].mean().item()/tot:4.1f} %)  max {d[:, i].max().item():10,.0f}')
