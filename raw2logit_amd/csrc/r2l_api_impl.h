@@ -30,6 +30,7 @@ static int r2l_fail(int code, const std::string& msg) {
     return 0;                                                                \
   }
 #define R2L_KERNEL_OCC(name, ArgsT, blockfn, LDS_FLOATS, W) R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS)
+#define R2L_KERNEL_NT(name, ArgsT, blockfn, NT, W) R2L_KERNEL(name, ArgsT, blockfn, 4)
 #define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS)                         \
   static int name(const ArgsT& a, int grid, void* stream) {                  \
     (void)stream;                                                            \
@@ -63,6 +64,21 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
   r2l_timed.push_back(t);
 }
 #define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS) R2L_KERNEL_OCC(name, ArgsT, blockfn, LDS_FLOATS, 1)
+// LDS-free kernels with their own workgroup size (independent wavefronts)
+#define R2L_KERNEL_NT(name, ArgsT, blockfn, NT, WAVES_PER_SIMD)                                 \
+  __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void name##_kernel(const ArgsT a) {         \
+    blockfn(a, (int)blockIdx.x, (int)gridDim.x, nullptr);                                      \
+  }                                                                                            \
+  static int name(const ArgsT& a, int grid, void* stream) {                                    \
+    R2LTimedLaunch t_;                                                                         \
+    const bool timed_ = r2l_timing_on;                                                         \
+    if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                      \
+    hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);       \
+    if (timed_) r2l_time_end((hipStream_t)stream, t_);                                         \
+    const hipError_t e = hipGetLastError();                                                    \
+    if (e != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(e)); \
+    return 0;                                                                                  \
+  }
 #define R2L_KERNEL_V(name, ArgsT, LDS_FLOATS, WAVES_PER_SIMD, ...)                             \
   __global__ __launch_bounds__(R2L_NT, WAVES_PER_SIMD) void name##_kernel(const ArgsT a) {     \
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];                             \
@@ -130,7 +146,8 @@ R2L_KERNEL(r2l_launch_add_bwd, R2LAddBwdArgs, r2l_add_bwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_fwd, R2LRaw2RgbArgs, r2l_raw2rgb_fwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_bwd, R2LRaw2RgbArgs, r2l_raw2rgb_bwd_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L_STATIC_LDS_FLOATS)
-R2L_KERNEL_OCC(r2l_launch_static_stream, R2LStaticStreamArgs, r2l_static_stream_block, 4, 2)
+R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_static_stream_block<0>, R2L_STREAM_NT, 4)
+R2L_KERNEL_NT(r2l_launch_static_stream_malvar, R2LStaticStreamArgs, r2l_static_stream_block<1>, R2L_STREAM_NT, 3)
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
 
@@ -450,6 +467,7 @@ int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const doub
     sa.nseg = (W + 255) / 256;
     const long want = 256L * 16 * 2;
     long nband = (want + (long)B * sa.nseg - 1) / ((long)B * sa.nseg);
+    nband = r2l_env_int("R2L_STREAM_BANDS", (int)nband);
     if (nband > H / 16) nband = H / 16;
     if (nband < 1) nband = 1;
     sa.band_h = (int)((H + nband - 1) / nband);
@@ -457,8 +475,10 @@ int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const doub
     const long nitems = (long)B * sa.nseg * sa.nband;
     if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_static_fwd: batch too large");
     sa.nitems = (int)nitems;
-    const int wpb = R2L_NT / 64;
-    return r2l_launch_static_stream(sa, (int)((nitems + wpb - 1) / wpb), stream);
+    const int wpb = R2L_STREAM_NT / 64;
+    const int grid = (int)((nitems + wpb - 1) / wpb);
+    return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_stream_malvar(sa, grid, stream)
+                                             : r2l_launch_static_stream_bilinear(sa, grid, stream);
   }
   const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC", 1024));
   return r2l_launch_static_short(a, grid, stream);

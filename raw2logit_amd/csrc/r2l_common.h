@@ -29,6 +29,7 @@ R2L_HD float r2l_log2(float x) { return log2f(x); }
 R2L_HD float r2l_exp2(float x) { return exp2f(x); }
 R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
 #define R2L_PHASE_BEGIN for (int tid = 0; tid < R2L_NT; ++tid) {
+#define R2L_PHASE_BEGIN_N(NT) for (int tid = 0; tid < (NT); ++tid) {
 #define R2L_PHASE_END }
 #define R2L_TREG_DECL(type, name) type name##_all[R2L_NT]
 #define R2L_TREG(name) name##_all[tid]
@@ -50,6 +51,7 @@ R2L_HD float r2l_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #define R2L_PHASE_BEGIN \
   {                     \
     const int tid = threadIdx.x;
+#define R2L_PHASE_BEGIN_N(NT) R2L_PHASE_BEGIN
 // A phase boundary only orders LDS traffic between the waves of the workgroup.  __syncthreads() would
 // also wait for every outstanding global store (s_waitcnt vmcnt(0)), i.e. expose the full HBM write
 // latency of the previous tile's output at every barrier; the raw barrier below waits for LDS only.

@@ -18,13 +18,17 @@ struct R2LStaticStreamArgs {
   int nseg, nband, band_h, nitems;
 };
 
-// one raw row -> 8 black-level-corrected float64 values: columns x0-2 .. x0+5 of source row `ys`
-// (symmetric extension at the left / right image edge; the black level follows the SOURCE site)
-R2L_HD void r2l_stream_load_row(const R2LStaticArgs& a, const float* img, int ys, int x0, bool le, bool re,
-                                double dst[8]) {
+// raw values of columns x0-2 .. x0+5 of source row `ys` (symmetric extension at the image edges)
+struct R2LRowStage {
+  float v[8];
+  int ys;
+};
+R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, const float* img, int ys, int x0, bool le, bool re,
+                                 R2LRowStage& st) {
   const float* r = img + (size_t)ys * a.W + x0;
   const r2l_f4 c = *(const r2l_f4*)r;
-  float v[8];
+  float* v = st.v;
+  st.ys = ys;
   v[2] = c.x;
   v[3] = c.y;
   v[4] = c.z;
@@ -45,6 +49,12 @@ R2L_HD void r2l_stream_load_row(const R2LStaticArgs& a, const float* img, int ys
     v[6] = q.x;
     v[7] = q.y;
   }
+}
+// staged row -> 8 black-level-corrected float64 values (the black level follows the SOURCE site)
+R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStage& st, bool le, bool re,
+                                   double dst[8]) {
+  const float* v = st.v;
+  const int ys = st.ys;
   const double be = (ys & 1) ? a.bl[2] : a.bl[0], bo = (ys & 1) ? a.bl[3] : a.bl[1];
   // source column parities: x0-2 even, x0-1 odd, ..., except the mirrored ones (1, 0 | W-1, W-2)
   dst[0] = (double)v[0] - (le ? bo : be);
@@ -76,7 +86,14 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
     st.y = x[k][1];
     st.z = x[k][2];
     st.w = x[k][3];
+#if defined(R2L_EXP_NT_STORE) && !defined(R2L_EMUL)
+    {
+      r2l_v4 nv = {st.x, st.y, st.z, st.w};
+      __builtin_nontemporal_store(nv, (r2l_v4*)(outb + (size_t)k * plane + off));
+    }
+#else
     *(r2l_f4*)(outb + (size_t)k * plane + off) = st;
+#endif
   }
 }
 
@@ -136,22 +153,29 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   double win[NR][8];
   int par[NR];  // source row parity of each window slot
   // warm-up: slots 0..NR-2 hold rows y0-HALO .. y0+HALO-1
+  R2LRowStage st;
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < NR - 1; ++i) {
     const int ys = r2l_symmetric(y0 - HALO + i, a.H);
-    r2l_stream_load_row(a, img, ys, x0, le, re, win[i]);
+    r2l_stream_fetch_row(a, img, ys, x0, le, re, st);
+    r2l_stream_convert_row(a, st, le, re, win[i]);
     par[i] = ys & 1;
   }
+  // software pipeline, two rows deep: the rows needed by the next TWO output rows are in flight while
+  // this one is computed (st = row y+HALO, st2 = row y+HALO+1)
+  R2LRowStage st2;
+  r2l_stream_fetch_row(a, img, r2l_symmetric(y0 + HALO, a.H), x0, le, re, st);
+  r2l_stream_fetch_row(a, img, r2l_symmetric(y0 + HALO + 1, a.H), x0, le, re, st2);
   for (int yb = y0; yb < y1; yb += NR) {
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < NR; ++k) {  // unrolled by the window depth: slot indices are compile-time
       const int y = yb + k;
       if (y < y1) {
-        {  // newest row y + HALO goes to slot (k + NR - 1) % NR
-          const int ys = r2l_symmetric(y + HALO, a.H);
-          r2l_stream_load_row(a, img, ys, x0, le, re, win[(k + NR - 1) % NR]);
-          par[(k + NR - 1) % NR] = ys & 1;
-        }
+        // newest row y + HALO (fetched one iteration ago) goes to slot (k + NR - 1) % NR
+        r2l_stream_convert_row(a, st, le, re, win[(k + NR - 1) % NR]);
+        par[(k + NR - 1) % NR] = st.ys & 1;
+        st = st2;
+        if (y + 2 < y1) r2l_stream_fetch_row(a, img, r2l_symmetric(y + 2 + HALO, a.H), x0, le, re, st2);
         double d[4][3];
         if (DEB == 0) {
           // interior rows: the tap rows have the checkerboard parities (compile-time after the uniform
@@ -180,16 +204,13 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   }
 }
 
+#define R2L_STREAM_NT 256  // 4 independent wavefronts per workgroup
+template <int DEB>
 R2L_BLOCKFN void r2l_static_stream_block(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {
   (void)lds;
   (void)nblk;
-  R2L_PHASE_BEGIN
-  const int item = bid * (R2L_NT / 64) + (tid >> 6);  // one work item per wavefront
-  if (item < sa.nitems) {
-    if (sa.s.debayer == R2L_DEBAYER_MALVAR2004)
-      r2l_static_stream_item<1>(sa, item, tid & 63);
-    else
-      r2l_static_stream_item<0>(sa, item, tid & 63);
-  }
+  R2L_PHASE_BEGIN_N(R2L_STREAM_NT)
+  const int item = bid * (R2L_STREAM_NT / 64) + (tid >> 6);  // one work item per wavefront
+  if (item < sa.nitems) r2l_static_stream_item<DEB>(sa, item, tid & 63);
   R2L_PHASE_END
 }
