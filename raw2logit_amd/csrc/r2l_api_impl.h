@@ -123,7 +123,7 @@ static_assert(R2L_LDS3(GBwd2) >= R2L_RED_FLOATS, "reduction scratch must fit");
 R2L_KERNEL(r2l_launch_fold, R2LFoldArgs, r2l_fold_block, 4)
 R2L_KERNEL(r2l_launch_unfold, R2LUnfoldArgs, r2l_unfold_block, 4)
 R2L_KERNEL(r2l_launch_bn_finalize, R2LBnFinalizeArgs, r2l_bn_finalize_block, 4)
-R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 * R2L_NT)
+R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 * R2L_NT + 64)
 #ifndef R2L_OCC_FWD
 #define R2L_OCC_FWD 4
 #endif

@@ -62,7 +62,7 @@ struct R2LTile {
 // so ids with equal (bid % 8) share an L2.  Each such group walks its own contiguous 1/8 of the tile
 // list, which keeps halo rows/columns shared by neighbouring tiles inside one L2.
 struct R2LTileWalk {
-  int ntx, nty, ntiles, nper, group, j, jstep;
+  int ntx, nty, ntiles, nper, group, w, k, jstep;
 };
 R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, int nblk) {
   R2LTileWalk w;
@@ -72,15 +72,20 @@ R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, i
   const int ngroups = (nblk % 8 == 0) ? 8 : 1;
   w.nper = (w.ntiles + ngroups - 1) / ngroups;
   w.group = bid % ngroups;
-  w.j = bid / ngroups;
+  w.w = bid / ngroups;
+  w.k = 0;
   w.jstep = nblk / ngroups;
   return w;
 }
+// k-th tile of a workgroup: block k of `jstep` consecutive tiles, rotated by k so that a workgroup does
+// not keep landing on the same position of every image (corner / edge tiles cost more than interior ones)
 R2L_HD bool r2l_walk_next(R2LTileWalk& w, int H, int W, int TW, int TH, R2LTile& t) {
-  while (w.j < w.nper) {
-    const int tile = w.group * w.nper + w.j;
-    w.j += w.jstep;
-    if (tile >= w.ntiles) return false;
+  while (w.k * w.jstep < w.nper) {
+    const int j = w.k * w.jstep + (w.w + w.k) % w.jstep;
+    w.k += 1;
+    if (j >= w.nper) continue;
+    const int tile = w.group * w.nper + j;
+    if (tile >= w.ntiles) continue;
     const int tx = tile % w.ntx, r = tile / w.ntx;
     t.b = r / w.nty;
     t.oy = (r % w.nty) * TH;
@@ -560,8 +565,10 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
 }
 
 // per-thread accumulators -> one partial per slot per workgroup, in a fixed order (bitwise
-// reproducible): slots go through LDS 32 at a time, thread s < 32 adds the R2L_NT values of slot s.
-#define R2L_RED_FLOATS (32 * (R2L_NT + 1))
+// reproducible).  Slots go through LDS 32 at a time: every thread parks its 32 values, then 16 threads
+// per slot add 32 of the R2L_NT values each (lane `part` takes threads part, part+16, ...: at most a 2-way
+// bank conflict), and one thread per slot adds the 16 partial sums.
+#define R2L_RED_FLOATS (32 * (R2L_NT + 1) + 32 * 16)
 #define R2L_ACC_DIRECT(regs, i) R2L_TREG(regs).acc[i]
 #define R2L_BLOCK_REDUCE(NACC, regs, lds, partial, bid, nblk) \
   R2L_BLOCK_REDUCE_F(NACC, R2L_ACC_DIRECT, regs, lds, partial, bid, nblk)
@@ -574,9 +581,22 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
       if (base_ + i_ < (NACC)) (lds)[i_ * (R2L_NT + 1) + tid] = VAL(regs, base_ + i_);     \
     R2L_PHASE_END                                                                           \
     R2L_PHASE_BEGIN                                                                         \
+    {                                                                                       \
+      const int slot_ = tid >> 4, part_ = tid & 15;                                         \
+      float s_ = 0.f;                                                                       \
+      if (base_ + slot_ < (NACC)) {                                                         \
+        R2L_PRAGMA_UNROLL                                                                   \
+        for (int j_ = 0; j_ < R2L_NT / 16; ++j_)                                            \
+          s_ += (lds)[slot_ * (R2L_NT + 1) + part_ + 16 * j_];                              \
+      }                                                                                     \
+      (lds)[32 * (R2L_NT + 1) + tid] = s_;                                                  \
+    }                                                                                       \
+    R2L_PHASE_END                                                                           \
+    R2L_PHASE_BEGIN                                                                         \
     if (tid < 32 && base_ + tid < (NACC)) {                                                 \
       float s_ = 0.f;                                                                       \
-      for (int j_ = 0; j_ < R2L_NT; ++j_) s_ += (lds)[tid * (R2L_NT + 1) + j_];                      \
+      R2L_PRAGMA_UNROLL                                                                     \
+      for (int j_ = 0; j_ < 16; ++j_) s_ += (lds)[32 * (R2L_NT + 1) + tid * 16 + j_];       \
       (partial)[(size_t)(base_ + tid) * (nblk) + (bid)] = s_;                               \
     }                                                                                       \
     R2L_PHASE_END                                                                           \
@@ -961,27 +981,44 @@ R2L_HD void r2l_adjoint_blur(int tid, const float* G2, float* HP, R2LFoldedRef F
 // (which nobody writes in this phase).  Out-of-image entries keep their values; the pixel phase masks
 // them (the zero padding of the sharpen conv has no adjoint contribution there).
 template <class G>
+R2L_HD void r2l_fold_one(float* HP, int fy, int fx, int oy, int ox, int H, int W) {
+  const int gy = oy - 4 + fy, gx = ox - 4 + fx;
+  if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) return;
+  int ey[3], ex[3];
+  ey[0] = fy;
+  ey[1] = (gy >= 1 && gy <= 2) ? fy - 2 * gy : -1;                    // image row -gy
+  ey[2] = (gy >= H - 3 && gy <= H - 2) ? fy + 2 * (H - 1 - gy) : -1;  // image row 2(H-1)-gy
+  ex[0] = fx;
+  ex[1] = (gx >= 1 && gx <= 2) ? fx - 2 * gx : -1;
+  ex[2] = (gx >= W - 3 && gx <= W - 2) ? fx + 2 * (W - 1 - gx) : -1;
+  float s = 0.f;
+  R2L_PRAGMA_UNROLL
+  for (int p = 0; p < 3; ++p)
+    R2L_PRAGMA_UNROLL
+  for (int q = 0; q < 3; ++q)
+    if ((p | q) != 0 && ey[p] >= 2 && ey[p] < G::FH - 2 && ex[q] >= 2 && ex[q] < G::FW - 2)
+      s += HP[ey[p] * G::FS + ex[q]];
+  HP[fy * G::FS + fx] += s;
+}
+// Only image rows / columns {1, 2, n-3, n-2} have mirror images: visit those columns over all rows, then
+// those rows over the remaining columns (each position once).
+template <class G>
 R2L_HD void r2l_fold_mirror(int tid, float* HP, int oy, int ox, int H, int W) {
   constexpr int NW = G::FW - 4, NH = G::FH - 4;
-  for (int i = tid; i < NW * NH; i += R2L_NT) {
-    const int fy = 2 + i / NW, fx = 2 + i % NW;
-    const int gy = oy - 4 + fy, gx = ox - 4 + fx;
-    if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) continue;
-    int ey[3], ex[3];
-    ey[0] = fy;
-    ey[1] = (gy >= 1 && gy <= 2) ? fy - 2 * gy : -1;                    // image row -gy
-    ey[2] = (gy >= H - 3 && gy <= H - 2) ? fy + 2 * (H - 1 - gy) : -1;  // image row 2(H-1)-gy
-    ex[0] = fx;
-    ex[1] = (gx >= 1 && gx <= 2) ? fx - 2 * gx : -1;
-    ex[2] = (gx >= W - 3 && gx <= W - 2) ? fx + 2 * (W - 1 - gx) : -1;
-    float s = 0.f;
-    R2L_PRAGMA_UNROLL
-    for (int p = 0; p < 3; ++p)
-      R2L_PRAGMA_UNROLL
-    for (int q = 0; q < 3; ++q)
-      if ((p | q) != 0 && ey[p] >= 2 && ey[p] < G::FH - 2 && ex[q] >= 2 && ex[q] < G::FW - 2)
-        s += HP[ey[p] * G::FS + ex[q]];
-    HP[fy * G::FS + fx] += s;
+  const int gc[4] = {1, 2, W - 3, W - 2}, gr[4] = {1, 2, H - 3, H - 2};
+  for (int i = tid; i < 4 * NH; i += R2L_NT) {
+    const int k = i / NH, fy = 2 + (i - k * NH);
+    const int fx = gc[k] - ox + 4;
+    const bool dup = (k >= 2) && (gc[k] == gc[k - 2]);  // W == 4: columns 1, 2 listed twice
+    if (!dup && fx >= 2 && fx < G::FW - 2) r2l_fold_one<G>(HP, fy, fx, oy, ox, H, W);
+  }
+  for (int i = tid; i < 4 * NW; i += R2L_NT) {
+    const int k = i / NW, fx = 2 + (i - k * NW);
+    const int fy = gr[k] - oy + 4;
+    const int gx = ox - 4 + fx;
+    const bool dup = (k >= 2) && (gr[k] == gr[k - 2]);
+    const bool colcand = gx == 1 || gx == 2 || gx == W - 3 || gx == W - 2;  // done by the first loop
+    if (!dup && !colcand && fy >= 2 && fy < G::FH - 2) r2l_fold_one<G>(HP, fy, fx, oy, ox, H, W);
   }
 }
 

@@ -89,9 +89,16 @@ R2L_BLOCKFN void r2l_reduce_rows_block(const R2LReduceRowsArgs& a, int bid, int 
   dl[tid] = s;
   R2L_PHASE_END
   R2L_PHASE_BEGIN
+  if (tid < 32) {  // fixed-order tree: 32 lanes add R2L_NT/32 neighbours each, lane 0 adds the 32 results
+    double t = 0.0;
+    for (int j = 0; j < R2L_NT / 32; ++j) t += dl[tid * (R2L_NT / 32) + j];
+    dl[R2L_NT + tid] = t;
+  }
+  R2L_PHASE_END
+  R2L_PHASE_BEGIN
   if (tid == 0) {
     double t = 0.0;
-    for (int j = 0; j < R2L_NT; ++j) t += dl[j];
+    for (int j = 0; j < 32; ++j) t += dl[R2L_NT + j];
     a.sums[bid] = t * a.scale;
   }
   R2L_PHASE_END
