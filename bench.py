@@ -37,6 +37,18 @@ ALGO_BYTES_PER_PX = {
 }
 
 
+def pmc_traffic(kernel, B, S):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
+    their own runs, gfx950 correction applied; profiles/r01_pmc_traffic.json), valid for the 64x512x512
+    workload only; None otherwise."""
+    path = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+    if (B, S) != (64, 512) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return t.get(kernel, {}).get('total_bytes')
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -66,7 +78,7 @@ def cpu_baseline(size):
         orc.parametrized_backward(P, c, cot)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or n >= 20:
+        if dt > 12.0:
             break
     return {'value': round(n * B * size * size / dt / 1e6, 3), 'unit': 'Mpix/s', 'cores': 1,
             'kind': 'port',
@@ -163,7 +175,7 @@ def main():
             achieved = B * S * S * bpp / (avg_us * 1e-6) / 1e9
             roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                        'traffic': None, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
+                        'traffic': pmc_traffic(dom, B, S), 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
 
     if rank == 0:
         out = {
