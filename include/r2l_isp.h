@@ -141,6 +141,32 @@ int r2l_additive_bwd(const float *grad_out, const float *out, const float *bn_me
 int r2l_static_fwd(const float *raw, float *out, int B, int H, int W, const double *camera_host,
                    int debayer, int sharpening, int denoising, double gamma, void *stream);
 
+/* ---- staged execution (track_stages=True, pipeline_torch.py:197-221): one entry point per materialised
+ * stage, each with its VJP, so that autograd can hold every stage tensor (retain_grad) and d/d raw exists.
+ * Tensors are (B,3,H,W) float32.  Weight gradients are float32 arrays; workspace from
+ * r2l_stage_workspace_bytes().
+ *   conv33   Debayer, 3->3 3x3 cross-correlation, mirror padding                          :187, :228-237
+ *   mix3     einsum('bchw,kc->bkhw', x, M) (white balance = diagonal M)                    :190-194, :198-203
+ *   pconv    channel 0 <- KxK conv of channel 0 (K=3 zero pad :195 | K=5 mirror pad :202), 1-2 copied;
+ *            gk25 is 5x5-strided (entry [i*5+j])
+ *   point    op 0/1 clip fwd/bwd (:206)  2/3 gamma fwd/bwd (:209; sums6[0] = sum g*out*log2(x))
+ *            4 add (:213)  5 BatchNorm apply  6 BatchNorm backward  7 BatchNorm statistics (sums6)   */
+size_t r2l_stage_workspace_bytes(void);
+int r2l_stage_conv33_fwd(const float *x, const float *w, float *y, int B, int H, int W, void *stream);
+int r2l_stage_conv33_bwd(const float *x, const float *w, const float *g, float *gx, float *gw,
+                         void *workspace, size_t workspace_bytes, int B, int H, int W, void *stream);
+int r2l_stage_mix3_fwd(const float *x, const float *m, float *y, int B, int H, int W, void *stream);
+int r2l_stage_mix3_bwd(const float *x, const float *m, const float *g, float *gx, float *gm, void *workspace,
+                       size_t workspace_bytes, int B, int H, int W, void *stream);
+int r2l_stage_pconv_fwd(const float *x, const float *k, float *y, int K, int mirror, int B, int H, int W,
+                        void *stream);
+int r2l_stage_pconv_bwd(const float *x, const float *k, const float *g, float *gx, float *gk25, int K,
+                        int mirror, void *workspace, size_t workspace_bytes, int B, int H, int W,
+                        void *stream);
+int r2l_stage_point(int op, const float *x, const float *g, const float *w, const float *aux,
+                    const float *aux2, float *y, float *sums6, void *workspace, size_t workspace_bytes,
+                    int B, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

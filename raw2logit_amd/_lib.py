@@ -52,6 +52,18 @@ _SIGNATURES = {
                                    ctypes.c_void_p]),
     'r2l_additive_bwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_stage_workspace_bytes': (ctypes.c_size_t, []),
+    'r2l_stage_conv33_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    'r2l_stage_conv33_bwd': (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_void_p, ctypes.c_size_t] +
+                             [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    'r2l_stage_mix3_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    'r2l_stage_mix3_bwd': (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_void_p, ctypes.c_size_t] +
+                           [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    'r2l_stage_pconv_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    'r2l_stage_pconv_bwd': (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 2 +
+                            [ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    'r2l_stage_point': (ctypes.c_int, [ctypes.c_int] + [_c_float_p] * 7 + [ctypes.c_void_p, ctypes.c_size_t] +
+                        [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'r2l_static_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),

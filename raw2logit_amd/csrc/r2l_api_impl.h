@@ -13,6 +13,7 @@
 #include "r2l_simple_kernels.h"
 #include "r2l_static_kernels.h"
 #include "r2l_static_stream.h"
+#include "r2l_staged_kernels.h"
 
 static thread_local std::string r2l_err;
 static int r2l_fail(int code, const std::string& msg) {
@@ -150,6 +151,14 @@ R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_static
 R2L_KERNEL_NT(r2l_launch_static_stream_malvar, R2LStaticStreamArgs, r2l_static_stream_block<1>, R2L_STREAM_NT, 3)
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
+
+R2L_KERNEL(r2l_launch_conv33_fwd, R2LStageArgs, r2l_conv33_fwd_block, 4)
+R2L_KERNEL(r2l_launch_conv33_bwd, R2LStageArgs, r2l_conv33_bwd_block, R2L_RED_FLOATS)
+R2L_KERNEL(r2l_launch_mix3_fwd, R2LStageArgs, r2l_mix3_fwd_block, 4)
+R2L_KERNEL(r2l_launch_mix3_bwd, R2LStageArgs, r2l_mix3_bwd_block, R2L_RED_FLOATS)
+R2L_KERNEL(r2l_launch_pconv_fwd, R2LStageArgs, r2l_pconv_fwd_block, 4)
+R2L_KERNEL(r2l_launch_pconv_bwd, R2LStageArgs, r2l_pconv_bwd_block, R2L_RED_FLOATS)
+R2L_KERNEL(r2l_launch_point, R2LPointArgs, r2l_point_block, R2L_RED_FLOATS)
 
 // ---- grid sizing ------------------------------------------------------------------------------
 #define R2L_MAX_BLOCKS 1024
@@ -300,7 +309,7 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
                        : (exact ? r2l_launch_fwd(a, grid, stream) : r2l_launch_fwd_ragged(a, grid, stream)))
     return e;
   if (stats) {
-    R2LReduceRowsArgs r{ws.part_small, stats, grid, 1.0};
+    R2LReduceRowsArgs r{ws.part_small, stats, grid, 1.0, nullptr};
     if (int e = r2l_launch_reduce_rows(r, 6, stream)) return e;
   }
   return 0;
@@ -326,7 +335,7 @@ int r2l_bn_bwd_reduce(const float* grad_out, const float* out, double* sums, voi
   int grid = nitems < (size_t)R2L_MAX_BLOCKS ? (int)nitems : R2L_MAX_BLOCKS;
   R2LBnReduceArgs a{grad_out, out, ws.part_small, B, H, W};
   if (int e = r2l_launch_bn_reduce(a, grid, stream)) return e;
-  R2LReduceRowsArgs r{ws.part_small, sums, grid, 1.0};
+  R2LReduceRowsArgs r{ws.part_small, sums, grid, 1.0, nullptr};
   return r2l_launch_reduce_rows(r, 6, stream);
 }
 
@@ -379,9 +388,9 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   a2.W = W;
   a2.debug = ws.debug + 16 * R2L_MAX_BLOCKS;
   if (int e = r2l_launch_bwd2(a2, g2, stream)) return e;
-  R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0};
+  R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0, nullptr};
   if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
-  R2LReduceRowsArgs r2{ws.part_b2, ws.sums + R2L_B1_NACC, g2, 1.0};
+  R2LReduceRowsArgs r2{ws.part_b2, ws.sums + R2L_B1_NACC, g2, 1.0, nullptr};
   if (int e = r2l_launch_reduce_rows(r2, R2L_B2_NACC, stream)) return e;
   R2LUnfoldArgs ua{params, ws.sums, grad_params, 1.0f};
   return r2l_launch_unfold(ua, 1, stream);
@@ -433,7 +442,7 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
   if (grid > R2L_MAX_BLOCKS) grid = R2L_MAX_BLOCKS;
   if (int e = r2l_launch_raw2rgb_bwd(a, (int)grid, stream)) return e;
   if (grad_black_level) {
-    R2LReduceRowsArgs r{(const float*)workspace, grad_black_level, (int)grid, 1.0};
+    R2LReduceRowsArgs r{(const float*)workspace, grad_black_level, (int)grid, 1.0, nullptr};
     return r2l_launch_reduce_rows(r, 4, stream);
   }
   return 0;
@@ -482,6 +491,86 @@ int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const doub
   }
   const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC", 1024));
   return r2l_launch_static_short(a, grid, stream);
+}
+
+// ---- staged (track_stages=True) entry points -------------------------------------------------------
+size_t r2l_stage_workspace_bytes(void) { return sizeof(float) * 81 * R2L_MAX_BLOCKS + 256; }
+
+static int r2l_stage_grid(int B, int H, int W, int per_thread) {
+  const size_t n = (size_t)B * H * W / per_thread;
+  size_t g = (n + R2L_NT - 1) / R2L_NT;
+  if (g > R2L_MAX_BLOCKS) g = R2L_MAX_BLOCKS;
+  return g < 1 ? 1 : (int)g;
+}
+static int r2l_stage_finish(const float* partial, int nslots, int grid, float* out, void* stream) {
+  R2LReduceRowsArgs r{partial, nullptr, grid, 1.0, out};
+  return r2l_launch_reduce_rows(r, nslots, stream);
+}
+
+int r2l_stage_conv33_fwd(const float* x, const float* w, float* y, int B, int H, int W, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!x || !w || !y) return r2l_fail(-1, "r2l_stage_conv33_fwd: null pointer");
+  R2LStageArgs a{x, nullptr, w, nullptr, y, nullptr, B, H, W, 3, 1};
+  return r2l_launch_conv33_fwd(a, r2l_stage_grid(B, H, W, 1), stream);
+}
+int r2l_stage_conv33_bwd(const float* x, const float* w, const float* g, float* gx, float* gw, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!x || !w || !g || !gw || !workspace) return r2l_fail(-1, "r2l_stage_conv33_bwd: null pointer");
+  if (workspace_bytes < r2l_stage_workspace_bytes()) return r2l_fail(-2, "r2l_stage: workspace too small");
+  const int grid = r2l_stage_grid(B, H, W, 1);
+  R2LStageArgs a{x, g, w, nullptr, gx, (float*)workspace, B, H, W, 3, 1};
+  if (int e = r2l_launch_conv33_bwd(a, grid, stream)) return e;
+  return r2l_stage_finish((const float*)workspace, 81, grid, gw, stream);
+}
+int r2l_stage_mix3_fwd(const float* x, const float* m, float* y, int B, int H, int W, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!x || !m || !y) return r2l_fail(-1, "r2l_stage_mix3_fwd: null pointer");
+  R2LStageArgs a{x, nullptr, m, nullptr, y, nullptr, B, H, W, 0, 0};
+  return r2l_launch_mix3_fwd(a, r2l_stage_grid(B, H, W, 1), stream);
+}
+int r2l_stage_mix3_bwd(const float* x, const float* m, const float* g, float* gx, float* gm, void* workspace,
+                       size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!m || !g || !workspace) return r2l_fail(-1, "r2l_stage_mix3_bwd: null pointer");
+  if (gm && !x) return r2l_fail(-1, "r2l_stage_mix3_bwd: the matrix gradient needs the forward input");
+  if (workspace_bytes < r2l_stage_workspace_bytes()) return r2l_fail(-2, "r2l_stage: workspace too small");
+  const int grid = r2l_stage_grid(B, H, W, 1);
+  R2LStageArgs a{gm ? x : nullptr, g, m, nullptr, gx, (float*)workspace, B, H, W, 0, 0};
+  if (int e = r2l_launch_mix3_bwd(a, grid, stream)) return e;
+  return gm ? r2l_stage_finish((const float*)workspace, 9, grid, gm, stream) : 0;
+}
+int r2l_stage_pconv_fwd(const float* x, const float* k, float* y, int K, int mirror, int B, int H, int W,
+                        void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!x || !k || !y || (K != 3 && K != 5)) return r2l_fail(-1, "r2l_stage_pconv_fwd: bad argument");
+  R2LStageArgs a{x, nullptr, k, nullptr, y, nullptr, B, H, W, K, mirror};
+  return r2l_launch_pconv_fwd(a, r2l_stage_grid(B, H, W, 1), stream);
+}
+int r2l_stage_pconv_bwd(const float* x, const float* k, const float* g, float* gx, float* gk25, int K,
+                        int mirror, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                        void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!x || !k || !g || !gk25 || !workspace || (K != 3 && K != 5))
+    return r2l_fail(-1, "r2l_stage_pconv_bwd: bad argument");
+  if (workspace_bytes < r2l_stage_workspace_bytes()) return r2l_fail(-2, "r2l_stage: workspace too small");
+  const int grid = r2l_stage_grid(B, H, W, 1);
+  R2LStageArgs a{x, g, k, nullptr, gx, (float*)workspace, B, H, W, K, mirror};
+  if (int e = r2l_launch_pconv_bwd(a, grid, stream)) return e;
+  return r2l_stage_finish((const float*)workspace, 25, grid, gk25, stream);
+}
+int r2l_stage_point(int op, const float* x, const float* g, const float* w, const float* aux,
+                    const float* aux2, float* y, float* sums6, void* workspace, size_t workspace_bytes,
+                    int B, int H, int W, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (op < 0 || op > 7) return r2l_fail(-1, "r2l_stage_point: unknown op");
+  const bool reduces = (op == 3 || op == 7);
+  if (reduces && (!sums6 || !workspace || workspace_bytes < r2l_stage_workspace_bytes()))
+    return r2l_fail(-2, "r2l_stage_point: reduction needs sums + workspace");
+  const int grid = r2l_stage_grid(B, H, W * 3, 4);
+  R2LPointArgs a{x, g, w, aux, aux2, y, reduces ? (float*)workspace : nullptr, B, H, W, op};
+  if (int e = r2l_launch_point(a, grid, stream)) return e;
+  return reduces ? r2l_stage_finish((const float*)workspace, 6, grid, sums6, stream) : 0;
 }
 
 }  // extern "C"

@@ -79,6 +79,7 @@ struct R2LReduceRowsArgs {
   double* sums;          // [nslots]
   int n;
   double scale;  // applied to the result
+  float* fsums;  // optional float32 copy of the result
 };
 R2L_BLOCKFN void r2l_reduce_rows_block(const R2LReduceRowsArgs& a, int bid, int nblk, float* lds) {
   (void)nblk;
@@ -99,7 +100,8 @@ R2L_BLOCKFN void r2l_reduce_rows_block(const R2LReduceRowsArgs& a, int bid, int 
   if (tid == 0) {
     double t = 0.0;
     for (int j = 0; j < 32; ++j) t += dl[R2L_NT + j];
-    a.sums[bid] = t * a.scale;
+    if (a.sums) a.sums[bid] = t * a.scale;
+    if (a.fsums) a.fsums[bid] = (float)(t * a.scale);
   }
   R2L_PHASE_END
 }

@@ -219,3 +219,54 @@ def check_harness(golden, device):
     with torch.no_grad():
         le = clf(proc(raw)).cpu().numpy()
     assert np.abs(le - g['harness/logits_eval_after']).max() < 5e-3
+
+
+def check_staged_case(case, golden, device):
+    """track_stages=True: every stage tensor, every stage gradient (retain_grad), d/d raw and the parameter
+    gradients against the reference's golden vectors."""
+    g = golden['param_cases']
+    grad_rtol = case.get('grad_rtol', 3e-3)
+    pre = case['name'] + '/'
+    full = case.get('full', True)
+    B, H, W = case['shape']
+    raw_np = orc.synth_raw(B, H, W, seed=case['seed'], kind=case['kind'])
+    cot = np.random.default_rng(1000 + case['seed']).standard_normal((B, 3, H, W)).astype(np.float32)
+    P = build_params(case)
+    m = make_module(case, P, device)
+    assert m.track_stages
+    raw = torch.from_numpy(raw_np).to(device).requires_grad_(True)
+    y = m(raw)
+    (y * torch.from_numpy(cot).to(device)).sum().backward()
+    assert list(m.stages.keys()) == list(g[pre + 'stage_keys'])
+    P64 = P.astype(np.float64)
+    _, _, cache = orc.parametrized_forward(raw_np, P64, track_stages=True, bn=oracle_bn(case))
+    o_nom, gr_nom, sg_nom = orc.parametrized_backward(P64, cache, cot, stage_grads=True)
+    o_lo, gr_lo, sg_lo = orc.parametrized_backward(P64, cache, cot, stage_grads=True, clip_shift=1e-6)
+    o_hi, gr_hi, sg_hi = orc.parametrized_backward(P64, cache, cot, stage_grads=True, clip_shift=-1e-6)
+
+    def flip(a, b, c):
+        return max(np.abs(np.asarray(b) - np.asarray(a)).max(), np.abs(np.asarray(c) - np.asarray(a)).max())
+    tol = out_tolerance(cache, case['bn'])
+    assert np.all(np.abs(_sample(y.detach().cpu().numpy(), full) - g[pre + 'out']) <= 2 * _sample(tol, full))
+    for k, st in m.stages.items():
+        ref = g[pre + 'stage/' + k]
+        got = _sample(st.detach().cpu().numpy(), full)
+        lim = 2e-4 if k in ('gamma_correct', 'noise') else 2e-5
+        assert np.abs(got - ref).max() <= lim, (k, np.abs(got - ref).max())
+        gref = g[pre + 'stage_grad/' + k]
+        ggot = _sample(st.grad.cpu().numpy(), full)
+        fl = _sample(np.maximum(np.abs(sg_lo[k] - sg_nom[k]), np.abs(sg_hi[k] - sg_nom[k])), full)
+        assert np.all(np.abs(ggot - gref) <= 2 * grad_rtol * (np.abs(gref).max() + 1e-6) + 2 * fl), \
+            ('stage grad', k, np.abs(ggot - gref).max())
+    gr = _sample(raw.grad.cpu().numpy(), full)
+    gr_ref = g[pre + 'grad_raw']
+    fl = _sample(np.maximum(np.abs(gr_lo - gr_nom), np.abs(gr_hi - gr_nom)), full)
+    assert np.all(np.abs(gr - gr_ref) <= 2 * grad_rtol * (np.abs(gr_ref).max() + 1e-6) + 2 * fl)
+    for k in o_nom:
+        ref = g[pre + 'grad/' + k]
+        got = NAME2ATTR[k](m).grad.detach().cpu().numpy().reshape(np.asarray(o_nom[k]).shape)
+        if k == 'additive_layer':
+            got = _sample(got, full)
+        e = np.abs(got - ref).max()
+        assert e <= 2 * grad_rtol * (np.abs(ref).max() + 1e-6) + 2 * flip(o_nom[k], o_lo[k], o_hi[k]), \
+            ('param grad', k, e)

@@ -31,3 +31,11 @@ def test_properties(emulation):
 
 def test_harness_logits_and_adam_step(golden, emulation):
     pc.check_harness(golden, 'cpu')
+
+
+TRACK_CASES = [c for c in PARAM_CASES if c['track']]
+
+
+@pytest.mark.parametrize('case', TRACK_CASES, ids=[c['name'] for c in TRACK_CASES])
+def test_staged_track_stages(case, golden, emulation):
+    pc.check_staged_case(case, golden, 'cpu')

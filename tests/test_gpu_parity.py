@@ -114,3 +114,11 @@ def test_full_size_static_config3_slice(dev):
 
 def test_harness_logits_and_adam_step(golden, dev):
     pc.check_harness(golden, dev)
+
+
+TRACK_CASES = [c for c in PARAM_CASES if c['track']]
+
+
+@pytest.mark.parametrize('case', TRACK_CASES, ids=[c['name'] for c in TRACK_CASES])
+def test_staged_track_stages(case, golden, dev):
+    pc.check_staged_case(case, golden, dev)
