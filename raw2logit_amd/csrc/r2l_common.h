@@ -91,6 +91,33 @@ R2L_HD r2l_f4 r2l_lds_f4(const float* p) {
 
 #define R2L_LN2 0.69314718055994530942
 
+// ---- packed pairs ---------------------------------------------------------------------------------
+// Two horizontally adjacent pixels share one v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: on gfx950 a packed
+// f32 instruction issues in the same 4 cycles as a scalar one (measured, tests/probes/valu_probe.hip), and
+// the fused kernels are bound by VALU issue, not by HBM.  Element h of a pair is the pixel in column 2p+h
+// of the thread's 4-column micro-tile; each half goes through exactly the operations (and the operation
+// order) of the unpacked code.
+#ifdef R2L_EMUL
+typedef float r2l_p2 __attribute__((vector_size(8)));
+R2L_HD r2l_p2 r2l_mk2(float a, float b) {
+  r2l_p2 r = {a, b};
+  return r;
+}
+R2L_HD r2l_p2 r2l_pfma(r2l_p2 a, r2l_p2 b, r2l_p2 c) { return r2l_mk2(fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])); }
+R2L_HD r2l_p2 r2l_pmul(r2l_p2 a, r2l_p2 b) { return r2l_mk2(a[0] * b[0], a[1] * b[1]); }
+R2L_HD r2l_p2 r2l_padd(r2l_p2 a, r2l_p2 b) { return r2l_mk2(a[0] + b[0], a[1] + b[1]); }
+#else
+typedef float r2l_p2 __attribute__((ext_vector_type(2)));
+R2L_HD r2l_p2 r2l_mk2(float a, float b) {
+  r2l_p2 r = {a, b};
+  return r;
+}
+R2L_HD r2l_p2 r2l_pfma(r2l_p2 a, r2l_p2 b, r2l_p2 c) { return __builtin_elementwise_fma(a, b, c); }
+R2L_HD r2l_p2 r2l_pmul(r2l_p2 a, r2l_p2 b) { return a * b; }
+R2L_HD r2l_p2 r2l_padd(r2l_p2 a, r2l_p2 b) { return a + b; }
+#endif
+R2L_HD r2l_p2 r2l_splat2(float a) { return r2l_mk2(a, a); }
+
 // torch 'reflect' (mirror without repeating the edge: c b | a b c), clamped for far-out indices
 R2L_HD int r2l_mirror(int i, int n) {
   i = i < 0 ? -i : i;
@@ -128,6 +155,11 @@ struct R2LFolded {
   float inv_gamma;
   float gamma;
   float pad[2];
+  // the parity-indexed stencils again, laid out [row parity][tap][column parity]: the weights of a pixel
+  // pair (even column, odd column) sit side by side, i.e. in one aligned SGPR pair after an s_load_dwordx2
+  float AY2[2][9][2];
+  float AU2[2][9][2];
+  float AV2[2][9][2];
 };
 
 // The kernels read the folded block through the CONSTANT address space so that every weight is a
@@ -164,10 +196,22 @@ R2L_HD void r2l_fold_T(const float* P, double T[3][3]) {
 R2L_HD void r2l_fold_one(const float* P, R2LFolded* F, int idx) {
   float* out = (float*)F;
   const int o_ay = 4, o_sharp = 4 + 108, o_blur = o_sharp + 9, o_m2 = o_blur + 25, o_ig = o_m2 + 9;
+  const int o_pair = o_ig + 4;
   if (idx < 4) {
     out[idx] = P[R2L_P_BLACK_LEVEL + idx];
-  } else if (idx < o_sharp) {
-    const int e = idx - o_ay, k = e / 36, par = (e % 36) / 9, t = e % 9;
+  } else if ((idx >= o_ay && idx < o_sharp) || (idx >= o_pair && idx < o_pair + 108)) {
+    int k, par, t;
+    if (idx < o_sharp) {
+      const int e = idx - o_ay;
+      k = e / 36;
+      par = (e % 36) / 9;
+      t = e % 9;
+    } else {  // [k][py][t][px]
+      const int e = idx - o_pair;
+      k = e / 36;
+      par = ((e % 36) / 18) * 2 + (e & 1);
+      t = (e % 18) / 2;
+    }
     const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
     const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
     double T[3][3];

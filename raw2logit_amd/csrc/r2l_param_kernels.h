@@ -15,9 +15,11 @@
 
 // diagnostic builds only (-DR2L_EXP_STAMPS): per-phase s_memtime totals of each workgroup's wave 0
 #if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
-#define R2L_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime(), t1_;
+#define R2L_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime(), t1_; \
+  const unsigned long long r0_ = __builtin_amdgcn_s_memrealtime();
 #define R2L_STAMP(k) t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - t0_; t0_ = t1_;
-#define R2L_STAMP_FLUSH(dbg, bid) if (threadIdx.x == 0 && (dbg)) for (int k_ = 0; k_ < 8; ++k_) (dbg)[(size_t)(bid) * 8 + k_] = (float)st_[k_];
+#define R2L_STAMP_FLUSH(dbg, bid) st_[7] = __builtin_amdgcn_s_memrealtime() - r0_; /* 100 MHz ticks: slot 7 */ \
+  if (threadIdx.x == 0 && (dbg)) for (int k_ = 0; k_ < 8; ++k_) (dbg)[(size_t)(bid) * 8 + k_] = (float)st_[k_];
 #else
 #define R2L_STAMP_DECL
 #define R2L_STAMP(k)
@@ -77,11 +79,14 @@ R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, i
   w.jstep = nblk / ngroups;
   return w;
 }
-// k-th tile of a workgroup: block k of `jstep` consecutive tiles, rotated by k so that a workgroup does
-// not keep landing on the same position of every image (corner / edge tiles cost more than interior ones)
+// k-th tile of a workgroup: block k of `jstep` consecutive tiles, rotated by k tile rows + k tile columns
+// so that a workgroup walks a diagonal of tile positions: border tiles cost more than interior ones (44 %
+// of the tiles of a 512x512 frame are border tiles), and with a rotation by columns only the workgroups
+// that start in the first or last tile row would see nothing but border tiles (measured: slowest workgroup
+// 28 % above the mean).
 R2L_HD bool r2l_walk_next(R2LTileWalk& w, int H, int W, int TW, int TH, R2LTile& t) {
   while (w.k * w.jstep < w.nper) {
-    const int j = w.k * w.jstep + (w.w + w.k) % w.jstep;
+    const int j = w.k * w.jstep + (w.w + w.k * (w.ntx + 1)) % w.jstep;
     w.k += 1;
     if (j >= w.nper) continue;
     const int tile = w.group * w.nper + j;
@@ -455,6 +460,36 @@ R2L_HD void r2l_chroma_row(const float vw[3][6], R2LFoldedRef F, float u[4], flo
   }
 }
 
+// packed forms: pair p = columns (2p, 2p+1) of the micro-tile row
+R2L_HD void r2l_blur_row2(const float yw[5][8], R2LFoldedRef F, r2l_p2 ypp[2]) {
+  ypp[0] = ypp[1] = r2l_splat2(0.f);
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 5; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 5; ++j) {
+    const r2l_p2 w = r2l_splat2(F.blur[i * 5 + j]);
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) ypp[p] = r2l_pfma(w, r2l_mk2(yw[i][2 * p + j], yw[i][2 * p + j + 1]), ypp[p]);
+  }
+}
+template <int PY>
+R2L_HD void r2l_chroma_row2(const float vw[3][6], R2LFoldedRef F, r2l_p2 u[2], r2l_p2 v[2]) {
+  u[0] = u[1] = v[0] = v[1] = r2l_splat2(0.f);
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    const r2l_p2 wu = r2l_mk2(F.AU2[PY][i * 3 + j][0], F.AU2[PY][i * 3 + j][1]);
+    const r2l_p2 wv = r2l_mk2(F.AV2[PY][i * 3 + j][0], F.AV2[PY][i * 3 + j][1]);
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) {
+      const r2l_p2 x = r2l_mk2(vw[i][2 * p + j], vw[i][2 * p + j + 1]);
+      u[p] = r2l_pfma(wu, x, u[p]);
+      v[p] = r2l_pfma(wv, x, v[p]);
+    }
+  }
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -470,66 +505,67 @@ struct R2LFwdArgs {
 };
 
 struct R2LFwdRegs {
-  float acc[6];
+  r2l_p2 acc[6];  // per pair half; the halves are added when the workgroup reduces
 };
+#define R2L_ACC_FWD(regs, i) (R2L_TREG(regs).acc[i][0] + R2L_TREG(regs).acc[i][1])
 
 template <class G, int PY, bool RAGGED, bool ADD>
 R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, int tx, int frow, int gx0,
                         unsigned off0, unsigned plane, float* ob, const float mean[3],
                         const float istd[3], R2LFwdRegs& regs) {
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
-  float ypp[4], u[4], v[4];
+  r2l_p2 ypp[2], u[2], v[2];
   {
     float yw[5][8];
     r2l_rows_yp<G>(YP, tx, frow, yw);
-    r2l_blur_row(yw, F, ypp);
+    r2l_blur_row2(yw, F, ypp);
   }
   {
     float vw[3][6];
     r2l_rows_3x6<G>(V, tx, frow, vw);
-    r2l_chroma_row<PY>(vw, F, u, v);
+    r2l_chroma_row2<PY>(vw, F, u, v);
   }
   const bool vec_ok = !RAGGED || (((a.W & 3) == 0) && (gx0 + 3 < a.W));
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
-    float x[4];
-    R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) {
-      float rgb = F.M2[k * 3] * ypp[c];
-      rgb = fmaf(F.M2[k * 3 + 1], u[c], rgb);
-      rgb = fmaf(F.M2[k * 3 + 2], v[c], rgb);
-      const float xc = fminf(fmaxf(rgb, 1e-5f), 1.0f);          // :206
-      x[c] = r2l_exp2(r2l_log2(xc) * F.inv_gamma);              // :209
-    }
+    r2l_p2 x[2];
     const unsigned off = (unsigned)k * plane + off0;
-    if (ADD) {                                                 // :213 (H == W == 256)
-      R2L_PRAGMA_UNROLL
-      for (int c = 0; c < 4; ++c)
-        if (!RAGGED || gx0 + c < a.W) x[c] += a.additive[off + c];
-    }
-    if (a.stat_partial) {
-      R2L_PRAGMA_UNROLL
-      for (int c = 0; c < 4; ++c)
-        if (!RAGGED || gx0 + c < a.W) {
-          const float d = x[c] - 0.5f;
-          regs.acc[k] += d;
-          regs.acc[3 + k] = fmaf(d, d, regs.acc[3 + k]);
-        }
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) {
+      r2l_p2 rgb = r2l_pmul(r2l_splat2(F.M2[k * 3]), ypp[p]);
+      rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 1]), u[p], rgb);
+      rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 2]), v[p], rgb);
+      const r2l_p2 lg = r2l_mk2(r2l_log2(fminf(fmaxf(rgb[0], 1e-5f), 1.0f)),     // :206
+                                r2l_log2(fminf(fmaxf(rgb[1], 1e-5f), 1.0f)));
+      const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));                    // :209
+      x[p] = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
+      if (ADD) {                                                                 // :213 (H == W == 256)
+        const float a0 = (!RAGGED || gx0 + 2 * p < a.W) ? a.additive[off + 2 * p] : 0.f;
+        const float a1 = (!RAGGED || gx0 + 2 * p + 1 < a.W) ? a.additive[off + 2 * p + 1] : 0.f;
+        x[p] = r2l_padd(x[p], r2l_mk2(a0, a1));
+      }
+      if (a.stat_partial) {
+        r2l_p2 d = r2l_padd(x[p], r2l_splat2(-0.5f));
+        if (RAGGED) d = r2l_mk2(gx0 + 2 * p < a.W ? d[0] : 0.f, gx0 + 2 * p + 1 < a.W ? d[1] : 0.f);
+        regs.acc[k] = r2l_padd(regs.acc[k], d);
+        regs.acc[3 + k] = r2l_pfma(d, d, regs.acc[3 + k]);
+      }
     }
     if (ob) {
       R2L_PRAGMA_UNROLL
-      for (int c = 0; c < 4; ++c) x[c] = (x[c] - mean[k]) * istd[k];  // :217
+      for (int p = 0; p < 2; ++p)
+        x[p] = r2l_pmul(r2l_padd(x[p], r2l_splat2(-mean[k])), r2l_splat2(istd[k]));  // :217
       if (vec_ok) {
         r2l_f4 st;
-        st.x = x[0];
-        st.y = x[1];
-        st.z = x[2];
-        st.w = x[3];
+        st.x = x[0][0];
+        st.y = x[0][1];
+        st.z = x[1][0];
+        st.w = x[1][1];
         *(r2l_f4*)(ob + off) = st;
       } else {
         R2L_PRAGMA_UNROLL
         for (int c = 0; c < 4; ++c)
-          if (gx0 + c < a.W) ob[off + c] = x[c];
+          if (gx0 + c < a.W) ob[off + c] = x[c >> 1][c & 1];
       }
     }
   }
@@ -615,7 +651,7 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 6; ++i) R2L_TREG(regs).acc[i] = 0.f;
+  for (int i = 0; i < 6; ++i) R2L_TREG(regs).acc[i] = r2l_splat2(0.f);
   if (have) r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   R2L_PHASE_END
   R2L_STAMP_DECL
@@ -655,7 +691,7 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   }
   R2L_STAMP_FLUSH(a.debug, bid)
   if (a.stat_partial) {
-    R2L_BLOCK_REDUCE(6, regs, lds, a.stat_partial, bid, nblk)
+    R2L_BLOCK_REDUCE_F(6, R2L_ACC_FWD, regs, lds, a.stat_partial, bid, nblk)
   }
 }
 
@@ -704,11 +740,37 @@ struct R2LBnConsts {
   float mean[3], istd[3], mg[3], mgx[3];
 };
 
+// grad_out of this thread's 2 rows x 4 columns x 3 channels, fetched two phases ahead of its use: in the
+// pixel phase a wave has one other wave per SIMD to hide behind (VGPR-bound, 1 workgroup per CU), which
+// does not cover an HBM round trip; issued before the Y phase the loads have ~2 phases to land.
+struct R2LGoutPre {
+  r2l_f4 g[2][3];
+};
+template <class G>
+R2L_HD void r2l_bwd1_fetch_gout(int tid, const R2LBwd1Args& a, const R2LTile& t, R2LGoutPre& gp) {
+  int tx, row0, py;
+  G::thread_tile(tid, tx, row0, py);
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const float* gb = a.gout + (size_t)t.b * 3 * plane;
+  const unsigned pix0 = (unsigned)(t.oy + row0) * (unsigned)a.W + (unsigned)(t.ox + 4 * tx);
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 2; ++r)
+    R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k)
+    gp.g[r][k] = *(const r2l_f4*)(gb + (unsigned)k * plane + pix0 + (unsigned)(2 * r) * (unsigned)a.W);
+}
+
 // one output row (4 pixels of this thread) of kernel B1; PY = row parity
-template <class G, int PY, bool RAGGED, bool ADD>
+R2L_HD float r2l_pick(bool second, float a, float b) {
+#ifndef R2L_EMUL
+  asm("" : "+v"(a), "+v"(b));  // a select of two register values (never a load through a selected address)
+#endif
+  return second ? b : a;
+}
+template <class G, int PY, bool RAGGED, bool ADD, bool PRE>
 R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, int tx, int frow, int gx0,
-                         unsigned off0, unsigned plane, const float* gb, float* gyb,
-                         const R2LBnConsts& bc, R2LBwd1Regs& regs) {
+                         unsigned off0, unsigned plane, const float* gb, const R2LGoutPre& gpre, bool second,
+                         float* gyb, const R2LBnConsts& bc, R2LBwd1Regs& regs) {
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
   float yw[5][8], vw[3][6];
   float ypp[4], u[4], v[4];
@@ -723,7 +785,12 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
   for (int k = 0; k < 3; ++k) {
     const unsigned off = (unsigned)k * plane + off0;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec_ok) {
+    if (PRE) {  // register select, not an indexed access (which would go through scratch)
+      g[0] = r2l_pick(second, gpre.g[0][k].x, gpre.g[1][k].x);
+      g[1] = r2l_pick(second, gpre.g[0][k].y, gpre.g[1][k].y);
+      g[2] = r2l_pick(second, gpre.g[0][k].z, gpre.g[1][k].z);
+      g[3] = r2l_pick(second, gpre.g[0][k].w, gpre.g[1][k].w);
+    } else if (vec_ok) {
       const r2l_f4 q = *(const r2l_f4*)(gb + off);
       g[0] = q.x;
       g[1] = q.y;
@@ -814,9 +881,9 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
 #endif
 }
 
-template <class G, bool RAGGED, bool ADD>
+template <class G, bool RAGGED, bool ADD, bool PRE>
 R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LBwd1Args& a,
-                            const R2LTile& t, R2LBwd1Regs& regs) {
+                            const R2LTile& t, const R2LGoutPre& gp, R2LBwd1Regs& regs) {
   int tx, row0, py;
   G::thread_tile(tid, tx, row0, py);
   const int gy0 = t.oy + row0, gx0 = t.ox + 4 * tx;
@@ -838,9 +905,11 @@ R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LB
     if (RAGGED && gy0 + rr >= a.H) break;
     const unsigned off0 = pix0 + (unsigned)rr * (unsigned)a.W;
     if (py)
-      r2l_bwd1_row<G, 1, RAGGED, ADD>(V, YP, a, tx, row0 + 4 + rr, gx0, off0, plane, gb, gyb, bc, regs);
+      r2l_bwd1_row<G, 1, RAGGED, ADD, PRE>(V, YP, a, tx, row0 + 4 + rr, gx0, off0, plane, gb, gp, rr != 0, gyb,
+                                           bc, regs);
     else
-      r2l_bwd1_row<G, 0, RAGGED, ADD>(V, YP, a, tx, row0 + 4 + rr, gx0, off0, plane, gb, gyb, bc, regs);
+      r2l_bwd1_row<G, 0, RAGGED, ADD, PRE>(V, YP, a, tx, row0 + 4 + rr, gx0, off0, plane, gb, gp, rr != 0, gyb,
+                                           bc, regs);
   }
 }
 
@@ -852,6 +921,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   float* YP = Y + G::PLANE;
   R2L_TREG_DECL(R2LBwd1Regs, regs);
   R2L_TREG_DECL(R2LPrefetch<G>, pre);
+  R2L_TREG_DECL(R2LGoutPre, gpre);
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t, tn;
   bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
@@ -872,6 +942,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
+    if (!MAYBE_RAGGED) r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre));  // consumed in the pixel phase
     if (t.border)
       r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     else
@@ -891,9 +962,9 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     R2L_PHASE_BEGIN
     if (haven) r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
     if (MAYBE_RAGGED && t.ragged)
-      r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
+      r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD, false>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
     else
-      r2l_bwd1_pixels<G, false, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
+      r2l_bwd1_pixels<G, false, ADD, !MAYBE_RAGGED>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
     R2L_PHASE_END
     R2L_STAMP(4)
     t = tn;

@@ -23,7 +23,8 @@ for _ in range(3):
     lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(P), None, ptr(bn), ptr(out), None, ptr(ws), n, B, H, W, 0, s), 'fwd')
     lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(P), None, ptr(bn), ptr(bnb), ptr(gout), ptr(gp), None, ptr(ws), n, B, H, W, 0, s), 'bwd')
 torch.cuda.synchronize()
-off = 768 + 106 * 1024 * 4 + 49 * 1024 * 4 + 8 * 1024 * 4 + 1280
+al = lambda x: (x + 255) & ~255
+off = al(4 * 267) + al(106 * 1024 * 4) + al(49 * 1024 * 4) + al(8 * 1024 * 4) + al(155 * 8)   # r2l_carve()
 dbg = ws[off:off + 3 * 8 * 1024 * 4].view(torch.float32).view(3, 1024, 8).double().cpu()
 names = {0: ['store', 'Y', 'YP', 'fill', 'pixels'], 1: ['store', 'Y', 'YP', 'fill', 'pixels'],
          2: ['store', 'adjblur', 'Y+fold', 'pixels']}
@@ -31,7 +32,17 @@ for k, kn in enumerate(['fwd', 'bwd1', 'bwd2']):
     d = dbg[k]
     nb = int((d.sum(1) > 0).sum())
     d = d[:nb]
+    rt = d[:, 7].mean().item()          # s_memrealtime ticks (100 MHz) over the same span
+    d = d[:, :7]
     tot = d.sum(1).mean().item()
-    print(f'{kn}: {nb} workgroups, mean total {tot:,.0f} cycles = {tot/2.4e3:.1f} us @2.4GHz')
+    print(f'{kn}: {nb} workgroups, mean total {tot:,.0f} cycles over {rt/100:.1f} us: in-kernel clock {tot/rt*0.1:.2f} GHz')
+    tt = d.sum(1)
+    print(f'   per-workgroup total: min {tt.min().item():,.0f}  median {tt.median().item():,.0f}  p90 {tt.quantile(0.9).item():,.0f}  max {tt.max().item():,.0f}')
     for i, nm in enumerate(names[k]):
         print(f'   {nm:8s} mean {d[:, i].mean().item():10,.0f}  ({100*d[:, i].mean().item()/tot:4.1f} %)  max {d[:, i].max().item():10,.0f}')
+if os.environ.get('R2L_STAMPS_DETAIL'):
+    for k, kn in enumerate(['fwd', 'bwd1', 'bwd2']):
+        d = dbg[k][:512, :7].sum(1)
+        print(kn, 'by XCD (bid % 8):', [int(d[x::8].mean().item() / 1e3) for x in range(8)])
+        print(kn, 'by w = bid // 8 (kcycles):', [int(d[8 * w:8 * w + 8].mean().item() / 1e3) for w in range(64)])
+        print(kn, 'fill-phase cycles by w:', [int(dbg[k][8 * w:8 * w + 8, 3].mean().item() / 1e3) for w in range(64)])
