@@ -92,9 +92,14 @@ int r2l_raw2rgb_bwd(const float *grad_out, float *grad_raw, double *grad_black_l
  *  additive  float[3*256*256] or NULL (requires H == W == 256, as in the reference :130)
  *  bn_mean_istd  float[6] = mean[3], 1/sqrt(var+eps)[3] to apply, or NULL for no normalisation
  *  out       (B,3,H,W), may be NULL with R2L_F_STATS_ONLY
- *  stats     double[6] or NULL: receives sum_c(x-0.5)[3], sum_c((x-0.5)^2)[3] of the PRE-normalisation
- *            output over this call's B*H*W pixels (the caller turns them into batch mean / biased
- *            variance; with several GPUs it sums the vectors of all ranks first)
+ *  stats     double[7] or NULL: receives sum_c(x-0.5)[3], sum_c((x-0.5)^2)[3] of the PRE-normalisation
+ *            output over this call's B*H*W pixels, then that pixel count (r2l_bn_finalize turns them into
+ *            batch mean / biased variance; with several GPUs the vectors of all ranks are summed first).
+ *            The per-workgroup partial sums are added in a fixed order by the last workgroups of the same
+ *            launch (no separate reduction launch, bitwise reproducible).
+ *  workspace r2l_isp_workspace_bytes() of device memory, uninitialised on first use; a call WITHOUT
+ *            R2L_F_FOLDED_VALID initialises it (folded weights, arrival counters).  A workspace must not be
+ *            used by two streams at once.
  */
 size_t r2l_isp_workspace_bytes(int B, int H, int W);
 int r2l_isp_fwd(const float *raw, const float *params, const float *additive,
@@ -105,14 +110,22 @@ int r2l_isp_fwd(const float *raw, const float *params, const float *additive,
  * totals double[7] = the `stats` vector of r2l_isp_fwd summed over all ranks, followed by the total pixel
  * count per channel n.  Writes bn_mean_istd float[6] (for the apply pass), optionally moments double[6] =
  * batch mean[3], biased variance[3], and optionally updates running_mean / running_var float[3] the way
- * nn.BatchNorm2d does (momentum, unbiased variance).                                              */
+ * nn.BatchNorm2d does (momentum, unbiased variance).  num_batches_tracked (device int64, optional) is
+ * incremented; momentum < 0 selects the cumulative moving average 1/num_batches_tracked
+ * (nn.BatchNorm2d(momentum=None)).                                                              */
 int r2l_bn_finalize(const double *totals, float *bn_mean_istd, double *moments, float *running_mean,
-                    float *running_var, double eps, double momentum, void *stream);
+                    float *running_var, long long *num_batches_tracked, double eps, double momentum,
+                    void *stream);
 
 /* BatchNorm backward reduction (nn.BatchNorm2d backward in train mode, :216-217):
- * sums double[6] = sum_c(g)[3], sum_c(g*xhat)[3] with xhat == the saved forward output.          */
-int r2l_bn_bwd_reduce(const float *grad_out, const float *out, double *sums, void *workspace,
-                      size_t workspace_bytes, int B, int H, int W, void *stream);
+ * sums double[6] = sum_c(g)[3], sum_c(g*xhat)[3] with xhat == the saved forward output; with `totals`
+ * (double[7], totals[6] = pixel count of the global batch) and bn_bwd (float[6]) also the means
+ * bn_bwd = sums / n that r2l_isp_bwd consumes (single GPU; with several GPUs the caller all-reduces
+ * `sums` and divides itself).  flags: R2L_F_FOLDED_VALID = the workspace went through r2l_isp_fwd /
+ * r2l_isp_bwd before (the reduction then finishes inside the same launch).                        */
+int r2l_bn_bwd_reduce(const float *grad_out, const float *out, const double *totals, double *sums,
+                      float *bn_bwd, void *workspace, size_t workspace_bytes, int B, int H, int W,
+                      int flags, void *stream);
 
 /* Backward of r2l_isp_fwd (what autograd computes for pipeline_torch.py:183-217), recomputing the
  * forward from `raw`:

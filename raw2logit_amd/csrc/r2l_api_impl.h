@@ -122,7 +122,7 @@ static_assert(R2L_LDS3(GFwd) >= R2L_RED_FLOATS, "reduction scratch must fit");
 static_assert(R2L_LDS3(GBwd2) >= R2L_RED_FLOATS, "reduction scratch must fit");
 
 R2L_KERNEL(r2l_launch_fold, R2LFoldArgs, r2l_fold_block, 4)
-R2L_KERNEL(r2l_launch_unfold, R2LUnfoldArgs, r2l_unfold_block, 4)
+R2L_KERNEL(r2l_launch_unfold, R2LUnfoldArgs, r2l_unfold_block, 4 + 2 * R2L_NSUMS + 2 * R2L_UNFOLD_TG + R2L_P_COUNT + 4)
 R2L_KERNEL(r2l_launch_bn_finalize, R2LBnFinalizeArgs, r2l_bn_finalize_block, 4)
 R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 * R2L_NT + 64)
 #ifndef R2L_OCC_FWD
@@ -161,7 +161,7 @@ R2L_KERNEL(r2l_launch_pconv_bwd, R2LStageArgs, r2l_pconv_bwd_block, R2L_RED_FLOA
 R2L_KERNEL(r2l_launch_point, R2LPointArgs, r2l_point_block, R2L_RED_FLOATS)
 
 // ---- grid sizing ------------------------------------------------------------------------------
-#define R2L_MAX_BLOCKS 1024
+static_assert(R2L_MAX_BLOCKS == 1024, "partials are laid out for at most 1024 workgroups");
 static int r2l_env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   if (!s || !*s) return dflt;
@@ -184,6 +184,8 @@ struct R2LWorkspace {
   float* part_b2;
   float* part_small;
   double* sums;
+  double* gpartial;    // [R2L_NSUMS][R2L_MAX_GROUPS] group partials of the in-kernel final reductions
+  unsigned* counters;  // [1 + R2L_MAX_GROUPS] arrival counters: zeroed by the fold kernel, zero after every launch
   float* gypp;
   float* debug;  // 3 x [R2L_MAX_BLOCKS][8] floats: per-phase cycle stamps of diagnostic builds (fwd, bwd1, bwd2)
   size_t total;
@@ -203,6 +205,10 @@ static R2LWorkspace r2l_carve(void* base, int B, int H, int W) {
   off += r2l_align_up(sizeof(float) * 8 * R2L_MAX_BLOCKS);
   w.sums = (double*)(p + off);
   off += r2l_align_up(sizeof(double) * R2L_NSUMS);
+  w.gpartial = (double*)(p + off);
+  off += r2l_align_up(sizeof(double) * R2L_NSUMS * R2L_MAX_GROUPS);
+  w.counters = (unsigned*)(p + off);
+  off += r2l_align_up(sizeof(unsigned) * (1 + R2L_MAX_GROUPS));
   w.debug = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * 3 * 8 * R2L_MAX_BLOCKS);
   w.gypp = (float*)(p + off);
@@ -288,7 +294,7 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
   const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
   if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_fwd: workspace too small");
   if (!(flags & R2L_F_FOLDED_VALID)) {
-    R2LFoldArgs fa{params, ws.folded};
+    R2LFoldArgs fa{params, ws.folded, ws.counters};
     if (int e = r2l_launch_fold(fa, 1, stream)) return e;
   }
   const int ntiles = B * ((H + GFwd::TH - 1) / GFwd::TH) * ((W + GFwd::TW - 1) / GFwd::TW);
@@ -304,38 +310,48 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
   a.H = H;
   a.W = W;
   a.debug = ws.debug;
+  // the statistics are reduced by the last workgroups of the same launch (the workspace's arrival counters
+  // are valid: this call or an earlier one on this workspace ran the fold kernel)
+  a.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6};
+  a.stats_out = stats;
   const bool exact = (H % GFwd::TH == 0) && (W % GFwd::TW == 0);
   if (int e = additive ? r2l_launch_fwd_add(a, grid, stream)
                        : (exact ? r2l_launch_fwd(a, grid, stream) : r2l_launch_fwd_ragged(a, grid, stream)))
     return e;
-  if (stats) {
-    R2LReduceRowsArgs r{ws.part_small, stats, grid, 1.0, nullptr};
-    if (int e = r2l_launch_reduce_rows(r, 6, stream)) return e;
-  }
   return 0;
 }
 
 int r2l_bn_finalize(const double* totals, float* bn_mean_istd, double* moments, float* running_mean,
-                    float* running_var, double eps, double momentum, void* stream) {
+                    float* running_var, long long* num_batches_tracked, double eps, double momentum,
+                    void* stream) {
   if (!totals || !bn_mean_istd) return r2l_fail(-1, "r2l_bn_finalize: null pointer");
   if ((running_mean == nullptr) != (running_var == nullptr))
     return r2l_fail(-1, "r2l_bn_finalize: running_mean and running_var go together");
-  R2LBnFinalizeArgs a{totals, bn_mean_istd, moments, running_mean, running_var, eps, momentum};
+  R2LBnFinalizeArgs a{totals, bn_mean_istd, moments, running_mean, running_var, eps, momentum, num_batches_tracked};
   return r2l_launch_bn_finalize(a, 1, stream);
 }
 
-int r2l_bn_bwd_reduce(const float* grad_out, const float* out, double* sums, void* workspace,
-                      size_t workspace_bytes, int B, int H, int W, void* stream) {
+int r2l_bn_bwd_reduce(const float* grad_out, const float* out, const double* totals, double* sums,
+                      float* bn_bwd, void* workspace, size_t workspace_bytes, int B, int H, int W, int flags,
+                      void* stream) {
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (!grad_out || !out || !sums || !workspace) return r2l_fail(-1, "r2l_bn_bwd_reduce: null pointer");
+  if (bn_bwd && !totals) return r2l_fail(-1, "r2l_bn_bwd_reduce: bn_bwd needs totals (the pixel count)");
   const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
   if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_bn_bwd_reduce: workspace too small");
   const size_t hw = (size_t)H * W;
   const size_t nitems = (size_t)3 * B * ((hw + R2L_SEG - 1) / R2L_SEG);
-  int grid = nitems < (size_t)R2L_MAX_BLOCKS ? (int)nitems : R2L_MAX_BLOCKS;
-  R2LBnReduceArgs a{grad_out, out, ws.part_small, B, H, W};
+  const int cap = r2l_tile_grid(R2L_MAX_BLOCKS, r2l_env_int("R2L_GRID_BNR", R2L_MAX_BLOCKS));
+  int grid = nitems < (size_t)cap ? (int)nitems : cap;
+  // a workspace that went through r2l_isp_fwd / r2l_isp_bwd has valid arrival counters: the last workgroups
+  // of the launch finish the reduction; otherwise a second, tiny launch does
+  const bool in_kernel = (flags & R2L_F_FOLDED_VALID) != 0;
+  R2LBnReduceArgs a{grad_out, out, ws.part_small, B, H, W,
+                    R2LTree{ws.part_small, nullptr, ws.gpartial, in_kernel ? ws.counters : nullptr, 6},
+                    sums, totals, bn_bwd};
   if (int e = r2l_launch_bn_reduce(a, grid, stream)) return e;
-  R2LReduceRowsArgs r{ws.part_small, sums, grid, 1.0, nullptr};
+  if (in_kernel) return 0;
+  R2LReduceRowsArgs r{ws.part_small, sums, grid, 1.0, bn_bwd, nullptr, 0.0, bn_bwd ? totals + 6 : nullptr};
   return r2l_launch_reduce_rows(r, 6, stream);
 }
 
@@ -354,11 +370,11 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
   if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_bwd: workspace too small");
   if (!(flags & R2L_F_FOLDED_VALID)) {
-    R2LFoldArgs fa{params, ws.folded};
+    R2LFoldArgs fa{params, ws.folded, ws.counters};
     if (int e = r2l_launch_fold(fa, 1, stream)) return e;
   }
   const int ntiles = B * ((H + GBwd1::TH - 1) / GBwd1::TH) * ((W + GBwd1::TW - 1) / GBwd1::TW);
-  const int g1 = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_BWD1", 512));
+  const int g1 = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_BWD1", 256));
   R2LBwd1Args a1;
   a1.raw = raw;
   a1.additive = additive;
@@ -377,7 +393,7 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
                        : (exact ? r2l_launch_bwd1(a1, g1, stream) : r2l_launch_bwd1_ragged(a1, g1, stream)))
     return e;
   const int ntiles2 = B * ((H + GBwd2::TH - 1) / GBwd2::TH) * ((W + GBwd2::TW - 1) / GBwd2::TW);
-  const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", 512));
+  const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", 256));
   R2LBwd2Args a2;
   a2.raw = raw;
   a2.F = ws.folded;
@@ -387,7 +403,14 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   a2.H = H;
   a2.W = W;
   a2.debug = ws.debug + 16 * R2L_MAX_BLOCKS;
+  // B2's last workgroups reduce both kernels' partials and unfold them into the 132 gradients (the two
+  // grids are equal unless the R2L_GRID_* overrides differ: then three tiny launches do it)
+  const bool in_kernel = g1 == g2;
+  a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC};
+  a2.params = params;
+  a2.grad_params = grad_params;
   if (int e = r2l_launch_bwd2(a2, g2, stream)) return e;
+  if (in_kernel) return 0;
   R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0, nullptr};
   if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
   R2LReduceRowsArgs r2{ws.part_b2, ws.sums + R2L_B1_NACC, g2, 1.0, nullptr};

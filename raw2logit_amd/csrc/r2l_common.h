@@ -91,6 +91,39 @@ R2L_HD r2l_f4 r2l_lds_f4(const float* p) {
 
 #define R2L_LN2 0.69314718055994530942
 
+// Primitives of the in-kernel final reductions.  Partials travel between workgroups (possibly on different
+// XCDs, whose L2s are not coherent with each other) through device-coherent accesses: relaxed agent-scope
+// atomic stores / loads, which write through / read past the local L2.  A full agent-scope fence would work
+// too but writes back and invalidates the whole L2 of the XCD (measured: every kernel 2-7x slower, the frames
+// being streamed lose their L2 lines); instead a producer only waits for its own coherent stores to be
+// acknowledged (s_waitcnt vmcnt(0)) before it takes its arrival ticket.
+// (the emulation runs the workgroups of a launch one after the other, so plain memory operations do)
+#ifdef R2L_EMUL
+#define R2L_STORES_DONE()
+R2L_HD unsigned r2l_ticket(unsigned* c) { return (*c)++; }
+R2L_HD void r2l_store_coherent(float* p, float v) { *p = v; }
+R2L_HD void r2l_store_coherent(double* p, double v) { *p = v; }
+R2L_HD float r2l_load_coherent(const float* p) { return *p; }
+R2L_HD double r2l_load_coherent(const double* p) { return *p; }
+#else
+#define R2L_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+R2L_HD unsigned r2l_ticket(unsigned* c) {
+  return __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+R2L_HD void r2l_store_coherent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+R2L_HD void r2l_store_coherent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+R2L_HD float r2l_load_coherent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+R2L_HD double r2l_load_coherent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // ---- packed pairs ---------------------------------------------------------------------------------
 // Two horizontally adjacent pixels share one v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: on gfx950 a packed
 // f32 instruction issues in the same 4 cycles as a scalar one (measured, tests/probes/valu_probe.hip), and
@@ -192,6 +225,20 @@ R2L_HD void r2l_fold_T(const float* P, double T[3][3]) {
       T[k][c] = s * (double)P[R2L_P_WHITE_BALANCE + c];
     }
 }
+// element (k, c) of T = M_RGB_2_YUV * colour_correction * diag(white_balance), float64
+R2L_HD double r2l_fold_T_one(const float* P, int k, int c) {
+  double s = 0;
+  for (int j = 0; j < 3; ++j) s += (double)P[R2L_P_M_RGB2YUV + k * 3 + j] * (double)P[R2L_P_CCM + j * 3 + c];
+  return s * (double)P[R2L_P_WHITE_BALANCE + c];
+}
+// A[k][par][t] = sum_j T[k][j] * debayer.weight[j][channel(site(par,t))][t], float64
+R2L_HD double r2l_fold_A_one(const float* P, int k, int par, int t) {
+  const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
+  const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
+  double s = 0;
+  for (int j = 0; j < 3; ++j) s += r2l_fold_T_one(P, k, j) * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
+  return s;
+}
 // element `idx` (float index into R2LFolded) of the folded block; one lane per element
 R2L_HD void r2l_fold_one(const float* P, R2LFolded* F, int idx) {
   float* out = (float*)F;
@@ -212,13 +259,8 @@ R2L_HD void r2l_fold_one(const float* P, R2LFolded* F, int idx) {
       par = ((e % 36) / 18) * 2 + (e & 1);
       t = (e % 18) / 2;
     }
-    const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
-    const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
-    double T[3][3];
-    r2l_fold_T(P, T);
-    double s = 0;
-    for (int j = 0; j < 3; ++j) s += T[k][j] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
-    out[idx] = (float)s;
+    // (no lane-private T[3][3]: a dynamically indexed array would live in scratch memory)
+    out[idx] = (float)r2l_fold_A_one(P, k, par, t);
   } else if (idx < o_blur) {
     out[idx] = P[R2L_P_SHARPEN + idx - o_sharp];
   } else if (idx < o_m2) {
@@ -257,17 +299,29 @@ enum {
 
 // Unfold the reduced sums into the gradient of trainable parameter `o` (index into the packed block);
 // float64 throughout, one lane per parameter.
-R2L_HD float r2l_unfold_one(const float* P, const double* S, int o) {
+// gT[k][j] = sum_{par,t} GA[k][par][t] * debayer.weight[j][chan(par,t)][t]  (shared by the white-balance
+// and colour-matrix gradients)
+R2L_HD double r2l_unfold_gT(const float* P, const double* S, int k, int j) {
   const double* b1 = S;
   const double* b2 = S + R2L_B1_NACC;
-  double T[3][3], M1[3][3], ccm[3][3], wb[3];
-  for (int c = 0; c < 3; ++c) wb[c] = P[R2L_P_WHITE_BALANCE + c];
-  for (int k = 0; k < 3; ++k)
-    for (int c = 0; c < 3; ++c) {
-      M1[k][c] = P[R2L_P_M_RGB2YUV + k * 3 + c];
-      ccm[k][c] = P[R2L_P_CCM + k * 3 + c];
+  const double* GA = (k == 0) ? (b2 + R2L_B2_GAY) : (k == 1 ? b1 + R2L_B1_GAU : b1 + R2L_B1_GAV);
+  double s = 0;
+  for (int par = 0; par < 4; ++par)
+    for (int t = 0; t < 9; ++t) {
+      const int c = r2l_site_channel((par >> 1) + t / 3 + 1, (par & 1) + t % 3 + 1);
+      s += GA[par * 9 + t] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
     }
-  r2l_fold_T(P, T);
+  return s;
+}
+// Unfold the reduced sums into the gradient of trainable parameter `o` (index into the packed block);
+// float64 throughout, one lane per parameter.  TG = T[9] (r2l_fold_T_one), gT[9] (r2l_unfold_gT) and the
+// folded stencils A[3][4][9] (r2l_fold_A_one), computed once per launch by 126 lanes.  P, S and TG are read in place (they sit in LDS): no lane-private
+// arrays, which dynamic indexing would send to scratch memory (measured: 17 us for this 132-lane step).
+R2L_HD float r2l_unfold_one(const float* P, const double* S, int o, const double* TG) {
+  const double* b1 = S;
+  const double* b2 = S + R2L_B1_NACC;
+  const double* T = TG;
+  const double* gT = TG + 9;
   if (o >= R2L_P_SHARPEN && o < R2L_P_BLUR) return (float)b2[R2L_B2_GSHARP + o - R2L_P_SHARPEN];
   if (o >= R2L_P_BLUR && o < R2L_P_NTRAIN) return (float)b1[R2L_B1_GBLUR + o - R2L_P_BLUR];
   if (o == R2L_P_GAMMA) {
@@ -281,7 +335,7 @@ R2L_HD float r2l_unfold_one(const float* P, const double* S, int o) {
     for (int k = 0; k < 3; ++k) {
       const double* GA = (k == 0) ? (b2 + R2L_B2_GAY) : (k == 1 ? b1 + R2L_B1_GAU : b1 + R2L_B1_GAV);
       for (int par = 0; par < 4; ++par)
-        if (r2l_site_channel((par >> 1) + dy + 2, (par & 1) + dx + 2) == c) g += T[k][j] * GA[par * 9 + t];
+        if (r2l_site_channel((par >> 1) + dy + 2, (par & 1) + dx + 2) == c) g += T[k * 3 + j] * GA[par * 9 + t];
     }
     return (float)g;
   }
@@ -294,37 +348,23 @@ R2L_HD float r2l_unfold_one(const float* P, const double* S, int o) {
           const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
           const int site = ((py + dy + 2) & 1) * 2 + ((px + dx + 2) & 1);
           if (site != o) continue;
-          const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
-          double a = 0;
-          for (int j = 0; j < 3; ++j) a += T[k][j] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
-          g -= a * SS[par];
+          g -= TG[18 + (k * 4 + par) * 9 + t] * SS[par];  // folded A[k][par][t], float64
         }
     }
     return (float)g;
   }
-  // white balance / colour matrix: through gT[k][c] = sum_{par,t} GA[k][par][t] * deb[c][chan(par,t)][t]
-  double gT[3][3];
-  for (int k = 0; k < 3; ++k) {
-    const double* GA = (k == 0) ? (b2 + R2L_B2_GAY) : (k == 1 ? b1 + R2L_B1_GAU : b1 + R2L_B1_GAV);
-    for (int j = 0; j < 3; ++j) {
-      double s = 0;
-      for (int par = 0; par < 4; ++par)
-        for (int t = 0; t < 9; ++t) {
-          const int c = r2l_site_channel((par >> 1) + t / 3 + 1, (par & 1) + t % 3 + 1);
-          s += GA[par * 9 + t] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
-        }
-      gT[k][j] = s;
-    }
-  }
+  // white balance / colour matrix: through gT
   if (o < R2L_P_CCM) {
     const int c = o - R2L_P_WHITE_BALANCE;
     double g = 0;
     for (int k = 0; k < 3; ++k)
-      for (int j = 0; j < 3; ++j) g += gT[k][c] * M1[k][j] * ccm[j][c];
+      for (int j = 0; j < 3; ++j)
+        g += gT[k * 3 + c] * (double)P[R2L_P_M_RGB2YUV + k * 3 + j] * (double)P[R2L_P_CCM + j * 3 + c];
     return (float)g;
   }
   const int j = (o - R2L_P_CCM) / 3, c = (o - R2L_P_CCM) % 3;
   double g = 0;
-  for (int k = 0; k < 3; ++k) g += gT[k][c] * M1[k][j] * wb[c];
+  for (int k = 0; k < 3; ++k)
+    g += gT[k * 3 + c] * (double)P[R2L_P_M_RGB2YUV + k * 3 + j] * (double)P[R2L_P_WHITE_BALANCE + c];
   return (float)g;
 }

@@ -460,6 +460,106 @@ R2L_HD void r2l_chroma_row(const float vw[3][6], R2LFoldedRef F, float u[4], flo
   }
 }
 
+// ---- final reduction inside the producing launch ------------------------------------------------------
+// The per-workgroup partials are summed in a fixed two-level order by whichever workgroups arrive last:
+// the last of every 16 consecutive workgroups adds its group's 16 partials per slot (float64) into a group
+// partial, and the last group to finish adds the <= 64 group partials.  The result does not depend on
+// arrival order (bitwise reproducible), no extra launch is needed, and the long part of the work (level 1)
+// overlaps with workgroups that are still computing.  counters[1 + g] / counters[0] count arrivals; they are
+// zero before the launch (the fold kernel initialises a fresh workspace) and are reset by the last arriver.
+#ifndef R2L_MAX_BLOCKS
+#define R2L_MAX_BLOCKS 1024
+#endif
+#define R2L_TREE_GROUP 16
+#define R2L_MAX_GROUPS (R2L_MAX_BLOCKS / R2L_TREE_GROUP)
+struct R2LTree {
+  const float* partial;   // [split][nblk]
+  const float* partial2;  // [nslots - split][nblk] (slots >= split), may be null when split == nslots
+  double* gpartial;       // [nslots][R2L_MAX_GROUPS]
+  unsigned* counters;     // [1 + R2L_MAX_GROUPS]; null: no in-kernel reduction
+  int split;
+};
+// Returns true (uniformly over the workgroup) in the ONE workgroup that arrives last; out[0..NSLOTS) then
+// holds the totals.  `out` may be LDS or global memory; lds4: 4 floats of LDS scratch for the tickets;
+// scratch: LDS staging area of scratch_n doubles (>= NSLOTS * R2L_TREE_GROUP floats and >= R2L_MAX_GROUPS
+// doubles).  The coherent loads are spread over all lanes and staged through LDS, so that their latency is
+// paid once per level rather than once per addend; the additions then run in a fixed order from LDS.
+template <int NSLOTS>
+R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* lds4, double* out, double* scratch,
+                                 int scratch_n) {
+  unsigned* lu = (unsigned*)lds4;
+  float* sf = (float*)scratch;
+  const int g = bid / R2L_TREE_GROUP, ngroups = (nblk + R2L_TREE_GROUP - 1) / R2L_TREE_GROUP;
+  const int g0 = g * R2L_TREE_GROUP;
+  const int gsize = (nblk - g0 < R2L_TREE_GROUP) ? nblk - g0 : R2L_TREE_GROUP;
+  R2L_PHASE_BEGIN
+  if (tid == 0) lu[0] = r2l_ticket(tr.counters + 1 + g);
+  R2L_PHASE_END
+  if (lu[0] + 1 != (unsigned)gsize) return false;
+  R2L_PHASE_BEGIN
+  if (tid == 0) tr.counters[1 + g] = 0;
+  for (int idx = tid; idx < NSLOTS * gsize; idx += R2L_NT) {
+    const int sl = idx / gsize, m = idx - sl * gsize;
+    const float* row = (sl < tr.split) ? tr.partial + (size_t)sl * nblk : tr.partial2 + (size_t)(sl - tr.split) * nblk;
+    sf[idx] = r2l_load_coherent(row + g0 + m);
+  }
+  R2L_PHASE_END
+  R2L_PHASE_BEGIN
+  for (int sl = tid; sl < NSLOTS; sl += R2L_NT) {
+    double acc = 0.0;
+    for (int m = 0; m < gsize; ++m) acc += (double)sf[sl * gsize + m];
+    r2l_store_coherent(tr.gpartial + (size_t)sl * R2L_MAX_GROUPS + g, acc);
+  }
+  R2L_STORES_DONE();
+  R2L_PHASE_END
+  R2L_PHASE_BEGIN
+  if (tid == 0) lu[1] = r2l_ticket(tr.counters);
+  R2L_PHASE_END
+  if (lu[1] + 1 != (unsigned)ngroups) return false;
+  const int chunk = scratch_n / ngroups;  // slots per pass
+  for (int s0 = 0; s0 < NSLOTS; s0 += chunk) {
+    const int cnt = (NSLOTS - s0 < chunk) ? NSLOTS - s0 : chunk;
+    R2L_PHASE_BEGIN
+    if (tid == 0) tr.counters[0] = 0;
+    for (int idx = tid; idx < cnt * ngroups; idx += R2L_NT) {
+      const int sl = idx / ngroups, q = idx - sl * ngroups;
+      scratch[idx] = r2l_load_coherent(tr.gpartial + (size_t)(s0 + sl) * R2L_MAX_GROUPS + q);
+    }
+    R2L_PHASE_END
+    R2L_PHASE_BEGIN
+    for (int sl = tid; sl < cnt; sl += R2L_NT) {
+      double acc = 0.0;
+      for (int q = 0; q < ngroups; ++q) acc += scratch[sl * ngroups + q];
+      out[s0 + sl] = acc;
+    }
+    R2L_PHASE_END
+  }
+  return true;
+}
+
+// sums (float64 in LDS) -> the 132 parameter gradients; tg (R2L_UNFOLD_TG doubles) and pl (R2L_P_COUNT floats)
+// are LDS
+#define R2L_UNFOLD_TG 126
+R2L_BLOCKFN void r2l_unfold_phases(const float* params, const double* sums, double* tg, float* pl,
+                                   float* grad_params) {
+  R2L_PHASE_BEGIN
+  if (tid < R2L_P_COUNT) pl[tid] = params[tid];
+  R2L_PHASE_END
+  R2L_PHASE_BEGIN
+  if (tid < 9) {
+    tg[tid] = r2l_fold_T_one(pl, tid / 3, tid % 3);
+  } else if (tid >= 64 && tid < 73) {
+    tg[9 + tid - 64] = r2l_unfold_gT(pl, sums, (tid - 64) / 3, (tid - 64) % 3);
+  } else if (tid >= 128 && tid < 128 + 108) {
+    const int e = tid - 128;
+    tg[18 + e] = r2l_fold_A_one(pl, e / 36, (e % 36) / 9, e % 9);
+  }
+  R2L_PHASE_END
+  R2L_PHASE_BEGIN
+  if (tid < R2L_P_NTRAIN) grad_params[tid] = r2l_unfold_one(pl, sums, tid, tg);
+  R2L_PHASE_END
+}
+
 // packed forms: pair p = columns (2p, 2p+1) of the micro-tile row
 R2L_HD void r2l_blur_row2(const float yw[5][8], R2LFoldedRef F, r2l_p2 ypp[2]) {
   ypp[0] = ypp[1] = r2l_splat2(0.f);
@@ -502,6 +602,8 @@ struct R2LFwdArgs {
   float* stat_partial;  // [6][nblk] or null
   int B, H, W;
   float* debug;  // diagnostic builds
+  R2LTree tree;  // in-kernel final reduction of the statistics -> stats_out[0..6), stats_out[6] = B*H*W
+  double* stats_out;
 };
 
 struct R2LFwdRegs {
@@ -633,10 +735,12 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
       float s_ = 0.f;                                                                       \
       R2L_PRAGMA_UNROLL                                                                     \
       for (int j_ = 0; j_ < 16; ++j_) s_ += (lds)[32 * (R2L_NT + 1) + tid * 16 + j_];       \
-      (partial)[(size_t)(base_ + tid) * (nblk) + (bid)] = s_;                               \
+      r2l_store_coherent(&(partial)[(size_t)(base_ + tid) * (nblk) + (bid)], s_);           \
     }                                                                                       \
+    R2L_STORES_DONE(); /* a later workgroup may finish the reduction inside this launch */  \
     R2L_PHASE_END                                                                           \
   }
+
 
 template <class G, bool ADD, bool MAYBE_RAGGED>
 R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* lds) {
@@ -692,6 +796,12 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   R2L_STAMP_FLUSH(a.debug, bid)
   if (a.stat_partial) {
     R2L_BLOCK_REDUCE_F(6, R2L_ACC_FWD, regs, lds, a.stat_partial, bid, nblk)
+    if (a.tree.counters && r2l_tree_finish<6>(a.tree, bid, nblk, lds, a.stats_out, (double*)(lds + 512),
+                                              (R2L_RED_FLOATS - 512) / 2)) {
+      R2L_PHASE_BEGIN
+      if (tid == 0) a.stats_out[6] = (double)a.B * (double)a.H * (double)a.W;
+      R2L_PHASE_END
+    }
   }
 }
 
@@ -711,28 +821,30 @@ struct R2LBwd1Args {
   float* debug;
 };
 
-// per-thread accumulators of B1: a thread only sees pixels of ONE row parity, so it keeps the two column
-// parities of its own row parity (18 of the 36 slots of each parity-indexed table)
-enum { R2L_L1_GBLUR = 0, R2L_L1_GAU = 25, R2L_L1_GAV = 43, R2L_L1_SU = 61, R2L_L1_SV = 63,
-       R2L_L1_GGAM = 65, R2L_L1_NACC = 66 };
+// per-thread accumulators of B1, as pairs: element h of a pair belongs to the pixels in the even (h = 0) or
+// odd (h = 1) columns of the micro-tile.  A thread only sees pixels of ONE row parity, so for the
+// parity-indexed tables the pair IS the two column parities of its row parity; for the other sums the halves
+// are added when the workgroup reduces.
+enum { R2L_L1_GBLUR = 0, R2L_L1_GAU = 25, R2L_L1_GAV = 34, R2L_L1_SU = 43, R2L_L1_SV = 44,
+       R2L_L1_GGAM = 45, R2L_L1_NACC = 46 };
 struct R2LBwd1Regs {
-  float acc[R2L_L1_NACC];
+  r2l_p2 acc[R2L_L1_NACC];
   int py;
 };
 // value of global slot i (layout R2L_B1_*) held by a thread of row parity py
 R2L_HD float r2l_b1_slot(const R2LBwd1Regs& r, int i) {
-  if (i < R2L_B1_GAU) return r.acc[R2L_L1_GBLUR + i];
+  if (i < R2L_B1_GAU) return r.acc[R2L_L1_GBLUR + i][0] + r.acc[R2L_L1_GBLUR + i][1];
   if (i < R2L_B1_SU) {
     const int tbl = (i - R2L_B1_GAU) / 36, k = (i - R2L_B1_GAU) % 36, par = k / 9, t = k % 9;
-    const float v = r.acc[(tbl ? R2L_L1_GAV : R2L_L1_GAU) + (par & 1) * 9 + t];
-    return ((par >> 1) == r.py) ? v : 0.f;
+    const r2l_p2 v = r.acc[(tbl ? R2L_L1_GAV : R2L_L1_GAU) + t];
+    return ((par >> 1) == r.py) ? ((par & 1) ? v[1] : v[0]) : 0.f;
   }
   if (i < R2L_B1_GGAM) {
     const int tbl = (i - R2L_B1_SU) / 4, par = (i - R2L_B1_SU) % 4;
-    const float v = r.acc[(tbl ? R2L_L1_SV : R2L_L1_SU) + (par & 1)];
-    return ((par >> 1) == r.py) ? v : 0.f;
+    const r2l_p2 v = r.acc[tbl ? R2L_L1_SV : R2L_L1_SU];
+    return ((par >> 1) == r.py) ? ((par & 1) ? v[1] : v[0]) : 0.f;
   }
-  return r.acc[R2L_L1_GGAM];
+  return r.acc[R2L_L1_GGAM][0] + r.acc[R2L_L1_GGAM][1];
 }
 #define R2L_ACC_B1(regs, i) r2l_b1_slot(R2L_TREG(regs), i)
 
@@ -772,15 +884,20 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
                          unsigned off0, unsigned plane, const float* gb, const R2LGoutPre& gpre, bool second,
                          float* gyb, const R2LBnConsts& bc, R2LBwd1Regs& regs) {
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
-  float yw[5][8], vw[3][6];
-  float ypp[4], u[4], v[4];
-  r2l_rows_yp<G>(YP, tx, frow, yw);
-  r2l_blur_row(yw, F, ypp);
-  r2l_rows_3x6<G>(V, tx, frow, vw);
-  r2l_chroma_row<PY>(vw, F, u, v);
+  r2l_p2 ypp[2], u[2], v[2];
+  {
+    float yw[5][8];
+    r2l_rows_yp<G>(YP, tx, frow, yw);
+    r2l_blur_row2(yw, F, ypp);
+  }
+  {
+    float vw[3][6];
+    r2l_rows_3x6<G>(V, tx, frow, vw);
+    r2l_chroma_row2<PY>(vw, F, u, v);
+  }
   const bool vec_ok = !RAGGED || (((a.W & 3) == 0) && (gx0 + 3 < a.W));
-  float grgb[3][4];
-  float ggam = 0.f;
+  r2l_p2 grgb[3][2];
+  r2l_p2 ggam = r2l_splat2(0.f);
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
     const unsigned off = (unsigned)k * plane + off0;
@@ -802,82 +919,92 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
         if (gx0 + c < a.W) g[c] = gb[off + c];
     }
     R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) {
-      const bool valid = !RAGGED || (gx0 + c < a.W);
-      float rgb = F.M2[k * 3] * ypp[c];
-      rgb = fmaf(F.M2[k * 3 + 1], u[c], rgb);
-      rgb = fmaf(F.M2[k * 3 + 2], v[c], rgb);
-      const float xc = fminf(fmaxf(rgb, 1e-5f), 1.0f);
-      const float lg = r2l_log2(xc);
-      const float og = r2l_exp2(lg * F.inv_gamma);
-      float x = og;
-      if (ADD) x += valid ? a.additive[off + c] : 0.f;
-      const float xhat = (x - bc.mean[k]) * bc.istd[k];
+    for (int p = 0; p < 2; ++p) {
+      const bool valid0 = !RAGGED || (gx0 + 2 * p < a.W), valid1 = !RAGGED || (gx0 + 2 * p + 1 < a.W);
+      r2l_p2 rgb = r2l_pmul(r2l_splat2(F.M2[k * 3]), ypp[p]);
+      rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 1]), u[p], rgb);
+      rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 2]), v[p], rgb);
+      const r2l_p2 xc = r2l_mk2(fminf(fmaxf(rgb[0], 1e-5f), 1.0f), fminf(fmaxf(rgb[1], 1e-5f), 1.0f));
+      const r2l_p2 lg = r2l_mk2(r2l_log2(xc[0]), r2l_log2(xc[1]));
+      const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));
+      const r2l_p2 og = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
+      r2l_p2 x = og;
+      if (ADD) x = r2l_padd(x, r2l_mk2(valid0 ? a.additive[off + 2 * p] : 0.f, valid1 ? a.additive[off + 2 * p + 1] : 0.f));
+      const r2l_p2 xhat = r2l_pmul(r2l_padd(x, r2l_splat2(-bc.mean[k])), r2l_splat2(bc.istd[k]));
       // BatchNorm2d backward, train mode: istd * (g - mean(g) - xhat * mean(g*xhat)); in eval mode
       // mg = mgx = 0 and only the scaling remains; without BatchNorm mean = 0, istd = 1 too, which
       // leaves g unchanged (exactly)
-      float gx = bc.istd[k] * (g[c] - bc.mg[k] - xhat * bc.mgx[k]);
-      if (RAGGED) gx = valid ? gx : 0.f;
-      ggam = fmaf(gx * og, lg, ggam);
-      const float gc = gx * og * F.inv_gamma * r2l_rcp(xc);
-      grgb[k][c] = (rgb >= 1e-5f && rgb <= 1.0f) ? gc : 0.f;  // torch.clip backward
+      r2l_p2 gx = r2l_padd(r2l_mk2(g[2 * p], g[2 * p + 1]), r2l_splat2(-bc.mg[k]));
+      gx = r2l_pmul(r2l_splat2(bc.istd[k]), r2l_pfma(xhat, r2l_splat2(-bc.mgx[k]), gx));
+      if (RAGGED) gx = r2l_mk2(valid0 ? gx[0] : 0.f, valid1 ? gx[1] : 0.f);
+      const r2l_p2 gxo = r2l_pmul(gx, og);
+      ggam = r2l_pfma(gxo, lg, ggam);
+      const r2l_p2 gc = r2l_pmul(r2l_pmul(gxo, r2l_splat2(F.inv_gamma)), r2l_mk2(r2l_rcp(xc[0]), r2l_rcp(xc[1])));
+      grgb[k][p] = r2l_mk2((rgb[0] >= 1e-5f && rgb[0] <= 1.0f) ? gc[0] : 0.f,       // torch.clip backward
+                           (rgb[1] >= 1e-5f && rgb[1] <= 1.0f) ? gc[1] : 0.f);
     }
   }
-  float gy2[4], gu[4], gv[4];  // d loss / d (Y'', U, V)
+  r2l_p2 gy2[2], gu[2], gv[2];  // d loss / d (Y'', U, V)
   R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) {
-    gy2[c] = F.M2[0] * grgb[0][c] + F.M2[3] * grgb[1][c] + F.M2[6] * grgb[2][c];
-    gu[c] = F.M2[1] * grgb[0][c] + F.M2[4] * grgb[1][c] + F.M2[7] * grgb[2][c];
-    gv[c] = F.M2[2] * grgb[0][c] + F.M2[5] * grgb[1][c] + F.M2[8] * grgb[2][c];
+  for (int p = 0; p < 2; ++p) {
+    gy2[p] = r2l_pfma(r2l_splat2(F.M2[6]), grgb[2][p],
+                      r2l_pfma(r2l_splat2(F.M2[3]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[0]), grgb[0][p])));
+    gu[p] = r2l_pfma(r2l_splat2(F.M2[7]), grgb[2][p],
+                     r2l_pfma(r2l_splat2(F.M2[4]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[1]), grgb[0][p])));
+    gv[p] = r2l_pfma(r2l_splat2(F.M2[8]), grgb[2][p],
+                     r2l_pfma(r2l_splat2(F.M2[5]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[2]), grgb[0][p])));
   }
   if (vec_ok) {
     r2l_f4 st;
-    st.x = gy2[0];
-    st.y = gy2[1];
-    st.z = gy2[2];
-    st.w = gy2[3];
+    st.x = gy2[0][0];
+    st.y = gy2[0][1];
+    st.z = gy2[1][0];
+    st.w = gy2[1][1];
     *(r2l_f4*)(gyb + off0) = st;
   } else {
     R2L_PRAGMA_UNROLL
     for (int c = 0; c < 4; ++c)
-      if (gx0 + c < a.W) gyb[off0 + c] = gy2[c];
+      if (gx0 + c < a.W) gyb[off0 + c] = gy2[c >> 1][c & 1];
   }
   R2L_SCHED_FENCE();
-  regs.acc[R2L_L1_GGAM] += ggam;
+  regs.acc[R2L_L1_GGAM] = r2l_padd(regs.acc[R2L_L1_GGAM], ggam);
 #ifndef R2L_EXP_NO_GBLUR
-  // d/d gaussian_blur.weight[i][j] = sum_p gY''(p) * YP_ext(p + (i-2, j-2))
+  // d/d gaussian_blur.weight[i][j] = sum_p gY''(p) * YP_ext(p + (i-2, j-2)).  The two windows are read from
+  // LDS a second time here rather than kept in 58 registers across the pointwise part (VGPR-bound kernel).
+  float yw[5][8];
+  r2l_rows_yp<G>(YP, tx, frow, yw);
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 5; ++i)
     R2L_PRAGMA_UNROLL
   for (int j = 0; j < 5; ++j) {
-    float s = regs.acc[R2L_L1_GBLUR + i * 5 + j];
+    r2l_p2 s = regs.acc[R2L_L1_GBLUR + i * 5 + j];
     R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) s = fmaf(gy2[c], yw[i][c + j], s);
+    for (int p = 0; p < 2; ++p) s = r2l_pfma(gy2[p], r2l_mk2(yw[i][2 * p + j], yw[i][2 * p + j + 1]), s);
     regs.acc[R2L_L1_GBLUR + i * 5 + j] = s;
   }
 #endif
 #ifndef R2L_EXP_NO_GA
   R2L_SCHED_FENCE();
-  // folded chroma stencils: GA[par][t] = sum_{p of parity par} gU(p) * v_ext(p+t)
+  // folded chroma stencils: GA[par][t] = sum_{p of parity par} gU(p) * v_ext(p+t); pair half = column parity
+  float vw[3][6];
+  r2l_rows_3x6<G>(V, tx, frow, vw);
   R2L_PRAGMA_UNROLL
-  for (int px = 0; px < 2; ++px) {
+  for (int i = 0; i < 3; ++i)
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 3; ++i)
-      R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 3; ++j) {
-      float su = regs.acc[R2L_L1_GAU + px * 9 + i * 3 + j];
-      float sv = regs.acc[R2L_L1_GAV + px * 9 + i * 3 + j];
-      R2L_PRAGMA_UNROLL
-      for (int c = px; c < 4; c += 2) {
-        su = fmaf(gu[c], vw[i][c + j], su);
-        sv = fmaf(gv[c], vw[i][c + j], sv);
-      }
-      regs.acc[R2L_L1_GAU + px * 9 + i * 3 + j] = su;
-      regs.acc[R2L_L1_GAV + px * 9 + i * 3 + j] = sv;
+  for (int j = 0; j < 3; ++j) {
+    r2l_p2 su = regs.acc[R2L_L1_GAU + i * 3 + j];
+    r2l_p2 sv = regs.acc[R2L_L1_GAV + i * 3 + j];
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) {
+      const r2l_p2 x = r2l_mk2(vw[i][2 * p + j], vw[i][2 * p + j + 1]);
+      su = r2l_pfma(gu[p], x, su);
+      sv = r2l_pfma(gv[p], x, sv);
     }
-    regs.acc[R2L_L1_SU + px] += gu[px] + gu[px + 2];
-    regs.acc[R2L_L1_SV + px] += gv[px] + gv[px + 2];
+    regs.acc[R2L_L1_GAU + i * 3 + j] = su;
+    regs.acc[R2L_L1_GAV + i * 3 + j] = sv;
   }
+  regs.acc[R2L_L1_SU] = r2l_padd(regs.acc[R2L_L1_SU], r2l_padd(gu[0], gu[1]));
+  regs.acc[R2L_L1_SV] = r2l_padd(regs.acc[R2L_L1_SV], r2l_padd(gv[0], gv[1]));
 #endif
 }
 
@@ -927,7 +1054,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < R2L_L1_NACC; ++i) R2L_TREG(regs).acc[i] = 0.f;
+  for (int i = 0; i < R2L_L1_NACC; ++i) R2L_TREG(regs).acc[i] = r2l_splat2(0.f);
   {
     int tx_, row_;
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
@@ -984,6 +1111,9 @@ struct R2LBwd2Args {
   float* partial;     // [R2L_B2_NACC][nblk]
   int B, H, W;
   float* debug;
+  R2LTree tree;         // in-kernel final reduction of B1's and B2's partials + unfold -> grad_params
+  const float* params;  // packed parameters (for the unfold)
+  float* grad_params;   // [R2L_P_NTRAIN]
 };
 
 enum { R2L_L2_GSHARP = 0, R2L_L2_GAY = 9, R2L_L2_SY = 27, R2L_L2_NACC = 29 };
@@ -1224,6 +1354,22 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     t = tn;
     have = haven;
   }
-  R2L_STAMP_FLUSH(a.debug, bid)
   R2L_BLOCK_REDUCE_F(R2L_B2_NACC, R2L_ACC_B2, regs, lds, a.partial, bid, nblk)
+  R2L_STAMP(4)
+  R2L_STAMP_FLUSH(a.debug, bid)
+  if (a.tree.counters) {
+    // LDS scratch of the epilogue: 4 floats of tickets, then float64 sums[R2L_NSUMS], T[9] + gT[9], and the
+    // packed parameters as floats (all below float 512, where the staging area of the reduction starts)
+    double* sums = (double*)(lds + 4);
+    double* tg = sums + R2L_NSUMS;
+    float* pl = (float*)(tg + R2L_UNFOLD_TG);
+    const bool last_ = r2l_tree_finish<R2L_NSUMS>(a.tree, bid, nblk, lds, sums, (double*)(lds + 512),
+                                                  (R2L_RED_FLOATS - 512) / 2);
+    R2L_STAMP(5)
+    R2L_STAMP_FLUSH(a.debug, bid)
+    if (!last_) return;
+    r2l_unfold_phases(a.params, sums, tg, pl, a.grad_params);
+    R2L_STAMP(6)
+    R2L_STAMP_FLUSH(a.debug, bid)
+  }
 }

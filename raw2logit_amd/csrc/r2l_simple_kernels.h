@@ -7,6 +7,7 @@
 struct R2LFoldArgs {
   const float* params;
   R2LFolded* F;
+  unsigned* counters;  // arrival counters of the in-kernel reductions: a fresh workspace starts at zero
 };
 R2L_BLOCKFN void r2l_fold_block(const R2LFoldArgs& a, int bid, int nblk, float* lds) {
   (void)bid;
@@ -14,6 +15,7 @@ R2L_BLOCKFN void r2l_fold_block(const R2LFoldArgs& a, int bid, int nblk, float* 
   (void)lds;
   R2L_PHASE_BEGIN
   if (tid < R2L_FOLDED_NFLOATS) r2l_fold_one(a.params, a.F, tid);
+  if (a.counters && tid < 1 + R2L_MAX_GROUPS) a.counters[tid] = 0;
   R2L_PHASE_END
 }
 
@@ -26,10 +28,13 @@ struct R2LUnfoldArgs {
 R2L_BLOCKFN void r2l_unfold_block(const R2LUnfoldArgs& a, int bid, int nblk, float* lds) {
   (void)bid;
   (void)nblk;
-  (void)lds;
+  double* sums = (double*)(lds + 4);
+  double* tg = sums + R2L_NSUMS;
+  float* pl = (float*)(tg + R2L_UNFOLD_TG);
   R2L_PHASE_BEGIN
-  if (tid < R2L_P_NTRAIN) a.grad_params[tid] = r2l_unfold_one(a.params, a.sums, tid) * a.scale;
+  if (tid < R2L_NSUMS) sums[tid] = a.sums[tid] * (double)a.scale;
   R2L_PHASE_END
+  r2l_unfold_phases(a.params, sums, tg, pl, a.grad_params);
 }
 
 // ---- BatchNorm bookkeeping on the device (no host round trip) ---------------------------------------
@@ -43,7 +48,8 @@ struct R2LBnFinalizeArgs {
   double* moments;
   float* running_mean;
   float* running_var;
-  double eps, momentum;
+  double eps, momentum;  // momentum < 0: cumulative moving average, 1 / num_batches_tracked (after its increment)
+  long long* num_batches_tracked;  // optional, incremented by one
 };
 R2L_BLOCKFN void r2l_bn_finalize_block(const R2LBnFinalizeArgs& a, int bid, int nblk, float* lds) {
   (void)bid;
@@ -51,6 +57,8 @@ R2L_BLOCKFN void r2l_bn_finalize_block(const R2LBnFinalizeArgs& a, int bid, int 
   (void)lds;
   R2L_PHASE_BEGIN
   if (tid < 3) {
+    const long long nbt = a.num_batches_tracked ? *a.num_batches_tracked + 1 : 1;
+    const double mom = a.momentum < 0.0 ? 1.0 / (double)nbt : a.momentum;
     const double n = a.tot[6];
     const double m1 = a.tot[tid] / n;
     double var = a.tot[3 + tid] / n - m1 * m1;
@@ -64,10 +72,13 @@ R2L_BLOCKFN void r2l_bn_finalize_block(const R2LBnFinalizeArgs& a, int bid, int 
     }
     if (a.running_mean) {
       const double unb = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
-      a.running_mean[tid] = (float)((1.0 - a.momentum) * (double)a.running_mean[tid] + a.momentum * mean);
-      a.running_var[tid] = (float)((1.0 - a.momentum) * (double)a.running_var[tid] + a.momentum * unb);
+      a.running_mean[tid] = (float)((1.0 - mom) * (double)a.running_mean[tid] + mom * mean);
+      a.running_var[tid] = (float)((1.0 - mom) * (double)a.running_var[tid] + mom * unb);
     }
   }
+  R2L_PHASE_END
+  R2L_PHASE_BEGIN  // after every lane has read the counter
+  if (tid == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
   R2L_PHASE_END
 }
 
@@ -80,6 +91,9 @@ struct R2LReduceRowsArgs {
   int n;
   double scale;  // applied to the result
   float* fsums;  // optional float32 copy of the result
+  double* count_out;  // optional: receives `count` (workgroup 0)
+  double count;
+  const double* divide_by;  // optional: fsums = result / *divide_by instead of a plain copy
 };
 R2L_BLOCKFN void r2l_reduce_rows_block(const R2LReduceRowsArgs& a, int bid, int nblk, float* lds) {
   (void)nblk;
@@ -101,7 +115,8 @@ R2L_BLOCKFN void r2l_reduce_rows_block(const R2LReduceRowsArgs& a, int bid, int 
     double t = 0.0;
     for (int j = 0; j < 32; ++j) t += dl[R2L_NT + j];
     if (a.sums) a.sums[bid] = t * a.scale;
-    if (a.fsums) a.fsums[bid] = (float)(t * a.scale);
+    if (a.fsums) a.fsums[bid] = (float)(a.divide_by ? t * a.scale / *a.divide_by : t * a.scale);
+    if (a.count_out && bid == 0) *a.count_out = a.count;
   }
   R2L_PHASE_END
 }
@@ -112,6 +127,10 @@ struct R2LBnReduceArgs {
   const float* out;
   float* partial;  // [6][nblk]
   int B, H, W;
+  R2LTree tree;          // in-kernel final reduction -> sums[6]
+  double* sums;
+  const double* totals;  // optional: totals[6] = pixel count n of the global batch
+  float* bn_bwd;         // optional (needs totals): mean_c(g)[3], mean_c(g*xhat)[3] = sums / n as float32
 };
 struct R2LAcc6 {
   float acc[6];
@@ -158,6 +177,16 @@ R2L_BLOCKFN void r2l_bn_reduce_block(const R2LBnReduceArgs& a, int bid, int nblk
     R2L_PHASE_END
   }
   R2L_BLOCK_REDUCE(6, regs, lds, a.partial, bid, nblk)
+  if (a.tree.counters) {
+    double* sl = (double*)(lds + 4);
+    if (!r2l_tree_finish<6>(a.tree, bid, nblk, lds, sl, (double*)(lds + 512), (R2L_RED_FLOATS - 512) / 2)) return;
+    R2L_PHASE_BEGIN
+    if (tid < 6) {
+      a.sums[tid] = sl[tid];
+      if (a.bn_bwd && a.totals) a.bn_bwd[tid] = (float)(sl[tid] / a.totals[6]);
+    }
+    R2L_PHASE_END
+  }
 }
 
 // ---- gradient of the additive layer (pipeline_torch.py:213): sum over the batch ------------------

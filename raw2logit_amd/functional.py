@@ -91,19 +91,33 @@ PARAM_LAYOUT = (('black_level', 0, 4), ('white_balance', 4, 3), ('colour_correct
                 ('gaussian_blur.weight', 107, 25))
 
 
-def gather_totals(stats, n_local, group=None):
-    """(sum(x-.5)[3], sum((x-.5)^2)[3]) of this rank -> the same sums over all ranks + pixel count.
+def gather_totals(stats7, group=None):
+    """(sum(x-.5)[3], sum((x-.5)^2)[3], pixel count) of this rank -> the same sums over all ranks.
 
     With several ranks the 7-vectors are all-gathered over RCCL/xGMI and added in rank order, so every rank
     gets bit-identical statistics, equal to the single-GPU statistics of the global batch."""
-    vec = torch.empty(7, dtype=torch.float64, device=stats.device)
-    vec[:6] = stats
-    vec[6] = float(n_local)
     if _group_size(group) > 1:
-        gathered = [torch.empty_like(vec) for _ in range(dist.get_world_size(group))]
-        dist.all_gather(gathered, vec, group=group)
-        vec = torch.stack(gathered, 0).sum(0)
-    return vec
+        gathered = [torch.empty_like(stats7) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(gathered, stats7, group=group)
+        return torch.stack(gathered, 0).sum(0)
+    return stats7
+
+
+def bn_finalize(lib, stream, totals, bn_module, eps, momentum, want_moments=True):
+    """totals -> (mean, istd) float32[6] (+ moments float64[6]); updates the module's running statistics and
+    num_batches_tracked on the device the way nn.BatchNorm2d does in train mode."""
+    dev = totals.device
+    bn = torch.empty(6, dtype=torch.float32, device=dev)
+    moments = torch.empty(6, dtype=torch.float64, device=dev) if want_moments else None
+    rm = rv = nbt = None
+    if bn_module is not None and bn_module.track_running_stats and bn_module.running_mean is not None:
+        rm, rv, nbt = bn_module.running_mean, bn_module.running_var, bn_module.num_batches_tracked
+        if rm.device != dev or nbt.dtype != torch.int64:
+            raise RuntimeError('BatchNorm buffers must live on the device of the frames')
+    lib.check(lib.r2l_bn_finalize(ptr(totals), ptr(bn), ptr(moments), ptr(rm), ptr(rv), ptr(nbt), float(eps),
+                                  float(momentum) if momentum is not None else -1.0, stream),
+              'r2l_bn_finalize')
+    return bn, moments
 
 
 class _IspFused(torch.autograd.Function):
@@ -130,26 +144,17 @@ class _IspFused(torch.autograd.Function):
                                    f'frames of {H}x{W}')      # same failure the reference has (:213)
         ws, nws = _workspace(lib, raw, B, H, W)
         dev = raw.device
-        bn = None
-        moments = torch.zeros(6, dtype=torch.float64, device=dev)
+        bn = moments = None
         folded = 0
+        ctx.totals = None
         if bn_mode == BN_TRAIN:
-            stats = torch.empty(6, dtype=torch.float64, device=dev)
+            stats = torch.empty(7, dtype=torch.float64, device=dev)
             lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(packed), ptr(additive), None, None, ptr(stats),
                                       ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream),
                       'r2l_isp_fwd(stats)')
             folded = _lib.R2L_F_FOLDED_VALID
-            totals = gather_totals(stats, B * H * W, group)
-            bn = torch.empty(6, dtype=torch.float32, device=dev)
-            rm = rv = None
-            if bn_module is not None and bn_module.track_running_stats and bn_module.running_mean is not None:
-                rm, rv = bn_module.running_mean, bn_module.running_var
-                bn_module.num_batches_tracked.add_(1)
-                if momentum is None:      # cumulative moving average
-                    momentum = 1.0 / float(bn_module.num_batches_tracked)
-            lib.check(lib.r2l_bn_finalize(ptr(totals), ptr(bn), ptr(moments), ptr(rm), ptr(rv), float(eps),
-                                          float(momentum if momentum is not None else 0.0), stream),
-                      'r2l_bn_finalize')
+            totals = gather_totals(stats, group)
+            bn, moments = bn_finalize(lib, stream, totals, bn_module, eps, momentum)
             ctx.totals = totals
         elif bn_mode == BN_EVAL:
             mean = bn_module.running_mean.detach().to(device=dev, dtype=torch.float64)
@@ -164,6 +169,8 @@ class _IspFused(torch.autograd.Function):
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.save_for_backward(raw, packed, additive, bn, out)
         ctx.ws = ws           # holds the folded weights of `packed`: the backward skips re-folding
+        if moments is None:
+            return out, None
         ctx.mark_non_differentiable(moments)
         return out, moments
 
@@ -181,11 +188,13 @@ class _IspFused(torch.autograd.Function):
         bn_bwd = None
         if ctx.bn_mode == BN_TRAIN:
             sums = torch.empty(6, dtype=torch.float64, device=raw.device)
-            lib.check(lib.r2l_bn_bwd_reduce(ptr(gout), ptr(out), ptr(sums), ptr(ws), nws, B, H, W,
-                                            stream), 'r2l_bn_bwd_reduce')
+            bn_bwd = torch.empty(6, dtype=torch.float32, device=raw.device)
+            lib.check(lib.r2l_bn_bwd_reduce(ptr(gout), ptr(out), ptr(ctx.totals), ptr(sums), ptr(bn_bwd),
+                                            ptr(ws), nws, B, H, W, _lib.R2L_F_FOLDED_VALID, stream),
+                      'r2l_bn_bwd_reduce')
             if _group_size(ctx.group) > 1:
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
-            bn_bwd = (sums / ctx.totals[6]).to(torch.float32)
+                bn_bwd = (sums / ctx.totals[6]).to(torch.float32)
         grads = [None] * 7
         if any(ctx.needs_input_grad[1:8]):
             gp = torch.empty(_lib.R2L_P_NTRAIN, dtype=torch.float32, device=raw.device)

@@ -9,7 +9,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import ptr
-from .functional import raw2rgb, _f32c, _group_size, gather_totals
+from .functional import raw2rgb, _f32c, _group_size, gather_totals, bn_finalize
 
 
 def _ws(lib, like):
@@ -199,21 +199,15 @@ class _BatchNorm(torch.autograd.Function):
         B, H, W = _dims(x)
         lib, s = _lib.library_for(x)
         dev = x.device
-        bn = torch.empty(6, dtype=torch.float32, device=dev)
         ctx.training = training
         ctx.group = group
         if training:
             _, sm = _point(lib, s, 7, x, x=x, out=False, sums=True)
-            totals = gather_totals(sm.to(torch.float64), B * H * W, group)
-            rm = rv = None
-            momentum = bn_module.momentum
-            if bn_module.track_running_stats and bn_module.running_mean is not None:
-                rm, rv = bn_module.running_mean, bn_module.running_var
-                bn_module.num_batches_tracked.add_(1)
-                if momentum is None:
-                    momentum = 1.0 / float(bn_module.num_batches_tracked)
-            lib.check(lib.r2l_bn_finalize(ptr(totals), ptr(bn), None, ptr(rm), ptr(rv), float(bn_module.eps),
-                                          float(momentum if momentum is not None else 0.0), s), 'bn_finalize')
+            stats = torch.cat([sm.to(torch.float64),
+                               torch.full((1,), float(B * H * W), dtype=torch.float64, device=dev)])
+            totals = gather_totals(stats, group)
+            bn, _ = bn_finalize(lib, s, totals, bn_module if bn_module.track_running_stats else None,
+                                bn_module.eps, bn_module.momentum, want_moments=False)
             ctx.n_total = totals[6]
         else:
             mean = bn_module.running_mean.detach().to(device=dev, dtype=torch.float64)
@@ -234,7 +228,8 @@ class _BatchNorm(torch.autograd.Function):
             sums = torch.empty(6, dtype=torch.float64, device=g.device)
             n = lib.r2l_isp_workspace_bytes(B, H, W)
             ws = torch.empty(n, dtype=torch.uint8, device=g.device)
-            lib.check(lib.r2l_bn_bwd_reduce(ptr(g), ptr(y), ptr(sums), ptr(ws), n, B, H, W, s), 'bn_bwd_reduce')
+            lib.check(lib.r2l_bn_bwd_reduce(ptr(g), ptr(y), None, ptr(sums), None, ptr(ws), n, B, H, W, 0, s),
+                      'bn_bwd_reduce')
             if _group_size(ctx.group) > 1:
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
             coef = (sums / ctx.n_total).to(torch.float32)

@@ -197,6 +197,45 @@ def check_ragged_and_properties(device, B=2, H=70, W=134):
         assert torch.allclose(yt.double(), (y.double() - mu) * torch.rsqrt(var + 1e-5), rtol=0, atol=2e-5)
 
 
+def check_grid_independence(device, B=40, H=64, W=64):
+    """The in-kernel final reductions (statistics, BatchNorm backward sums, the 155 gradient sums + unfold) are
+    finished by whichever workgroups arrive last; the result must not depend on the number of workgroups
+    (1 group of <= 16, several groups, a ragged last group) nor on the separate-launch fallback that is taken
+    when the two backward kernels run different grids."""
+    import copy
+    import os
+    raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=11, kind='scene')).to(device)
+    cot = torch.from_numpy(np.random.default_rng(12).standard_normal((B, 3, H, W)).astype(np.float32)).to(device)
+    proto = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).to(device).train()
+
+    def run(env):
+        m = copy.deepcopy(proto)
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            y = m(raw)
+            (y * cot).sum().backward()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
+        return y.detach().cpu().numpy(), grads, m.batch_norm.running_var.cpu().numpy().copy(), \
+            int(m.batch_norm.num_batches_tracked)
+    y0, g0, rv0, nbt0 = run({})
+    assert nbt0 == 1
+    for env in ({'R2L_GRID_FWD': '8', 'R2L_GRID_BWD1': '8', 'R2L_GRID_BWD2': '8'},
+                {'R2L_GRID_FWD': '24', 'R2L_GRID_BWD1': '24', 'R2L_GRID_BWD2': '24'},
+                {'R2L_GRID_BWD1': '8', 'R2L_GRID_BWD2': '16'}):
+        y1, g1, rv1, _ = run(env)
+        assert np.abs(y1 - y0).max() <= 2e-5, (env, np.abs(y1 - y0).max())
+        assert np.allclose(rv1, rv0, rtol=1e-5, atol=0)
+        for n in g0:
+            assert np.abs(g1[n] - g0[n]).max() <= 2e-4 * (np.abs(g0[n]).max() + 1e-6), (env, n)
+
+
 def check_harness(golden, device):
     """LitModel-style composition (processor -> classifier -> CE loss -> Adam step, model.py:77-146):
     logits, loss and the ISP parameters after one optimiser step must match what the REFERENCE processor

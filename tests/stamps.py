@@ -24,10 +24,10 @@ for _ in range(3):
     lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(P), None, ptr(bn), ptr(bnb), ptr(gout), ptr(gp), None, ptr(ws), n, B, H, W, 0, s), 'bwd')
 torch.cuda.synchronize()
 al = lambda x: (x + 255) & ~255
-off = al(4 * 267) + al(106 * 1024 * 4) + al(49 * 1024 * 4) + al(8 * 1024 * 4) + al(155 * 8)   # r2l_carve()
+off = al(4 * 267) + al(106 * 1024 * 4) + al(49 * 1024 * 4) + al(8 * 1024 * 4) + al(155 * 8) + al(155 * 64 * 8) + al(4 * 65)   # r2l_carve()
 dbg = ws[off:off + 3 * 8 * 1024 * 4].view(torch.float32).view(3, 1024, 8).double().cpu()
 names = {0: ['store', 'Y', 'YP', 'fill', 'pixels'], 1: ['store', 'Y', 'YP', 'fill', 'pixels'],
-         2: ['store', 'adjblur', 'Y+fold', 'pixels']}
+         2: ['store', 'adjblur', 'Y+fold', 'pixels', 'blockred', 'tree', 'unfold']}
 for k, kn in enumerate(['fwd', 'bwd1', 'bwd2']):
     d = dbg[k]
     nb = int((d.sum(1) > 0).sum())

@@ -39,3 +39,7 @@ TRACK_CASES = [c for c in PARAM_CASES if c['track']]
 @pytest.mark.parametrize('case', TRACK_CASES, ids=[c['name'] for c in TRACK_CASES])
 def test_staged_track_stages(case, golden, emulation):
     pc.check_staged_case(case, golden, 'cpu')
+
+
+def test_reductions_do_not_depend_on_the_grid(emulation):
+    pc.check_grid_independence('cpu')

@@ -122,3 +122,7 @@ TRACK_CASES = [c for c in PARAM_CASES if c['track']]
 @pytest.mark.parametrize('case', TRACK_CASES, ids=[c['name'] for c in TRACK_CASES])
 def test_staged_track_stages(case, golden, dev):
     pc.check_staged_case(case, golden, dev)
+
+
+def test_reductions_do_not_depend_on_the_grid(dev):
+    pc.check_grid_independence(dev)
