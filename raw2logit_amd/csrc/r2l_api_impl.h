@@ -142,7 +142,8 @@ R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bw
 R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true>)
 R2L_KERNEL_OCC(r2l_launch_bwd2, R2LBwd2Args, r2l_bwd2_block<GBwd2>, R2L_LDS3(GBwd2), R2L_OCC_BWD2)
-R2L_KERNEL(r2l_launch_bn_reduce, R2LBnReduceArgs, r2l_bn_reduce_block, R2L_RED_FLOATS)
+// 14 KB of LDS instead of 68 KB: 8 workgroups' worth of loads in flight per CU instead of 2
+R2L_KERNEL_OCC(r2l_launch_bn_reduce, R2LBnReduceArgs, r2l_bn_reduce_block, R2L_RED_FLOATS_N(6), 8)
 R2L_KERNEL(r2l_launch_add_bwd, R2LAddBwdArgs, r2l_add_bwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_fwd, R2LRaw2RgbArgs, r2l_raw2rgb_fwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_bwd, R2LRaw2RgbArgs, r2l_raw2rgb_bwd_block, R2L_RED_FLOATS)

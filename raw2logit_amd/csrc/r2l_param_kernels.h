@@ -250,13 +250,15 @@ struct R2LItemWalk {
   }
 };
 
-// 4 rows x 6 columns window around a 4-wide x 2-tall item at (fy, fx): rows fy-1..fy+2,
-// columns fx-1..fx+4 of an UNSHIFTED plane
-template <class G>
-R2L_HD void r2l_window_4x6(const float* Pl, int fy, int fx, float w[4][6]) {
+// (RPI + 2) rows x 6 columns window around a 4-wide x RPI-tall item at (fy0, fx): rows fy0-1..fy0+RPI,
+// columns fx-1..fx+4 of an UNSHIFTED plane.  Rows past the end of the plane (items of the last row group)
+// are clamped: their values only feed output rows that are not stored.
+template <class G, int RPI>
+R2L_HD void r2l_window_rows6(const float* Pl, int fy0, int fx, float w[RPI + 2][6]) {
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 4; ++i) {
-    const float* r = Pl + (fy - 1 + i) * G::FS + fx;  // three aligned 128-bit reads: cols fx-4..fx+7
+  for (int i = 0; i < RPI + 2; ++i) {
+    const int fy = (fy0 - 1 + i < G::FH - 1) ? fy0 - 1 + i : G::FH - 1;
+    const float* r = Pl + fy * G::FS + fx;  // three aligned 128-bit reads: cols fx-4..fx+7
     const r2l_f4 l = r2l_lds_f4(r - 4);
     const r2l_f4 m = r2l_lds_f4(r);
     const r2l_f4 h = r2l_lds_f4(r + 4);
@@ -268,91 +270,83 @@ R2L_HD void r2l_window_4x6(const float* Pl, int fy, int fx, float w[4][6]) {
     w[i][5] = h.x;
   }
 }
+// The stencil phases work on items of 4 columns x 4 rows: 18 x 18 (Y) or 18 x 17 (YP, adjoint blur) items
+// cover the frame in ONE pass of the 512 lanes (with 4 x 2 items the 630 items needed a second pass in which
+// two wavefronts worked and six waited at the barrier), and an even row count keeps the Bayer row parity of
+// every output row a compile-time constant.
+#define R2L_RPI 4
 
 // ---- phase B: Y on frame rows/cols [1, F-1) ------------------------------------------------------
 template <class G, bool BORDER>
 R2L_HD void r2l_compute_y(int tid, const float* V, float* Y, R2LFoldedRef F, int oy, int ox, int H,
                           int W) {
-  constexpr int CPR = G::FW / 4, NRP = (G::FH - 2) / 2;
-  constexpr int NIT = (CPR * NRP + R2L_NT - 1) / R2L_NT;
-  R2LItemWalk<CPR> iw;
-  iw.init(tid);
-  R2L_PRAGMA_NOUNROLL
-  for (int it = 0; it < NIT; ++it) {
-    if (iw.row < NRP) {
-      const int fy = 1 + 2 * iw.row, fx = 4 * iw.col;  // fy is odd
-      float w[4][6];
-      r2l_window_4x6<G>(V, fy, fx, w);
+  constexpr int CPR = G::FW / 4, RPI = R2L_RPI, NRG = (G::FH - 2 + RPI - 1) / RPI;
+  static_assert(CPR * NRG <= R2L_NT, "one pass");
+  const int rg = tid / CPR, col = tid - rg * CPR;
+  if (rg >= NRG) return;
+  const int fy0 = 1 + RPI * rg, fx = 4 * col;  // fy0 is odd
+  float w[RPI + 2][6];
+  r2l_window_rows6<G, RPI>(V, fy0, fx, w);
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < RPI; ++r) {
+    const int py = (1 + r) & 1;  // parity of frame row fy0 + r (tile origins are even)
+    r2l_p2 o[2];
+    o[0] = o[1] = r2l_splat2(0.f);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
       R2L_PRAGMA_UNROLL
-      for (int r = 0; r < 2; ++r) {
-        float o[4];
-        R2L_PRAGMA_UNROLL
-        for (int c = 0; c < 4; ++c) {
-          const int par = (((1 + r) & 1) << 1) | (c & 1);
-          float s = 0.f;
-          R2L_PRAGMA_UNROLL
-          for (int i = 0; i < 3; ++i)
-            R2L_PRAGMA_UNROLL
-          for (int j = 0; j < 3; ++j) s = fmaf(F.AY[par][i * 3 + j], w[r + i][c + j], s);
-          o[c] = s;
-        }
-        if (BORDER) {  // zero padding of the sharpen conv: Y is 0 outside the image
-          const int gy = oy - 4 + fy + r;
-          const bool yin = (unsigned)gy < (unsigned)H;
-          R2L_PRAGMA_UNROLL
-          for (int c = 0; c < 4; ++c) {
-            const int gx = ox - 4 + fx + c;
-            o[c] = (yin && (unsigned)gx < (unsigned)W) ? o[c] : 0.f;
-          }
-        }
-        r2l_f4 st;
-        st.x = o[0];
-        st.y = o[1];
-        st.z = o[2];
-        st.w = o[3];
-        *(r2l_f4*)(Y + (fy + r) * G::FS + fx) = st;
-      }
+    for (int j = 0; j < 3; ++j) {
+      const r2l_p2 wy = r2l_mk2(F.AY2[py][i * 3 + j][0], F.AY2[py][i * 3 + j][1]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(wy, r2l_mk2(w[r + i][2 * p + j], w[r + i][2 * p + j + 1]), o[p]);
     }
-    iw.next();
+    r2l_f4 st;
+    st.x = o[0][0];
+    st.y = o[0][1];
+    st.z = o[1][0];
+    st.w = o[1][1];
+    if (BORDER) {  // zero padding of the sharpen conv: Y is 0 outside the image
+      const int gy = oy - 4 + fy0 + r, gx = ox - 4 + fx;
+      const bool yin = (unsigned)gy < (unsigned)H;
+      st.x = (yin && (unsigned)gx < (unsigned)W) ? st.x : 0.f;
+      st.y = (yin && (unsigned)(gx + 1) < (unsigned)W) ? st.y : 0.f;
+      st.z = (yin && (unsigned)(gx + 2) < (unsigned)W) ? st.z : 0.f;
+      st.w = (yin && (unsigned)(gx + 3) < (unsigned)W) ? st.w : 0.f;
+    }
+    if (fy0 + r <= G::FH - 2) *(r2l_f4*)(Y + (fy0 + r) * G::FS + fx) = st;
   }
 }
 
 // ---- phase C: YP = sharpen(Y) on frame rows/cols [2, F-2), stored shifted by +2 columns ----------
 template <class G>
 R2L_HD void r2l_compute_yp(int tid, const float* Y, float* YP, R2LFoldedRef F) {
-  constexpr int CPR = G::FW / 4, NRP = (G::FH - 4) / 2;
-  constexpr int NIT = (CPR * NRP + R2L_NT - 1) / R2L_NT;
-  R2LItemWalk<CPR> iw;
-  iw.init(tid);
-  R2L_PRAGMA_NOUNROLL
-  for (int it = 0; it < NIT; ++it) {
-    if (iw.row < NRP) {
-      const int fy = 2 + 2 * iw.row, fx = 4 * iw.col;
-      float w[4][6];
-      r2l_window_4x6<G>(Y, fy, fx, w);
+  constexpr int CPR = G::FW / 4, RPI = R2L_RPI, NRG = (G::FH - 4) / RPI;
+  static_assert((G::FH - 4) % RPI == 0 && CPR * NRG <= R2L_NT, "one pass, no ragged row group");
+  const int rg = tid / CPR, col = tid - rg * CPR;
+  if (rg >= NRG) return;
+  const int fy0 = 2 + RPI * rg, fx = 4 * col;
+  float w[RPI + 2][6];
+  r2l_window_rows6<G, RPI>(Y, fy0, fx, w);
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < RPI; ++r) {
+    r2l_p2 o[2];
+    o[0] = o[1] = r2l_splat2(0.f);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
       R2L_PRAGMA_UNROLL
-      for (int r = 0; r < 2; ++r) {
-        float o[4];
-        R2L_PRAGMA_UNROLL
-        for (int c = 0; c < 4; ++c) {
-          float s = 0.f;
-          R2L_PRAGMA_UNROLL
-          for (int i = 0; i < 3; ++i)
-            R2L_PRAGMA_UNROLL
-          for (int j = 0; j < 3; ++j) s = fmaf(F.sharp[i * 3 + j], w[r + i][c + j], s);
-          o[c] = s;
-        }
-        float* d = YP + (fy + r) * G::FS + fx + 2;
-        r2l_f2 lo, hi;
-        lo.x = o[0];
-        lo.y = o[1];
-        hi.x = o[2];
-        hi.y = o[3];
-        *(r2l_f2*)d = lo;
-        *(r2l_f2*)(d + 2) = hi;
-      }
+    for (int j = 0; j < 3; ++j) {
+      const r2l_p2 ws = r2l_splat2(F.sharp[i * 3 + j]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(ws, r2l_mk2(w[r + i][2 * p + j], w[r + i][2 * p + j + 1]), o[p]);
     }
-    iw.next();
+    float* d = YP + (fy0 + r) * G::FS + fx + 2;
+    r2l_f2 lo, hi;
+    lo.x = o[0][0];
+    lo.y = o[0][1];
+    hi.x = o[1][0];
+    hi.y = o[1][1];
+    *(r2l_f2*)d = lo;
+    *(r2l_f2*)(d + 2) = hi;
   }
 }
 
@@ -561,7 +555,8 @@ R2L_BLOCKFN void r2l_unfold_phases(const float* params, const double* sums, doub
 }
 
 // packed forms: pair p = columns (2p, 2p+1) of the micro-tile row
-R2L_HD void r2l_blur_row2(const float yw[5][8], R2LFoldedRef F, r2l_p2 ypp[2]) {
+template <class FT>
+R2L_HD void r2l_blur_row2(const float yw[5][8], const FT& F, r2l_p2 ypp[2]) {
   ypp[0] = ypp[1] = r2l_splat2(0.f);
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 5; ++i)
@@ -572,8 +567,8 @@ R2L_HD void r2l_blur_row2(const float yw[5][8], R2LFoldedRef F, r2l_p2 ypp[2]) {
     for (int p = 0; p < 2; ++p) ypp[p] = r2l_pfma(w, r2l_mk2(yw[i][2 * p + j], yw[i][2 * p + j + 1]), ypp[p]);
   }
 }
-template <int PY>
-R2L_HD void r2l_chroma_row2(const float vw[3][6], R2LFoldedRef F, r2l_p2 u[2], r2l_p2 v[2]) {
+template <int PY, class FT>
+R2L_HD void r2l_chroma_row2(const float vw[3][6], const FT& F, r2l_p2 u[2], r2l_p2 v[2]) {
   u[0] = u[1] = v[0] = v[1] = r2l_splat2(0.f);
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 3; ++i)
@@ -706,7 +701,9 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
 // reproducible).  Slots go through LDS 32 at a time: every thread parks its 32 values, then 16 threads
 // per slot add 32 of the R2L_NT values each (lane `part` takes threads part, part+16, ...: at most a 2-way
 // bank conflict), and one thread per slot adds the 16 partial sums.
-#define R2L_RED_FLOATS (32 * (R2L_NT + 1) + 32 * 16)
+#define R2L_RED_ROWS(NACC) ((NACC) < 32 ? (NACC) : 32)
+#define R2L_RED_FLOATS_N(NACC) (R2L_RED_ROWS(NACC) * (R2L_NT + 1) + 32 * 16)  // LDS floats of a NACC-slot reduction
+#define R2L_RED_FLOATS R2L_RED_FLOATS_N(32)
 #define R2L_ACC_DIRECT(regs, i) R2L_TREG(regs).acc[i]
 #define R2L_BLOCK_REDUCE(NACC, regs, lds, partial, bid, nblk) \
   R2L_BLOCK_REDUCE_F(NACC, R2L_ACC_DIRECT, regs, lds, partial, bid, nblk)
@@ -727,14 +724,14 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
         for (int j_ = 0; j_ < R2L_NT / 16; ++j_)                                            \
           s_ += (lds)[slot_ * (R2L_NT + 1) + part_ + 16 * j_];                              \
       }                                                                                     \
-      (lds)[32 * (R2L_NT + 1) + tid] = s_;                                                  \
+      (lds)[R2L_RED_ROWS(NACC) * (R2L_NT + 1) + tid] = s_;                                                  \
     }                                                                                       \
     R2L_PHASE_END                                                                           \
     R2L_PHASE_BEGIN                                                                         \
     if (tid < 32 && base_ + tid < (NACC)) {                                                 \
       float s_ = 0.f;                                                                       \
       R2L_PRAGMA_UNROLL                                                                     \
-      for (int j_ = 0; j_ < 16; ++j_) s_ += (lds)[32 * (R2L_NT + 1) + tid * 16 + j_];       \
+      for (int j_ = 0; j_ < 16; ++j_) s_ += (lds)[R2L_RED_ROWS(NACC) * (R2L_NT + 1) + tid * 16 + j_];       \
       r2l_store_coherent(&(partial)[(size_t)(base_ + tid) * (nblk) + (bid)], s_);           \
     }                                                                                       \
     R2L_STORES_DONE(); /* a later workgroup may finish the reduction inside this launch */  \
@@ -968,7 +965,6 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
   }
   R2L_SCHED_FENCE();
   regs.acc[R2L_L1_GGAM] = r2l_padd(regs.acc[R2L_L1_GGAM], ggam);
-#ifndef R2L_EXP_NO_GBLUR
   // d/d gaussian_blur.weight[i][j] = sum_p gY''(p) * YP_ext(p + (i-2, j-2)).  The two windows are read from
   // LDS a second time here rather than kept in 58 registers across the pointwise part (VGPR-bound kernel).
   float yw[5][8];
@@ -982,8 +978,6 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
     for (int p = 0; p < 2; ++p) s = r2l_pfma(gy2[p], r2l_mk2(yw[i][2 * p + j], yw[i][2 * p + j + 1]), s);
     regs.acc[R2L_L1_GBLUR + i * 5 + j] = s;
   }
-#endif
-#ifndef R2L_EXP_NO_GA
   R2L_SCHED_FENCE();
   // folded chroma stencils: GA[par][t] = sum_{p of parity par} gU(p) * v_ext(p+t); pair half = column parity
   float vw[3][6];
@@ -1005,7 +999,6 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
   }
   regs.acc[R2L_L1_SU] = r2l_padd(regs.acc[R2L_L1_SU], r2l_padd(gu[0], gu[1]));
   regs.acc[R2L_L1_SV] = r2l_padd(regs.acc[R2L_L1_SV], r2l_padd(gv[0], gv[1]));
-#endif
 }
 
 template <class G, bool RAGGED, bool ADD, bool PRE>
@@ -1135,45 +1128,45 @@ R2L_HD float r2l_b2_slot(const R2LBwd2Regs& r, int i) {
 // phase: HP(q') = sum_t blur[t] * G2_ext0(q' - t) on frame rows/cols [2, F-2); G2 is stored shifted
 template <class G>
 R2L_HD void r2l_adjoint_blur(int tid, const float* G2, float* HP, R2LFoldedRef F) {
-  constexpr int CPR = G::FW / 4, NRP = (G::FH - 4) / 2;
-  for (int it = tid; it < CPR * NRP; it += R2L_NT) {
-    const int rp = it / CPR, cx = it - rp * CPR;
-    const int fy = 2 + 2 * rp, fx = 4 * cx;
-    float w[6][8];  // rows fy-2..fy+3, cols fx-2..fx+5
+  constexpr int CPR = G::FW / 4, RPI = R2L_RPI, NRG = (G::FH - 4) / RPI;
+  static_assert((G::FH - 4) % RPI == 0 && CPR * NRG <= R2L_NT, "one pass, no ragged row group");
+  const int rg = tid / CPR, cx = tid - rg * CPR;
+  if (rg >= NRG) return;
+  const int fy0 = 2 + RPI * rg, fx = 4 * cx;
+  float w[RPI + 4][8];  // rows fy0-2..fy0+RPI+1, cols fx-2..fx+5
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < RPI + 4; ++i) {
+    const float* r = G2 + (fy0 - 2 + i) * G::FS + fx;  // (+2 shift) - 2
+    const r2l_f4 a = r2l_lds_f4(r);
+    const r2l_f4 b = r2l_lds_f4(r + 4);
+    w[i][0] = a.x;
+    w[i][1] = a.y;
+    w[i][2] = a.z;
+    w[i][3] = a.w;
+    w[i][4] = b.x;
+    w[i][5] = b.y;
+    w[i][6] = b.z;
+    w[i][7] = b.w;
+  }
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < RPI; ++r) {
+    r2l_p2 o[2];
+    o[0] = o[1] = r2l_splat2(0.f);
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 6; ++i) {
-      const float* r = G2 + (fy - 2 + i) * G::FS + fx;  // (+2 shift) - 2
-      const r2l_f4 a = r2l_lds_f4(r);
-      const r2l_f4 b = r2l_lds_f4(r + 4);
-      w[i][0] = a.x;
-      w[i][1] = a.y;
-      w[i][2] = a.z;
-      w[i][3] = a.w;
-      w[i][4] = b.x;
-      w[i][5] = b.y;
-      w[i][6] = b.z;
-      w[i][7] = b.w;
-    }
-    R2L_PRAGMA_UNROLL
-    for (int r = 0; r < 2; ++r) {
-      float o[4];
+    for (int i = 0; i < 5; ++i)
       R2L_PRAGMA_UNROLL
-      for (int c = 0; c < 4; ++c) {
-        float s = 0.f;
-        R2L_PRAGMA_UNROLL
-        for (int i = 0; i < 5; ++i)
-          R2L_PRAGMA_UNROLL
-        for (int j = 0; j < 5; ++j)  // source p = q' - (i-2, j-2)  ->  window index (r+4-i, c+4-j)
-          s = fmaf(F.blur[i * 5 + j], w[r + 4 - i][c + 4 - j], s);
-        o[c] = s;
-      }
-      r2l_f4 st;
-      st.x = o[0];
-      st.y = o[1];
-      st.z = o[2];
-      st.w = o[3];
-      *(r2l_f4*)(HP + (fy + r) * G::FS + fx) = st;
+    for (int j = 0; j < 5; ++j) {  // source p = q' - (i-2, j-2)  ->  window index (r+4-i, c+4-j)
+      const r2l_p2 wb = r2l_splat2(F.blur[i * 5 + j]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p)
+        o[p] = r2l_pfma(wb, r2l_mk2(w[r + 4 - i][2 * p + 4 - j], w[r + 4 - i][2 * p + 5 - j]), o[p]);
     }
+    r2l_f4 st;
+    st.x = o[0][0];
+    st.y = o[0][1];
+    st.z = o[1][0];
+    st.w = o[1][1];
+    *(r2l_f4*)(HP + (fy0 + r) * G::FS + fx) = st;
   }
 }
 

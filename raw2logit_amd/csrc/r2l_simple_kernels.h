@@ -179,7 +179,8 @@ R2L_BLOCKFN void r2l_bn_reduce_block(const R2LBnReduceArgs& a, int bid, int nblk
   R2L_BLOCK_REDUCE(6, regs, lds, a.partial, bid, nblk)
   if (a.tree.counters) {
     double* sl = (double*)(lds + 4);
-    if (!r2l_tree_finish<6>(a.tree, bid, nblk, lds, sl, (double*)(lds + 512), (R2L_RED_FLOATS - 512) / 2)) return;
+    if (!r2l_tree_finish<6>(a.tree, bid, nblk, lds, sl, (double*)(lds + 512), (R2L_RED_FLOATS_N(6) - 512) / 2))
+      return;
     R2L_PHASE_BEGIN
     if (tid < 6) {
       a.sums[tid] = sl[tid];

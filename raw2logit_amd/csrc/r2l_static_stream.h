@@ -86,14 +86,7 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
     st.y = x[k][1];
     st.z = x[k][2];
     st.w = x[k][3];
-#if defined(R2L_EXP_NT_STORE) && !defined(R2L_EMUL)
-    {
-      r2l_v4 nv = {st.x, st.y, st.z, st.w};
-      __builtin_nontemporal_store(nv, (r2l_v4*)(outb + (size_t)k * plane + off));
-    }
-#else
     *(r2l_f4*)(outb + (size_t)k * plane + off) = st;
-#endif
   }
 }
 

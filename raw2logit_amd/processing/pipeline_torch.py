@@ -208,7 +208,11 @@ class ParametrizedProcessing(nn.Module):
         self.stages = {}
         self.buffer = {}
 
-        if self.track_stages:
+        # The fused kernels keep every intermediate in LDS / registers: they neither materialise the stage
+        # tensors nor produce d/d raw.  Whenever a caller can observe either (track_stages=True, or frames
+        # that require grad as in model.py:228), the stage-by-stage kernels run instead and fill
+        # ``self.stages`` exactly like the reference (:183-214).
+        if self.track_stages or (raw.requires_grad and torch.is_grad_enabled()):
             from ..staged import staged_forward
             rgb = staged_forward(self, raw)
         else:

@@ -248,9 +248,10 @@ def staged_forward(module, raw):
     m.stages['color_correct'] = rgb
     yuv = _Mix3.apply(rgb, m.M_RGB_2_YUV)                                                # :194
     yuv = _PlaneConv.apply(yuv, m.sharpening_filter.weight, False)                       # :195
-    rgb = _Mix3.apply(yuv, m.M_YUV_2_RGB)                                                # :198
-    m.stages['sharpening'] = rgb
-    yuv = _Mix3.apply(rgb, m.M_RGB_2_YUV)                                                # :200
+    if m.track_stages:  # the reference takes the YUV->RGB->YUV round trip only then (:197-200)
+        rgb = _Mix3.apply(yuv, m.M_YUV_2_RGB)                                            # :198
+        m.stages['sharpening'] = rgb
+        yuv = _Mix3.apply(rgb, m.M_RGB_2_YUV)                                            # :200
     yuv = _PlaneConv.apply(yuv, m.gaussian_blur.weight, True)                            # :202
     rgb = _Mix3.apply(yuv, m.M_YUV_2_RGB)                                                # :203
     m.stages['gaussian'] = rgb

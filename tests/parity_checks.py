@@ -262,7 +262,9 @@ def check_harness(golden, device):
 
 def check_staged_case(case, golden, device):
     """track_stages=True: every stage tensor, every stage gradient (retain_grad), d/d raw and the parameter
-    gradients against the reference's golden vectors."""
+    gradients against the reference's golden vectors.  For a case with track_stages=False the frames still
+    require grad here, which makes the module take the stage-by-stage kernels (d/d raw exists, stages are
+    filled like the reference's, no stage gradients are retained)."""
     g = golden['param_cases']
     grad_rtol = case.get('grad_rtol', 3e-3)
     pre = case['name'] + '/'
@@ -272,7 +274,7 @@ def check_staged_case(case, golden, device):
     cot = np.random.default_rng(1000 + case['seed']).standard_normal((B, 3, H, W)).astype(np.float32)
     P = build_params(case)
     m = make_module(case, P, device)
-    assert m.track_stages
+    assert m.track_stages == case['track']
     raw = torch.from_numpy(raw_np).to(device).requires_grad_(True)
     y = m(raw)
     (y * torch.from_numpy(cot).to(device)).sum().backward()
@@ -292,6 +294,9 @@ def check_staged_case(case, golden, device):
         got = _sample(st.detach().cpu().numpy(), full)
         lim = 2e-4 if k in ('gamma_correct', 'noise') else 2e-5
         assert np.abs(got - ref).max() <= lim, (k, np.abs(got - ref).max())
+        if not case['track']:
+            assert not st.retains_grad      # (:220-222: retain_grad only when track_stages)
+            continue
         gref = g[pre + 'stage_grad/' + k]
         ggot = _sample(st.grad.cpu().numpy(), full)
         fl = _sample(np.maximum(np.abs(sg_lo[k] - sg_nom[k]), np.abs(sg_hi[k] - sg_nom[k])), full)

@@ -1,7 +1,7 @@
 """Diagnostic: per-phase cycle totals (s_memtime) of the tile kernels, from a -DR2L_EXP_STAMPS build."""
 import os, sys, ctypes, torch
 HERE = os.path.dirname(os.path.abspath(__file__))
-os.environ['R2L_LIB_PATH'] = os.path.join(HERE, '_build', 'lib_stamps.so')
+os.environ['R2L_LIB_PATH'] = os.path.join(HERE, '_build', os.environ.get('R2L_STAMPS_LIB', 'lib_stamps.so'))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import isp_oracle as orc
 from raw2logit_amd import _lib

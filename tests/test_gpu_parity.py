@@ -126,3 +126,12 @@ def test_staged_track_stages(case, golden, dev):
 
 def test_reductions_do_not_depend_on_the_grid(dev):
     pc.check_grid_independence(dev)
+
+
+GRAD_RAW_CASES = [c for c in PARAM_CASES if not c['track'] and c['name'] in (
+    'drone_bn_train', 'drone_additive_bn', 'micro_bn_train', 'drone_ragged_tile', 'tiny_4x4', 'drone_bn_eval')]
+
+
+@pytest.mark.parametrize('case', GRAD_RAW_CASES, ids=[c['name'] for c in GRAD_RAW_CASES])
+def test_frames_requiring_grad_take_the_staged_kernels(case, golden, dev):
+    pc.check_staged_case(case, golden, dev)
