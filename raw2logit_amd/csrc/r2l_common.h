@@ -36,6 +36,7 @@ R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
 #define R2L_PRAGMA_UNROLL
 #define R2L_PRAGMA_NOUNROLL
 #define R2L_SCHED_FENCE()
+#define R2L_PRIO(n)
 #else
 #include <hip/hip_runtime.h>
 #define R2L_HD static __device__ __forceinline__
@@ -66,6 +67,8 @@ R2L_HD float r2l_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // keeps the scheduler from hoisting the scalar loads of LATER weights above this point (their live
 // ranges would overflow the SGPR file and be spilled to VGPR lanes)
 #define R2L_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// wave issue priority (0..3)
+#define R2L_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
 
 // 128-bit LDS read that stays one ds_read_b128: without the empty asm hipcc scalarises the vector load

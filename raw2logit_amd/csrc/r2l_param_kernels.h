@@ -601,6 +601,16 @@ struct R2LFwdArgs {
   double* stats_out;
 };
 
+// Two forward workgroups share a CU; the hardware favours the older one's waves, so left alone the younger
+// workgroup finishes ~40 % later and runs the tail at half occupancy.  Waves in the short LDS-bound stencil
+// phases get a higher issue priority than waves in the long VALU-bound pixel phase: the two workgroups then
+// interleave phase by phase instead of by age (measured: 82 -> 78 us).
+#ifndef R2L_PRIO_PIXELS
+#define R2L_PRIO_PIXELS 0
+#endif
+#ifndef R2L_PRIO_STENCIL
+#define R2L_PRIO_STENCIL 2
+#endif
 struct R2LFwdRegs {
   r2l_p2 acc[6];  // per pair half; the halves are added when the workgroup reduces
 };
@@ -781,10 +791,12 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
     }
     R2L_PHASE_BEGIN
     if (haven) r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));  // next tile, in flight
+    R2L_PRIO(R2L_PRIO_PIXELS);
     if (MAYBE_RAGGED && t.ragged)
       r2l_fwd_pixels<G, MAYBE_RAGGED, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
     else
       r2l_fwd_pixels<G, false, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
+    R2L_PRIO(R2L_PRIO_STENCIL);
     R2L_PHASE_END
     R2L_STAMP(4)
     t = tn;
