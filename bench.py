@@ -188,7 +188,13 @@ def main():
                        'global_batch': world * B, 'frame': [S, S],
                        'parallelism': f'batch shard x{world}' if world > 1 else 'single GPU',
                        'step': 'forward + backward' + (' + 132-float grad all-reduce' if world > 1 else '')},
-            'roofline': roofline, 'kernels': kernels,
+            'roofline': roofline,
+            # the whole step against SURVEY.md section 8d's 52 B/px (single fused backward; this kernel split
+            # moves 72 B/px)
+            'step_roofline': {'algo_bytes_per_px': 52.0, 'achieved': round(px_per_step / world * 52.0 * args.steps / dt / 1e9, 1),
+                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': round(px_per_step / world * 52.0 * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
+            'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S)

@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round artefacts on the GPU box: bench line, rocprofv3 kernel stats of the same command, PMC passes
+# (counters in their own runs, kernel-trace only).  Usage: bash tests/profile_round.sh <tag>
+# Results land in gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+TAG=${1:-r01_c}
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/$TAG
+rm -rf $OUT; mkdir -p $OUT
+python3 bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+tail -c 600 $OUT/bench.json
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1)
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+run() { n=$1; shift; (cd /tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/$n.log 2>&1); }
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM
+run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+run tcc1 FETCH_SIZE
+run tcc2 WRITE_SIZE
+python3 - "$OUT" <<'PY'
+import csv, glob, collections, json, sys
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + '/*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0]
+        if k.startswith('r2l_'):
+            agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+with open(out + '/pmc_summary.txt', 'w') as fh:
+    for k in sorted(agg):
+        fh.write(k + '\n')
+        for c, v in sorted(agg[k].items()):
+            fh.write('   %-28s %14.0f  (n=%d)\n' % (c, sum(v) / len(v), len(v)))
+# HBM traffic per launch: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE under-counts by 2x on gfx950
+# (MI355X_MICROARCH.md, HBM / rocprofv3 section), WRITE_SIZE is taken as read
+traffic = {}
+for k, c in agg.items():
+    if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+        fb = 2.0 * 1024.0 * sum(c['FETCH_SIZE']) / len(c['FETCH_SIZE'])
+        wb = 1024.0 * sum(c['WRITE_SIZE']) / len(c['WRITE_SIZE'])
+        traffic[k] = {'fetch_bytes': fb, 'write_bytes': wb, 'total_bytes': fb + wb,
+                      'note': 'FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as read; KiB -> bytes; 64x512x512 '
+                              'workload; averaged over the launches of a step (fwd: stats-only and apply)'}
+json.dump(traffic, open(out + '/pmc_traffic.json', 'w'), indent=1)
+print(open(out + '/pmc_summary.txt').read()[-1500:])
+PY
+rm -rf $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/tcc1 $OUT/tcc2
+ls -la $OUT
