@@ -30,7 +30,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # algorithmic HBM bytes per raw pixel of each kernel (DESIGN.md section "bytes per pixel")
 ALGO_BYTES_PER_PX = {
-    'r2l_launch_fwd_kernel': 16.0,        # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0)
+    'r2l_launch_fwd_kernel': 16.0,          # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0)
     'r2l_launch_bwd1_kernel': 20.0,       # raw 4 + grad_out 12 in, dL/dY'' 4 out
     'r2l_launch_bwd2_kernel': 8.0,        # raw 4 + dL/dY'' 4 in
     'r2l_launch_bn_reduce_kernel': 24.0,  # grad_out 12 + saved output 12 in
@@ -58,6 +58,9 @@ def parse():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--raw-u16', action='store_true',
+                    help='feed the 12-bit frames as uint16 containers (2 B/px ingest, normalised in-kernel; '
+                         'SURVEY.md section 8f) instead of float32: a separate variant, not the headline config')
     return ap.parse_args()
 
 
@@ -107,10 +110,14 @@ def main():
     lib = _lib.device_library()                     # raises if the HIP extension is missing
 
     B, S = args.batch, args.size
-    raw = torch.from_numpy(orc.synth_raw(B, S, S, seed=rank, kind='uniform')).to(dev)
+    raw_np = orc.synth_raw(B, S, S, seed=rank, kind='uniform')      # float32 = u16 / 4095
+    if args.raw_u16:
+        raw_np = np.rint(raw_np.astype(np.float64) * 4095.0).astype(np.uint16)
+    raw = torch.from_numpy(raw_np).to(dev)
     cot = torch.randn((B, 3, S, S), device=dev, generator=torch.Generator(dev).manual_seed(1 + rank))
     model = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, track_stages=False, batch_norm_output=True)
     model = model.to(dev).train()
+    model.raw_bits = 12
     if world > 1:
         model.process_group = dist.group.WORLD
     params = list(model.parameters())
@@ -163,26 +170,31 @@ def main():
         for line in buf.value.decode().splitlines():
             name, cnt, ms = line.split()
             kernels[name] = {'launches': int(cnt), 'avg_us': round(1e3 * float(ms) / int(cnt), 2)}
-        cand = {k: v for k, v in kernels.items() if k in ALGO_BYTES_PER_PX}
+        # 16-bit container variants (r2l_launch_*_u16_kernel): 2 B/px less raw traffic
+        algo = dict(ALGO_BYTES_PER_PX)
+        for k, v in ALGO_BYTES_PER_PX.items():
+            if 'bn_reduce' not in k:
+                algo[k.replace('_kernel', '_u16_kernel')] = v - 2.0
+        cand = {k: v for k, v in kernels.items() if k in algo}
         if cand:
             total = {k: v['launches'] * v['avg_us'] for k, v in cand.items()}
             dom = max(total, key=total.get)
             avg_us = cand[dom]['avg_us']
-            bpp = ALGO_BYTES_PER_PX[dom]
-            if dom == 'r2l_launch_fwd_kernel':
-                # two launches per step: stats-only (4 B/px) and apply (16 B/px): average bytes
-                bpp = (4.0 + 16.0) / 2
+            bpp = algo[dom]
+            if dom.startswith('r2l_launch_fwd'):
+                # two launches per step: stats-only (raw only) and apply (raw + 12 B/px out): average bytes
+                bpp = ((bpp - 12.0) + bpp) / 2
             achieved = B * S * S * bpp / (avg_us * 1e-6) / 1e9
             roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                        'traffic': pmc_traffic(dom, B, S), 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
+                        'traffic': pmc_traffic(dom, B, S) if not args.raw_u16 else None, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
 
     if rank == 0:
         out = {
             'metric': 'ISP Mpix/s (fwd+bwd) on 512x512 raw batches', 'value': round(value, 1),
             'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' + (' (uint16 containers)' if args.raw_u16 else ''),
             'config': {'workload': f'parametrized ISP fwd+bwd, BatchNorm train, {B}x{S}x{S} 12-bit RGGB '
                                    f'frames per GPU, Drone camera parameters',
                        'global_batch': world * B, 'frame': [S, S],

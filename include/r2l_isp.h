@@ -154,6 +154,25 @@ int r2l_additive_bwd(const float *grad_out, const float *out, const float *bn_me
 int r2l_static_fwd(const float *raw, float *out, int B, int H, int W, const double *camera_host,
                    int debayer, int sharpening, int denoising, double gamma, void *stream);
 
+/* ---- 16-bit ingest.  The reference's datasets deliver the sensor's 16-bit
+ * containers and normalise them on the host: img = load_image(path) / (2**bits - 1), float32
+ * (dataset.py:86-87, :140-143; utils/dataset_utils.py:18-26).  The *_u16 variants read the containers
+ * themselves (2 B/px instead of 4) and apply that float32 division inside the kernel (denom = 2**bits - 1;
+ * the result equals the correctly rounded float32 quotient, so every output is bit-identical to the float32
+ * entry point fed with the host-normalised frame).  W % 4 == 0 required.  No grad_raw (integer input).   */
+int r2l_isp_fwd_u16(const unsigned short *raw, float denom, const float *params, const float *additive,
+                    const float *bn_mean_istd, float *out, double *stats, void *workspace,
+                    size_t workspace_bytes, int B, int H, int W, int flags, void *stream);
+int r2l_isp_bwd_u16(const unsigned short *raw, float denom, const float *params, const float *additive,
+                    const float *bn_mean_istd, const float *bn_bwd, const float *grad_out,
+                    float *grad_params, void *workspace, size_t workspace_bytes, int B, int H, int W,
+                    int flags, void *stream);
+int r2l_raw2rgb_fwd_u16(const unsigned short *raw, float denom, const float *black_level, float *out, int B,
+                        int H, int W, int reduce_size, int out_channels, void *stream);
+int r2l_static_fwd_u16(const unsigned short *raw, float denom, float *out, int B, int H, int W,
+                       const double *camera_host, int debayer, int sharpening, int denoising, double gamma,
+                       void *stream);
+
 /* ---- staged execution (track_stages=True, pipeline_torch.py:197-221): one entry point per materialised
  * stage, each with its VJP, so that autograd can hold every stage tensor (retain_grad) and d/d raw exists.
  * Tensors are (B,3,H,W) float32.  Weight gradients are float32 arrays; workspace from
@@ -163,7 +182,8 @@ int r2l_static_fwd(const float *raw, float *out, int B, int H, int W, const doub
  *   pconv    channel 0 <- KxK conv of channel 0 (K=3 zero pad :195 | K=5 mirror pad :202), 1-2 copied;
  *            gk25 is 5x5-strided (entry [i*5+j])
  *   point    op 0/1 clip fwd/bwd (:206)  2/3 gamma fwd/bwd (:209; sums6[0] = sum g*out*log2(x))
- *            4 add (:213)  5 BatchNorm apply  6 BatchNorm backward  7 BatchNorm statistics (sums6)   */
+ *            4 add (:213)  5 BatchNorm apply  6 BatchNorm backward  7 BatchNorm statistics (sums6)
+ *            8 (x - w[c]) / w[3+c]: the T.Normalize(mean, std) that follows the static pipeline (train.py:157-171) */
 size_t r2l_stage_workspace_bytes(void);
 int r2l_stage_conv33_fwd(const float *x, const float *w, float *y, int B, int H, int W, void *stream);
 int r2l_stage_conv33_bwd(const float *x, const float *w, const float *g, float *gx, float *gw,

@@ -52,6 +52,17 @@ _SIGNATURES = {
                                    ctypes.c_void_p]),
     'r2l_additive_bwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_isp_fwd_u16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p,
+                                       _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_isp_bwd_u16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p,
+                                       _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_size_t,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_raw2rgb_fwd_u16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, _c_float_p, _c_float_p] +
+                            [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    'r2l_static_fwd_u16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     'r2l_stage_workspace_bytes': (ctypes.c_size_t, []),
     'r2l_stage_conv33_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'r2l_stage_conv33_bwd': (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_void_p, ctypes.c_size_t] +
@@ -135,8 +146,8 @@ def ptr(t):
 
 
 def hipcc_command(out_path=LIB_PATH):
-    # -fno-slp-vectorize: the SLP vectoriser pairs the stencil FMAs into v_pk_fma_f32 at the price of
-    # register shuffles (v_pk_mov) and ~100 more live VGPRs in the backward kernel, which costs occupancy
+    # -fno-slp-vectorize: packed f32 is written out by hand where it pays (r2l_p2 pairs of adjacent pixels); the
+    # SLP vectoriser's own pairing adds register shuffles and ~100 live VGPRs to the backward kernels
     return ['hipcc', '-O3', '-std=c++17', '-fno-slp-vectorize', '--offload-arch=gfx950', '-shared', '-fPIC',
             os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path]
 

@@ -134,22 +134,40 @@ R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 *
 #ifndef R2L_OCC_BWD2
 #define R2L_OCC_BWD2 2
 #endif
-// hot instantiation (frames that tile exactly, no additive layer) + the general ones
-R2L_KERNEL_V(r2l_launch_fwd, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false>)
-R2L_KERNEL_V(r2l_launch_fwd_ragged, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true>)
-R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, true, true>)
-R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false>)
-R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true>)
-R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true>)
-R2L_KERNEL_OCC(r2l_launch_bwd2, R2LBwd2Args, r2l_bwd2_block<GBwd2>, R2L_LDS3(GBwd2), R2L_OCC_BWD2)
+// hot instantiation (frames that tile exactly, no additive layer) + the general ones; each again for 16-bit
+// container frames (compile-time, so that the float32 kernels carry no decode code)
+R2L_KERNEL_V(r2l_launch_fwd, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, false>)
+R2L_KERNEL_V(r2l_launch_fwd_ragged, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true, false>)
+R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, true, true, false>)
+R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, false>)
+R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, false>)
+R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
+R2L_KERNEL_V(r2l_launch_bwd2, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bwd2_block<GBwd2, false>)
+R2L_KERNEL_V(r2l_launch_fwd_u16, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, true>)
+R2L_KERNEL_V(r2l_launch_fwd_ragged_u16, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true, true>)
+R2L_KERNEL_V(r2l_launch_fwd_add_u16, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, true, true, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_ragged_u16, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_add_u16, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, true>)
+R2L_KERNEL_V(r2l_launch_bwd2_u16, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bwd2_block<GBwd2, true>)
 // 14 KB of LDS instead of 68 KB: 8 workgroups' worth of loads in flight per CU instead of 2
 R2L_KERNEL_OCC(r2l_launch_bn_reduce, R2LBnReduceArgs, r2l_bn_reduce_block, R2L_RED_FLOATS_N(6), 8)
 R2L_KERNEL(r2l_launch_add_bwd, R2LAddBwdArgs, r2l_add_bwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_fwd, R2LRaw2RgbArgs, r2l_raw2rgb_fwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_bwd, R2LRaw2RgbArgs, r2l_raw2rgb_bwd_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L_STATIC_LDS_FLOATS)
-R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_static_stream_block<0>, R2L_STREAM_NT, 4)
-R2L_KERNEL_NT(r2l_launch_static_stream_malvar, R2LStaticStreamArgs, r2l_static_stream_block<1>, R2L_STREAM_NT, 3)
+#define R2L_STREAM_BLOCK(name, DEB, U16)                                                                 \
+  R2L_BLOCKFN void name(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {                  \
+    r2l_static_stream_block<DEB, U16>(sa, bid, nblk, lds);                                               \
+  }
+R2L_STREAM_BLOCK(r2l_stream_block_bilinear, 0, false)
+R2L_STREAM_BLOCK(r2l_stream_block_malvar, 1, false)
+R2L_STREAM_BLOCK(r2l_stream_block_bilinear_u16, 0, true)
+R2L_STREAM_BLOCK(r2l_stream_block_malvar_u16, 1, true)
+R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear, R2L_STREAM_NT, 4)
+R2L_KERNEL_NT(r2l_launch_static_stream_malvar, R2LStaticStreamArgs, r2l_stream_block_malvar, R2L_STREAM_NT, 3)
+R2L_KERNEL_NT(r2l_launch_static_stream_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_u16, R2L_STREAM_NT, 4)
+R2L_KERNEL_NT(r2l_launch_static_stream_malvar_u16, R2LStaticStreamArgs, r2l_stream_block_malvar_u16, R2L_STREAM_NT, 3)
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
 
@@ -282,11 +300,19 @@ size_t r2l_isp_workspace_bytes(int B, int H, int W) {
   return r2l_carve(nullptr, B, H, W).total;
 }
 
-int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
-                const float* bn_mean_istd, float* out, double* stats, void* workspace,
-                size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
+static int r2l_check_raw(const R2LRaw& raw, int W, const char* who) {
+  if (!raw.f32 && !raw.u16) return r2l_fail(-1, std::string(who) + ": null pointer");
+  if (raw.u16 && !(raw.denom >= 1.f)) return r2l_fail(-1, std::string(who) + ": denom must be >= 1 (2**bits - 1)");
+  if (raw.u16 && (W & 3)) return r2l_fail(-1, std::string(who) + ": 16-bit frames need W % 4 == 0");
+  return 0;
+}
+
+static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float* additive,
+                            const float* bn_mean_istd, float* out, double* stats, void* workspace,
+                            size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
   if (int e = r2l_check_dims(B, H, W)) return e;
-  if (!raw || !params || !workspace) return r2l_fail(-1, "r2l_isp_fwd: null pointer");
+  if (int e = r2l_check_raw(raw, W, "r2l_isp_fwd")) return e;
+  if (!params || !workspace) return r2l_fail(-1, "r2l_isp_fwd: null pointer");
   if (additive && (H != 256 || W != 256))
     return r2l_fail(-1, "additive_layer is (1,3,256,256): needs 256x256 frames");
   const bool stats_only = (flags & R2L_F_STATS_ONLY) != 0;
@@ -316,9 +342,14 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
   a.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6};
   a.stats_out = stats;
   const bool exact = (H % GFwd::TH == 0) && (W % GFwd::TW == 0);
-  if (int e = additive ? r2l_launch_fwd_add(a, grid, stream)
-                       : (exact ? r2l_launch_fwd(a, grid, stream) : r2l_launch_fwd_ragged(a, grid, stream)))
-    return e;
+  int e;
+  if (raw.u16)
+    e = additive ? r2l_launch_fwd_add_u16(a, grid, stream)
+                 : (exact ? r2l_launch_fwd_u16(a, grid, stream) : r2l_launch_fwd_ragged_u16(a, grid, stream));
+  else
+    e = additive ? r2l_launch_fwd_add(a, grid, stream)
+                 : (exact ? r2l_launch_fwd(a, grid, stream) : r2l_launch_fwd_ragged(a, grid, stream));
+  if (e) return e;
   return 0;
 }
 
@@ -356,12 +387,13 @@ int r2l_bn_bwd_reduce(const float* grad_out, const float* out, const double* tot
   return r2l_launch_reduce_rows(r, 6, stream);
 }
 
-int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
-                const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,
-                float* grad_params, float* grad_raw, void* workspace, size_t workspace_bytes, int B,
-                int H, int W, int flags, void* stream) {
+static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float* additive,
+                            const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,
+                            float* grad_params, float* grad_raw, void* workspace, size_t workspace_bytes, int B,
+                            int H, int W, int flags, void* stream) {
   if (int e = r2l_check_dims(B, H, W)) return e;
-  if (!raw || !params || !grad_out || !grad_params || !workspace)
+  if (int e = r2l_check_raw(raw, W, "r2l_isp_bwd")) return e;
+  if (!params || !grad_out || !grad_params || !workspace)
     return r2l_fail(-1, "r2l_isp_bwd: null pointer");
   if (bn_bwd && !bn_mean_istd) return r2l_fail(-1, "r2l_isp_bwd: bn_bwd given without bn_mean_istd");
   if (additive && (H != 256 || W != 256))
@@ -390,9 +422,14 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   a1.W = W;
   a1.debug = ws.debug + 8 * R2L_MAX_BLOCKS;
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
-  if (int e = additive ? r2l_launch_bwd1_add(a1, g1, stream)
-                       : (exact ? r2l_launch_bwd1(a1, g1, stream) : r2l_launch_bwd1_ragged(a1, g1, stream)))
-    return e;
+  int e1;
+  if (raw.u16)
+    e1 = additive ? r2l_launch_bwd1_add_u16(a1, g1, stream)
+                  : (exact ? r2l_launch_bwd1_u16(a1, g1, stream) : r2l_launch_bwd1_ragged_u16(a1, g1, stream));
+  else
+    e1 = additive ? r2l_launch_bwd1_add(a1, g1, stream)
+                  : (exact ? r2l_launch_bwd1(a1, g1, stream) : r2l_launch_bwd1_ragged(a1, g1, stream));
+  if (e1) return e1;
   const int ntiles2 = B * ((H + GBwd2::TH - 1) / GBwd2::TH) * ((W + GBwd2::TW - 1) / GBwd2::TW);
   const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", 256));
   R2LBwd2Args a2;
@@ -410,7 +447,7 @@ int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
   a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC};
   a2.params = params;
   a2.grad_params = grad_params;
-  if (int e = r2l_launch_bwd2(a2, g2, stream)) return e;
+  if (int e = raw.u16 ? r2l_launch_bwd2_u16(a2, g2, stream) : r2l_launch_bwd2(a2, g2, stream)) return e;
   if (in_kernel) return 0;
   R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0, nullptr};
   if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
@@ -432,11 +469,12 @@ int r2l_additive_bwd(const float* grad_out, const float* out, const float* bn_me
   return r2l_launch_add_bwd(a, grid, stream);
 }
 
-int r2l_raw2rgb_fwd(const float* raw, const float* black_level, float* out, int B, int H, int W,
-                    int reduce_size, int out_channels, void* stream) {
+static int r2l_raw2rgb_fwd_impl(const R2LRaw& raw, const float* black_level, float* out, int B, int H, int W,
+                                int reduce_size, int out_channels, void* stream) {
   if (B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return r2l_fail(-1, "raw2rgb: H and W must be even");
   if (out_channels != 3 && out_channels != 4) return r2l_fail(-1, "raw2rgb: out_channels in {3,4}");
-  if (!raw || !out) return r2l_fail(-1, "raw2rgb: null pointer");
+  if (int e = r2l_check_raw(raw, 4, "raw2rgb")) return e;
+  if (!out) return r2l_fail(-1, "raw2rgb: null pointer");
   R2LRaw2RgbArgs a{raw, black_level, out, nullptr, nullptr, nullptr, B, H, W, reduce_size, out_channels};
   const size_t nitems = (size_t)B * (H / 2) * ((W + 3) / 4);
   size_t grid = (nitems + R2L_NT - 1) / R2L_NT;
@@ -459,7 +497,7 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
   if (!grad_out) return r2l_fail(-1, "raw2rgb_bwd: null pointer");
   if (grad_black_level && (!workspace || workspace_bytes < r2l_raw2rgb_bwd_workspace_bytes(B, H, W)))
     return r2l_fail(-2, "raw2rgb_bwd: workspace too small");
-  R2LRaw2RgbArgs a{nullptr, nullptr, nullptr, grad_out, grad_raw,
+  R2LRaw2RgbArgs a{r2l_raw_f32(nullptr), nullptr, nullptr, grad_out, grad_raw,
                    grad_black_level ? (float*)workspace : nullptr, B, H, W, reduce_size, out_channels};
   const size_t nitems = (size_t)B * (H / 2) * ((W + 3) / 4);
   size_t grid = (nitems + R2L_NT - 1) / R2L_NT;
@@ -472,10 +510,11 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
   return 0;
 }
 
-int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const double* camera_host,
-                   int debayer, int sharpening, int denoising, double gamma, void* stream) {
+static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int W, const double* camera_host,
+                               int debayer, int sharpening, int denoising, double gamma, void* stream) {
   if (int e = r2l_check_dims(B, H, W)) return e;
-  if (!raw || !out || !camera_host) return r2l_fail(-1, "r2l_static_fwd: null pointer");
+  if (int e = r2l_check_raw(raw, W, "r2l_static_fwd")) return e;
+  if (!out || !camera_host) return r2l_fail(-1, "r2l_static_fwd: null pointer");
   if (debayer != R2L_DEBAYER_BILINEAR && debayer != R2L_DEBAYER_MALVAR2004)
     return r2l_fail(-1, "r2l_static_fwd: unknown debayer");
   if (sharpening != R2L_SHARPEN_NONE && sharpening != R2L_SHARPEN_FILTER)
@@ -510,11 +549,61 @@ int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const doub
     sa.nitems = (int)nitems;
     const int wpb = R2L_STREAM_NT / 64;
     const int grid = (int)((nitems + wpb - 1) / wpb);
+    if (raw.u16)
+      return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_stream_malvar_u16(sa, grid, stream)
+                                               : r2l_launch_static_stream_bilinear_u16(sa, grid, stream);
     return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_stream_malvar(sa, grid, stream)
                                              : r2l_launch_static_stream_bilinear(sa, grid, stream);
   }
   const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC", 1024));
   return r2l_launch_static_short(a, grid, stream);
+}
+
+int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
+                const float* bn_mean_istd, float* out, double* stats, void* workspace,
+                size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
+  return r2l_isp_fwd_impl(r2l_raw_f32(raw), params, additive, bn_mean_istd, out, stats, workspace, workspace_bytes,
+                          B, H, W, flags, stream);
+}
+int r2l_isp_fwd_u16(const unsigned short* raw, float denom, const float* params, const float* additive,
+                    const float* bn_mean_istd, float* out, double* stats, void* workspace,
+                    size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
+  return r2l_isp_fwd_impl(r2l_raw_u16(raw, denom), params, additive, bn_mean_istd, out, stats, workspace,
+                          workspace_bytes, B, H, W, flags, stream);
+}
+int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
+                const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,
+                float* grad_params, float* grad_raw, void* workspace, size_t workspace_bytes, int B,
+                int H, int W, int flags, void* stream) {
+  return r2l_isp_bwd_impl(r2l_raw_f32(raw), params, additive, bn_mean_istd, bn_bwd, grad_out, grad_params, grad_raw,
+                          workspace, workspace_bytes, B, H, W, flags, stream);
+}
+int r2l_isp_bwd_u16(const unsigned short* raw, float denom, const float* params, const float* additive,
+                    const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,
+                    float* grad_params, void* workspace, size_t workspace_bytes, int B, int H, int W, int flags,
+                    void* stream) {
+  return r2l_isp_bwd_impl(r2l_raw_u16(raw, denom), params, additive, bn_mean_istd, bn_bwd, grad_out, grad_params,
+                          nullptr, workspace, workspace_bytes, B, H, W, flags, stream);
+}
+int r2l_raw2rgb_fwd(const float* raw, const float* black_level, float* out, int B, int H, int W,
+                    int reduce_size, int out_channels, void* stream) {
+  return r2l_raw2rgb_fwd_impl(r2l_raw_f32(raw), black_level, out, B, H, W, reduce_size, out_channels, stream);
+}
+int r2l_raw2rgb_fwd_u16(const unsigned short* raw, float denom, const float* black_level, float* out, int B,
+                        int H, int W, int reduce_size, int out_channels, void* stream) {
+  return r2l_raw2rgb_fwd_impl(r2l_raw_u16(raw, denom), black_level, out, B, H, W, reduce_size, out_channels,
+                              stream);
+}
+int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const double* camera_host,
+                   int debayer, int sharpening, int denoising, double gamma, void* stream) {
+  return r2l_static_fwd_impl(r2l_raw_f32(raw), out, B, H, W, camera_host, debayer, sharpening, denoising, gamma,
+                             stream);
+}
+int r2l_static_fwd_u16(const unsigned short* raw, float denom, float* out, int B, int H, int W,
+                       const double* camera_host, int debayer, int sharpening, int denoising, double gamma,
+                       void* stream) {
+  return r2l_static_fwd_impl(r2l_raw_u16(raw, denom), out, B, H, W, camera_host, debayer, sharpening, denoising,
+                             gamma, stream);
 }
 
 // ---- staged (track_stages=True) entry points -------------------------------------------------------
@@ -587,7 +676,7 @@ int r2l_stage_point(int op, const float* x, const float* g, const float* w, cons
                     const float* aux2, float* y, float* sums6, void* workspace, size_t workspace_bytes,
                     int B, int H, int W, void* stream) {
   if (int e = r2l_check_dims(B, H, W)) return e;
-  if (op < 0 || op > 7) return r2l_fail(-1, "r2l_stage_point: unknown op");
+  if (op < 0 || op > 8) return r2l_fail(-1, "r2l_stage_point: unknown op");
   const bool reduces = (op == 3 || op == 7);
   if (reduces && (!sums6 || !workspace || workspace_bytes < r2l_stage_workspace_bytes()))
     return r2l_fail(-2, "r2l_stage_point: reduction needs sums + workspace");

@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/r2l_isp.h"
 
@@ -17,6 +18,7 @@
 
 #ifdef R2L_EMUL
 #define R2L_HD static inline
+#define R2L_HOSTDEV static inline
 #define R2L_MEMBER inline
 #define R2L_BLOCKFN static inline
 struct alignas(16) r2l_f4 {
@@ -40,6 +42,7 @@ R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
 #else
 #include <hip/hip_runtime.h>
 #define R2L_HD static __device__ __forceinline__
+#define R2L_HOSTDEV static __host__ __device__ __forceinline__
 #define R2L_MEMBER __device__ __forceinline__
 #define R2L_BLOCKFN static __device__ __forceinline__
 typedef float4 r2l_f4;
@@ -126,6 +129,67 @@ R2L_HD double r2l_load_coherent(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
+
+// ---- raw frames: float32 in [0,1], or the sensor's 16-bit containers normalised on the fly ---------------
+// The reference divides the loaded container values by 2**bits - 1 in float32 (dataset.py:86-87, :140-143;
+// utils/dataset_utils.py:18-26).  With u16 != null the kernels read the containers themselves (2 B/px instead
+// of 4) and apply that division when a value enters LDS / the register window: q0 = u * (1/d), one residual
+// step e = fma(-q0, d, u), q = fma(e, 1/d, q0) -- equal to the correctly rounded float32 quotient u / d for
+// every 16-bit u and d = 65535, 4095, 1023, 255 (checked exhaustively by the tests).
+struct R2LRaw {
+  const float* f32;
+  const unsigned short* u16;
+  float denom, rdenom;
+};
+R2L_HOSTDEV R2LRaw r2l_raw_f32(const float* p) {
+  R2LRaw r;
+  r.f32 = p;
+  r.u16 = nullptr;
+  r.denom = r.rdenom = 1.f;
+  return r;
+}
+R2L_HOSTDEV R2LRaw r2l_raw_u16(const unsigned short* p, float denom) {
+  R2LRaw r;
+  r.f32 = nullptr;
+  r.u16 = p;
+  r.denom = denom;
+  r.rdenom = 1.0f / denom;
+  return r;
+}
+R2L_HD float r2l_raw_decode(unsigned u, const R2LRaw& r) {
+  const float uf = (float)u;
+  const float q0 = uf * r.rdenom;
+  const float e = fmaf(-q0, r.denom, uf);
+  return fmaf(e, r.rdenom, q0);
+}
+// element i / the aligned 4-element chunk starting at element i of a raw buffer, as float32
+R2L_HD float r2l_raw_elem(const R2LRaw& r, size_t i) { return r.u16 ? r2l_raw_decode(r.u16[i], r) : r.f32[i]; }
+R2L_HD r2l_f4 r2l_raw_vec4(const R2LRaw& r, size_t i) {
+  r2l_f4 v;
+  if (r.u16) {
+    const r2l_f2 b = *(const r2l_f2*)(r.u16 + i);
+    unsigned lo, hi;
+    memcpy(&lo, &b.x, 4);
+    memcpy(&hi, &b.y, 4);
+    v.x = r2l_raw_decode(lo & 0xffffu, r);
+    v.y = r2l_raw_decode(lo >> 16, r);
+    v.z = r2l_raw_decode(hi & 0xffffu, r);
+    v.w = r2l_raw_decode(hi >> 16, r);
+  } else {
+    v = *(const r2l_f4*)(r.f32 + i);
+  }
+  return v;
+}
+R2L_HD unsigned r2l_f2u(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  return u;
+}
+R2L_HD float r2l_u2f(unsigned u) {
+  float x;
+  memcpy(&x, &u, 4);
+  return x;
+}
 
 // ---- packed pairs ---------------------------------------------------------------------------------
 // Two horizontally adjacent pixels share one v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: on gfx950 a packed

@@ -188,10 +188,59 @@ R2L_HD void r2l_fetch_tile(int tid, const float* gb, const R2LTile& t, int H, in
     r2l_fetch_frame<G, false, MODE>(tid, base, t.oy, t.ox, H, W, pf);
 }
 
+// 16-bit containers: the 4 values of a chunk travel as raw bits in .x/.y of the prefetch register (decoded
+// when they are written to LDS, so that the fetch stays a fire-and-forget load)
+template <class G, bool BORDER>
+R2L_HD void r2l_fetch_frame_u16(int tid, const unsigned short* gb, int oy, int ox, int H, int W,
+                                R2LPrefetch<G>& pf) {
+  R2LChunkWalk<G> w;
+  w.init(tid);
+  const bool vec_ok = (W & 3) == 0;
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < R2LPrefetch<G>::NIT; ++it) {
+    r2l_f2 v;
+    v.x = v.y = 0.f;
+    if (w.fy < G::FH) {
+      const int fy = w.fy, cx = w.cx;
+      const int gx0 = ox - 4 + 4 * cx;
+      if (!BORDER) {
+        v = *(const r2l_f2*)(gb + (size_t)(oy - 4 + fy) * W + gx0);
+      } else {
+        const int gy = r2l_mirror(oy - 4 + fy, H);
+        const unsigned short* row = gb + (size_t)gy * W;
+        if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
+          v = *(const r2l_f2*)(row + gx0);
+        } else {
+          const unsigned a0 = row[r2l_mirror(gx0, W)], a1 = row[r2l_mirror(gx0 + 1, W)];
+          const unsigned a2 = row[r2l_mirror(gx0 + 2, W)], a3 = row[r2l_mirror(gx0 + 3, W)];
+          v.x = r2l_u2f(a0 | (a1 << 16));
+          v.y = r2l_u2f(a2 | (a3 << 16));
+        }
+      }
+    }
+    pf.v[it].x = v.x;
+    pf.v[it].y = v.y;
+    w.next();
+  }
+}
+// raw frame of tile t -> prefetch registers (either container type)
+template <class G, bool U16>
+R2L_HD void r2l_fetch_raw_tile(int tid, const R2LRaw& raw, const R2LTile& t, int H, int W, R2LPrefetch<G>& pf) {
+  if (U16) {
+    const unsigned short* base = raw.u16 + (size_t)t.b * H * W;
+    if (t.border)
+      r2l_fetch_frame_u16<G, true>(tid, base, t.oy, t.ox, H, W, pf);
+    else
+      r2l_fetch_frame_u16<G, false>(tid, base, t.oy, t.ox, H, W, pf);
+  } else {
+    r2l_fetch_tile<G, 0>(tid, raw.f32, t, H, W, pf);
+  }
+}
+
 // registers -> V plane, black level removed (mirror padding keeps the Bayer parity, so the site follows
 // from the frame coordinates)
-template <class G>
-R2L_HD void r2l_store_v(int tid, float* V, R2LFoldedRef F, const R2LPrefetch<G>& pf) {
+template <class G, bool U16>
+R2L_HD void r2l_store_v(int tid, float* V, R2LFoldedRef F, const R2LPrefetch<G>& pf, const R2LRaw& raw) {
   R2LChunkWalk<G> w;
   w.init(tid);
   R2L_PRAGMA_UNROLL
@@ -199,6 +248,13 @@ R2L_HD void r2l_store_v(int tid, float* V, R2LFoldedRef F, const R2LPrefetch<G>&
     if (w.fy < G::FH) {
       const int fy = w.fy, cx = w.cx;
       r2l_f4 v = pf.v[it];
+      if (U16) {
+        const unsigned lo = r2l_f2u(v.x), hi = r2l_f2u(v.y);
+        v.x = r2l_raw_decode(lo & 0xffffu, raw);
+        v.y = r2l_raw_decode(lo >> 16, raw);
+        v.z = r2l_raw_decode(hi & 0xffffu, raw);
+        v.w = r2l_raw_decode(hi >> 16, raw);
+      }
       const float b0 = (fy & 1) ? F.bl[2] : F.bl[0], b1 = (fy & 1) ? F.bl[3] : F.bl[1];
       v.x -= b0;
       v.y -= b1;
@@ -589,7 +645,7 @@ R2L_HD void r2l_chroma_row2(const float vw[3][6], const FT& F, r2l_p2 u[2], r2l_
 // forward
 // ================================================================================================
 struct R2LFwdArgs {
-  const float* raw;       // (B,H,W)
+  R2LRaw raw;             // (B,H,W)
   const float* additive;  // (3,256,256) or null
   const R2LFolded* F;
   const float* bn;      // mean[3], istd[3] or null
@@ -749,7 +805,7 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
   }
 
 
-template <class G, bool ADD, bool MAYBE_RAGGED>
+template <class G, bool ADD, bool MAYBE_RAGGED, bool U16>
 R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* lds) {
   float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
@@ -763,12 +819,12 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 6; ++i) R2L_TREG(regs).acc[i] = r2l_splat2(0.f);
-  if (have) r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
+  if (have) r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   R2L_PHASE_END
   R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN
-    r2l_store_v<G>(tid, V, F, R2L_TREG(pre));
+    r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre), a.raw);
     R2L_PHASE_END
     R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
@@ -790,7 +846,7 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
     R2L_STAMP(3)
     }
     R2L_PHASE_BEGIN
-    if (haven) r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));  // next tile, in flight
+    if (haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));  // next tile, in flight
     R2L_PRIO(R2L_PRIO_PIXELS);
     if (MAYBE_RAGGED && t.ragged)
       r2l_fwd_pixels<G, MAYBE_RAGGED, ADD>(tid, V, YP, a, t, R2L_TREG(regs));
@@ -818,7 +874,7 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
 // backward, kernel B1: everything that is pointwise in the pixel + the blur-weight / chroma sums
 // ================================================================================================
 struct R2LBwd1Args {
-  const float* raw;
+  R2LRaw raw;
   const float* additive;
   const R2LFolded* F;
   const float* bn;      // mean[3], istd[3] or null
@@ -1045,7 +1101,7 @@ R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LB
   }
 }
 
-template <class G, bool ADD, bool MAYBE_RAGGED>
+template <class G, bool ADD, bool MAYBE_RAGGED, bool U16>
 R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* lds) {
   float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
@@ -1064,12 +1120,12 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     int tx_, row_;
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
   }
-  if (have) r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
+  if (have) r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   R2L_PHASE_END
   R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN
-    r2l_store_v<G>(tid, V, F, R2L_TREG(pre));
+    r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre), a.raw);
     R2L_PHASE_END
     R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
@@ -1092,7 +1148,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     R2L_STAMP(3)
     }
     R2L_PHASE_BEGIN
-    if (haven) r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
+    if (haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
     if (MAYBE_RAGGED && t.ragged)
       r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD, false>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
     else
@@ -1110,7 +1166,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
 // backward, kernel B2: adjoint of blur (mirror pad) and sharpen (zero pad) on the luma plane
 // ================================================================================================
 struct R2LBwd2Args {
-  const float* raw;
+  R2LRaw raw;
   const R2LFolded* F;
   const float* gypp;  // (B,H,W) from B1
   float* partial;     // [R2L_B2_NACC][nblk]
@@ -1299,7 +1355,7 @@ R2L_HD void r2l_bwd2_pixels(int tid, const float* V, const float* Y, const float
   }
 }
 
-template <class G>
+template <class G, bool U16>
 R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* lds) {
   float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
   float* G2 = V + G::PLANE;  // dL/dY'' (shifted); dead after the adjoint blur, then holds Y
@@ -1320,14 +1376,14 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
   }
   if (have) {
-    r2l_fetch_tile<G, 0>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre_v));
+    r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre_v));
     r2l_fetch_tile<G, 1>(tid, a.gypp, t, a.H, a.W, R2L_TREG(pre_g));
   }
   R2L_PHASE_END
   R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN
-    r2l_store_v<G>(tid, V, F, R2L_TREG(pre_v));
+    r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre_v), a.raw);
     r2l_store_plane_s2<G>(tid, G2, R2L_TREG(pre_g));
     R2L_PHASE_END
     R2L_STAMP(0)
@@ -1347,7 +1403,7 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     R2L_STAMP(2)
     R2L_PHASE_BEGIN
     if (haven) {
-      r2l_fetch_tile<G, 0>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre_v));
+      r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre_v));
       r2l_fetch_tile<G, 1>(tid, a.gypp, tn, a.H, a.W, R2L_TREG(pre_g));
     }
     if (t.border)

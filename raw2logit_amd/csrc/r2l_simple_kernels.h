@@ -242,7 +242,7 @@ R2L_BLOCKFN void r2l_add_bwd_block(const R2LAddBwdArgs& a, int bid, int nblk, fl
 // ---- raw2rgb (pipeline_torch.py:240-283) -----------------------------------------------------------
 // one lane per pair of horizontally adjacent Bayer quads (4 columns x 2 rows of raw)
 struct R2LRaw2RgbArgs {
-  const float* raw;  // fwd input / (bwd: unused)
+  R2LRaw raw;        // fwd input / (bwd: unused)
   const float* bl;   // 4 floats or null
   float* out;        // fwd output
   const float* gout;  // bwd input
@@ -271,11 +271,10 @@ R2L_BLOCKFN void r2l_raw2rgb_fwd_block(const R2LRaw2RgbArgs& a, int bid, int nbl
     r2l_quadpair_coords(idx, a.H, a.W, b, qy, qx2);
     const int y = 2 * qy, x = 4 * qx2;
     const int nq = (x + 2 < a.W) ? 2 : 1;  // quads in this pair (W even)
-    const float* r0 = a.raw + ((size_t)b * a.H + y) * a.W + x;
-    const float* r1 = r0 + a.W;
+    const size_t r0 = ((size_t)b * a.H + y) * a.W + x, r1 = r0 + a.W;
     for (int q = 0; q < nq; ++q) {
-      const float R = r0[2 * q] - bl[0], G1 = r0[2 * q + 1] - bl[1];
-      const float G2 = r1[2 * q] - bl[2], Bv = r1[2 * q + 1] - bl[3];
+      const float R = r2l_raw_elem(a.raw, r0 + 2 * q) - bl[0], G1 = r2l_raw_elem(a.raw, r0 + 2 * q + 1) - bl[1];
+      const float G2 = r2l_raw_elem(a.raw, r1 + 2 * q) - bl[2], Bv = r2l_raw_elem(a.raw, r1 + 2 * q + 1) - bl[3];
       if (a.reduce_size) {
         const int h2 = a.H / 2, w2 = a.W / 2;
         float* o = a.out + (size_t)b * C * h2 * w2 + (size_t)qy * w2 + (x / 2 + q);

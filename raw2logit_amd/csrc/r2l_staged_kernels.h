@@ -256,6 +256,7 @@ R2L_BLOCKFN void r2l_pconv_bwd_block(const R2LStageArgs& a, int bid, int nblk, f
 // op 4 add fwd: y = x + w[(c,h,w)] (broadcast over B)
 // op 5 bn apply: y = (x - w[c]) * w[3+c]                op 6 bn bwd: y = w[3+c] * (g - aux2[c] - out * aux2[3+c])
 // op 7 bn stats: acc[c] += x - .5, acc[3+c] += (x - .5)^2
+// op 8 normalize: y = (x - w[c]) / w[3+c]  (torchvision T.Normalize(mean, std), train.py:157-171)
 struct R2LPointArgs {
   const float* x;
   const float* g;
@@ -299,6 +300,7 @@ R2L_BLOCKFN void r2l_point_block(const R2LPointArgs& a, int bid, int nblk, float
         } break;
         case 4: o[q] = xv[q] + a.w[(e + q) % (3 * hw)]; break;
         case 5: o[q] = (xv[q] - a.w[c]) * a.w[3 + c]; break;
+        case 8: o[q] = (xv[q] - a.w[c]) / a.w[3 + c]; break;
         case 6: o[q] = a.w[3 + c] * (gv[q] - (a.aux2 ? a.aux2[c] : 0.f) - av[q] * (a.aux2 ? a.aux2[3 + c] : 0.f)); break;
         default: {
           const float d = xv[q] - 0.5f;

@@ -25,7 +25,7 @@ typedef R2LGeom<64, 64> GStatic;
 #define R2L_STATIC_SHORT_LDS_FLOATS (2 * GStatic::PAD + GStatic::PLANE)
 
 struct R2LStaticArgs {
-  const float* raw;
+  R2LRaw raw;
   float* out;
   int B, H, W;
   int debayer, full, sharpen, denoise;
@@ -53,7 +53,7 @@ static inline void r2l_inv3(const double* m, double* o) {
   o[8] = (a * e - b * d) / det;
 }
 
-static inline void r2l_static_setup(R2LStaticArgs& a, const float* raw, float* out, int B, int H, int W,
+static inline void r2l_static_setup(R2LStaticArgs& a, const R2LRaw& raw, float* out, int B, int H, int W,
                                     const double* cam, int debayer, int sharpening, int denoising,
                                     double gamma) {
   // skimage.color yuv_from_rgb (scikit-image 0.18.1); the reference's own copy is
@@ -98,22 +98,22 @@ static inline void r2l_static_setup(R2LStaticArgs& a, const float* raw, float* o
 
 // ---- phase A: raw tile + halo, symmetric ('reflect' of scipy) coordinates, plain float32 -----------
 template <class G>
-R2L_HD void r2l_load_raw_sym(int tid, float* V, const float* rawb, int oy, int ox, int H, int W) {
+R2L_HD void r2l_load_raw_sym(int tid, float* V, const R2LRaw& raw, size_t img0, int oy, int ox, int H, int W) {
   constexpr int CPR = G::FW / 4;
   const bool vec_ok = (W & 3) == 0;
   for (int ci = tid; ci < CPR * G::FH; ci += R2L_NT) {
     const int fy = ci / CPR, cx = ci - fy * CPR;
     const int gy = r2l_symmetric(oy - 4 + fy, H);
     const int gx0 = ox - 4 + 4 * cx;
-    const float* row = rawb + (size_t)gy * W;
+    const size_t row = img0 + (size_t)gy * W;
     r2l_f4 v;
     if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
-      v = *(const r2l_f4*)(row + gx0);
+      v = r2l_raw_vec4(raw, row + gx0);
     } else {
-      v.x = row[r2l_symmetric(gx0, W)];
-      v.y = row[r2l_symmetric(gx0 + 1, W)];
-      v.z = row[r2l_symmetric(gx0 + 2, W)];
-      v.w = row[r2l_symmetric(gx0 + 3, W)];
+      v.x = r2l_raw_elem(raw, row + r2l_symmetric(gx0, W));
+      v.y = r2l_raw_elem(raw, row + r2l_symmetric(gx0 + 1, W));
+      v.z = r2l_raw_elem(raw, row + r2l_symmetric(gx0 + 2, W));
+      v.w = r2l_raw_elem(raw, row + r2l_symmetric(gx0 + 3, W));
     }
     *(r2l_f4*)(V + fy * G::FS + 4 * cx) = v;
   }
@@ -430,9 +430,9 @@ R2L_BLOCKFN void r2l_static_block(const R2LStaticArgs& a, int bid, int nblk, flo
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t;
   while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
-    const float* rawb = a.raw + (size_t)t.b * a.H * a.W;
+    const size_t img0 = (size_t)t.b * a.H * a.W;
     R2L_PHASE_BEGIN
-    r2l_load_raw_sym<G>(tid, V, rawb, t.oy, t.ox, a.H, a.W);
+    r2l_load_raw_sym<G>(tid, V, a.raw, img0, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
     R2L_PHASE_BEGIN
     r2l_static_compute_y<G>(tid, V, Y, a, t.oy, t.ox);
@@ -458,9 +458,9 @@ R2L_BLOCKFN void r2l_static_short_block(const R2LStaticArgs& a, int bid, int nbl
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t;
   while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
-    const float* rawb = a.raw + (size_t)t.b * a.H * a.W;
+    const size_t img0 = (size_t)t.b * a.H * a.W;
     R2L_PHASE_BEGIN
-    r2l_load_raw_sym<G>(tid, V, rawb, t.oy, t.ox, a.H, a.W);
+    r2l_load_raw_sym<G>(tid, V, a.raw, img0, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
     R2L_PHASE_BEGIN
     r2l_static_pixels<G, false>(tid, V, (const double*)nullptr, a, t);

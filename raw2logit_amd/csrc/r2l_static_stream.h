@@ -18,17 +18,30 @@ struct R2LStaticStreamArgs {
   int nseg, nband, band_h, nitems;
 };
 
-// raw values of columns x0-2 .. x0+5 of source row `ys` (symmetric extension at the image edges)
+// raw values of columns x0-2 .. x0+5 of source row `ys` (symmetric extension at the image edges); with 16-bit
+// containers the undecoded bits (v[0] = left pair, v[1..2] = the 4 centre values, v[3] = right pair), decoded
+// when the row enters the window so that the fetch stays a fire-and-forget load
 struct R2LRowStage {
   float v[8];
   int ys;
 };
-R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, const float* img, int ys, int x0, bool le, bool re,
+template <bool U16>
+R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, size_t img0, int ys, int x0, bool le, bool re,
                                  R2LRowStage& st) {
-  const float* r = img + (size_t)ys * a.W + x0;
-  const r2l_f4 c = *(const r2l_f4*)r;
+  const size_t e = img0 + (size_t)ys * a.W + x0;
   float* v = st.v;
   st.ys = ys;
+  if (U16) {
+    const unsigned short* r = a.raw.u16 + e;
+    const r2l_f2 c = *(const r2l_f2*)r;
+    v[1] = c.x;
+    v[2] = c.y;
+    v[0] = le ? 0.f : *(const float*)(r - 2);
+    v[3] = re ? 0.f : *(const float*)(r + 4);
+    return;
+  }
+  const float* r = a.raw.f32 + e;
+  const r2l_f4 c = *(const r2l_f4*)r;
   v[2] = c.x;
   v[3] = c.y;
   v[4] = c.z;
@@ -51,9 +64,24 @@ R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, const float* img, int y
   }
 }
 // staged row -> 8 black-level-corrected float64 values (the black level follows the SOURCE site)
+template <bool U16>
 R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStage& st, bool le, bool re,
                                    double dst[8]) {
-  const float* v = st.v;
+  float v[8];
+  if (U16) {
+    const unsigned l = r2l_f2u(st.v[0]), c0 = r2l_f2u(st.v[1]), c1 = r2l_f2u(st.v[2]), q = r2l_f2u(st.v[3]);
+    v[2] = r2l_raw_decode(c0 & 0xffffu, a.raw);
+    v[3] = r2l_raw_decode(c0 >> 16, a.raw);
+    v[4] = r2l_raw_decode(c1 & 0xffffu, a.raw);
+    v[5] = r2l_raw_decode(c1 >> 16, a.raw);
+    v[0] = le ? v[3] : r2l_raw_decode(l & 0xffffu, a.raw);
+    v[1] = le ? v[2] : r2l_raw_decode(l >> 16, a.raw);
+    v[6] = re ? v[5] : r2l_raw_decode(q & 0xffffu, a.raw);
+    v[7] = re ? v[4] : r2l_raw_decode(q >> 16, a.raw);
+  } else {
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 8; ++i) v[i] = st.v[i];
+  }
   const int ys = st.ys;
   const double be = (ys & 1) ? a.bl[2] : a.bl[0], bo = (ys & 1) ? a.bl[3] : a.bl[1];
   // source column parities: x0-2 even, x0-1 odd, ..., except the mirrored ones (1, 0 | W-1, W-2)
@@ -129,7 +157,7 @@ R2L_HD void r2l_stream_malvar_row(const double* w0, const double* w1, const doub
 }
 
 // one lane's work item: image b, column strip seg (256 columns), row band
-template <int DEB>
+template <int DEB, bool U16>
 R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int lane) {
   const R2LStaticArgs& a = sa.s;
   constexpr int HALO = DEB ? 2 : 1, NR = 2 * HALO + 1;
@@ -141,7 +169,7 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   const int y1 = (y0 + sa.band_h < a.H) ? y0 + sa.band_h : a.H;
   const bool le = x0 == 0, re = x0 + 4 >= a.W;
   const size_t plane = (size_t)a.H * a.W;
-  const float* img = a.raw + (size_t)b * plane;
+  const size_t img = (size_t)b * plane;  // element offset of image b
   float* outb = a.out + (size_t)b * 3 * plane;
   double win[NR][8];
   int par[NR];  // source row parity of each window slot
@@ -150,25 +178,25 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < NR - 1; ++i) {
     const int ys = r2l_symmetric(y0 - HALO + i, a.H);
-    r2l_stream_fetch_row(a, img, ys, x0, le, re, st);
-    r2l_stream_convert_row(a, st, le, re, win[i]);
+    r2l_stream_fetch_row<U16>(a, img, ys, x0, le, re, st);
+    r2l_stream_convert_row<U16>(a, st, le, re, win[i]);
     par[i] = ys & 1;
   }
   // software pipeline, two rows deep: the rows needed by the next TWO output rows are in flight while
   // this one is computed (st = row y+HALO, st2 = row y+HALO+1)
   R2LRowStage st2;
-  r2l_stream_fetch_row(a, img, r2l_symmetric(y0 + HALO, a.H), x0, le, re, st);
-  r2l_stream_fetch_row(a, img, r2l_symmetric(y0 + HALO + 1, a.H), x0, le, re, st2);
+  r2l_stream_fetch_row<U16>(a, img, r2l_symmetric(y0 + HALO, a.H), x0, le, re, st);
+  r2l_stream_fetch_row<U16>(a, img, r2l_symmetric(y0 + HALO + 1, a.H), x0, le, re, st2);
   for (int yb = y0; yb < y1; yb += NR) {
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < NR; ++k) {  // unrolled by the window depth: slot indices are compile-time
       const int y = yb + k;
       if (y < y1) {
         // newest row y + HALO (fetched one iteration ago) goes to slot (k + NR - 1) % NR
-        r2l_stream_convert_row(a, st, le, re, win[(k + NR - 1) % NR]);
+        r2l_stream_convert_row<U16>(a, st, le, re, win[(k + NR - 1) % NR]);
         par[(k + NR - 1) % NR] = st.ys & 1;
         st = st2;
-        if (y + 2 < y1) r2l_stream_fetch_row(a, img, r2l_symmetric(y + 2 + HALO, a.H), x0, le, re, st2);
+        if (y + 2 < y1) r2l_stream_fetch_row<U16>(a, img, r2l_symmetric(y + 2 + HALO, a.H), x0, le, re, st2);
         double d[4][3];
         if (DEB == 0) {
           // interior rows: the tap rows have the checkerboard parities (compile-time after the uniform
@@ -198,12 +226,12 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
 }
 
 #define R2L_STREAM_NT 256  // 4 independent wavefronts per workgroup
-template <int DEB>
+template <int DEB, bool U16>
 R2L_BLOCKFN void r2l_static_stream_block(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {
   (void)lds;
   (void)nblk;
   R2L_PHASE_BEGIN_N(R2L_STREAM_NT)
   const int item = bid * (R2L_STREAM_NT / 64) + (tid >> 6);  // one work item per wavefront
-  if (item < sa.nitems) r2l_static_stream_item<DEB>(sa, item, tid & 63);
+  if (item < sa.nitems) r2l_static_stream_item<DEB, U16>(sa, item, tid & 63);
   R2L_PHASE_END
 }

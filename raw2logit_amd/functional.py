@@ -15,6 +15,19 @@ def _f32c(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+U16_DTYPES = (torch.uint16, torch.int16)   # int16 = the same 16 bits (torch's uint16 support is recent)
+
+
+def _raw_arg(raw, bits, name='raw'):
+    """(tensor, denom | None): float32 frames in [0,1], or the sensor's 16-bit containers with
+    denom = 2**bits - 1 (dataset.py:86-87: the normalisation then happens inside the kernel)."""
+    if raw.dtype in U16_DTYPES:
+        if raw.shape[-1] % 4:
+            raise ValueError('16-bit frames need W % 4 == 0')
+        return (raw if raw.is_contiguous() else raw.contiguous()), float(2 ** int(bits) - 1)
+    return _f32c(raw, name), None
+
+
 def _workspace(lib, like, B, H, W):
     n = lib.r2l_isp_workspace_bytes(B, H, W)
     return torch.empty(n, dtype=torch.uint8, device=like.device), n
@@ -31,8 +44,8 @@ def _group_size(group):
 # --------------------------------------------------------------------------------------------------
 class _Raw2Rgb(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw, black_level, reduce_size, out_channels):
-        raw = _f32c(raw, 'raw')
+    def forward(ctx, raw, black_level, reduce_size, out_channels, bits=16):
+        raw, denom = _raw_arg(raw, bits)
         B, H, W = raw.shape
         lib, stream = _lib.library_for(raw)
         bl = None
@@ -43,8 +56,12 @@ class _Raw2Rgb(torch.autograd.Function):
             out = torch.empty((B, out_channels, H // 2, W // 2), dtype=torch.float32, device=raw.device)
         else:
             out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=raw.device)
-        lib.check(lib.r2l_raw2rgb_fwd(ptr(raw), ptr(bl), ptr(out), B, H, W, int(reduce_size),
-                                      int(out_channels), stream), 'r2l_raw2rgb_fwd')
+        if denom is None:
+            lib.check(lib.r2l_raw2rgb_fwd(ptr(raw), ptr(bl), ptr(out), B, H, W, int(reduce_size),
+                                          int(out_channels), stream), 'r2l_raw2rgb_fwd')
+        else:
+            lib.check(lib.r2l_raw2rgb_fwd_u16(ptr(raw), denom, ptr(bl), ptr(out), B, H, W, int(reduce_size),
+                                              int(out_channels), stream), 'r2l_raw2rgb_fwd_u16')
         ctx.dims = (B, H, W, bool(reduce_size), int(out_channels))
         ctx.has_bl = black_level is not None
         ctx.bl_shape = None if black_level is None else tuple(black_level.shape)
@@ -69,15 +86,21 @@ class _Raw2Rgb(torch.autograd.Function):
                                           int(reduce_size), oc, stream), 'r2l_raw2rgb_bwd')
         if gbl is not None:
             gbl = gbl.to(torch.float32).reshape(ctx.bl_shape)
-        return graw, gbl, None, None
+        return graw, gbl, None, None, None
 
 
 def raw2rgb(raw, black_level=None, reduce_size=True, out_channels=3):
-    """drop-in for processing.pipeline_torch.raw2rgb (:240-283)."""
+    """drop-in for processing.pipeline_torch.raw2rgb (:240-283), same signature.  `raw` may also hold 16-bit
+    containers (uint16 / int16 tensor): they are divided by 2**16 - 1 inside the kernel (dataset.py:86-87);
+    raw2rgb_bits() takes other bit depths."""
+    return raw2rgb_bits(raw, black_level, reduce_size, out_channels, 16)
+
+
+def raw2rgb_bits(raw, black_level=None, reduce_size=True, out_channels=3, bits=16):
     assert out_channels in [3, 4]
     if black_level is not None and not torch.is_tensor(black_level):
         black_level = torch.as_tensor(black_level, dtype=torch.float32, device=raw.device)
-    return _Raw2Rgb.apply(raw, black_level, reduce_size, out_channels)
+    return _Raw2Rgb.apply(raw, black_level, reduce_size, out_channels, bits)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -120,6 +143,12 @@ def bn_finalize(lib, stream, totals, bn_module, eps, momentum, want_moments=True
     return bn, moments
 
 
+def _isp_fwd(lib, raw, denom, *rest):
+    if denom is None:
+        return lib.r2l_isp_fwd(ptr(raw), *rest)
+    return lib.r2l_isp_fwd_u16(ptr(raw), denom, *rest)
+
+
 class _IspFused(torch.autograd.Function):
     """out, batch_moments = f(raw, 7 parameter tensors, M_RGB_2_YUV, M_YUV_2_RGB, additive | None, ...).
 
@@ -128,8 +157,9 @@ class _IspFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, bl, wb, ccm, gamma, deb, sharp, blur, m1, m2, additive, bn_mode, bn_module, eps,
-                momentum, group):
-        raw = _f32c(raw, 'raw')
+                momentum, group, bits=16):
+        raw, denom = _raw_arg(raw, bits)
+        ctx.denom = denom
         params = (bl, wb, ccm, gamma, deb, sharp, blur)
         packed = torch.cat([p.detach().reshape(-1) for p in params] +
                            [m1.reshape(-1), m2.reshape(-1)]).to(torch.float32)
@@ -149,9 +179,8 @@ class _IspFused(torch.autograd.Function):
         ctx.totals = None
         if bn_mode == BN_TRAIN:
             stats = torch.empty(7, dtype=torch.float64, device=dev)
-            lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(packed), ptr(additive), None, None, ptr(stats),
-                                      ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream),
-                      'r2l_isp_fwd(stats)')
+            lib.check(_isp_fwd(lib, raw, denom, ptr(packed), ptr(additive), None, None, ptr(stats),
+                               ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream), 'r2l_isp_fwd(stats)')
             folded = _lib.R2L_F_FOLDED_VALID
             totals = gather_totals(stats, group)
             bn, moments = bn_finalize(lib, stream, totals, bn_module, eps, momentum)
@@ -161,8 +190,8 @@ class _IspFused(torch.autograd.Function):
             var = bn_module.running_var.detach().to(device=dev, dtype=torch.float64)
             bn = torch.cat([mean, torch.rsqrt(var + eps)]).to(torch.float32)
         out = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(out), None,
-                                  ptr(ws), nws, B, H, W, folded, stream), 'r2l_isp_fwd')
+        lib.check(_isp_fwd(lib, raw, denom, ptr(packed), ptr(additive), ptr(bn), ptr(out), None,
+                           ptr(ws), nws, B, H, W, folded, stream), 'r2l_isp_fwd')
         ctx.bn_mode = bn_mode
         ctx.group = group
         ctx.has_additive = additive is not None
@@ -198,9 +227,14 @@ class _IspFused(torch.autograd.Function):
         grads = [None] * 7
         if any(ctx.needs_input_grad[1:8]):
             gp = torch.empty(_lib.R2L_P_NTRAIN, dtype=torch.float32, device=raw.device)
-            lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(bn_bwd),
-                                      ptr(gout), ptr(gp), None, ptr(ws), nws, B, H, W,
-                                      _lib.R2L_F_FOLDED_VALID, stream), 'r2l_isp_bwd')
+            if ctx.denom is None:
+                lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(bn_bwd),
+                                          ptr(gout), ptr(gp), None, ptr(ws), nws, B, H, W,
+                                          _lib.R2L_F_FOLDED_VALID, stream), 'r2l_isp_bwd')
+            else:
+                lib.check(lib.r2l_isp_bwd_u16(ptr(raw), ctx.denom, ptr(packed), ptr(additive), ptr(bn),
+                                              ptr(bn_bwd), ptr(gout), ptr(gp), ptr(ws), nws, B, H, W,
+                                              _lib.R2L_F_FOLDED_VALID, stream), 'r2l_isp_bwd_u16')
             for i, ((_, off, n), shape) in enumerate(zip(PARAM_LAYOUT, ctx.shapes)):
                 if ctx.needs_input_grad[1 + i]:
                     grads[i] = gp[off:off + n].view(shape)
@@ -209,7 +243,7 @@ class _IspFused(torch.autograd.Function):
             gadd = torch.empty_like(additive)
             lib.check(lib.r2l_additive_bwd(ptr(gout), ptr(out), ptr(bn), ptr(bn_bwd), ptr(gadd), B, H,
                                            W, stream), 'r2l_additive_bwd')
-        return (None, *grads, None, None, gadd, None, None, None, None, None)
+        return (None, *grads, None, None, gadd, None, None, None, None, None, None)
 
 
 def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
@@ -219,7 +253,7 @@ def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
                            module.gamma_correct, module.debayer.weight, module.sharpening_filter.weight,
                            module.gaussian_blur.weight, module.M_RGB_2_YUV, module.M_YUV_2_RGB,
                            module.additive_layer, bn_mode, bn, bn.eps if bn is not None else 1e-5,
-                           bn.momentum if bn is not None else None, group)
+                           bn.momentum if bn is not None else None, group, getattr(module, 'raw_bits', 16))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -231,13 +265,13 @@ _DENOISE = {'gaussian_denoising': 1}
 
 
 def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
-                    denoising='gaussian_denoising', gamma=2.2):
+                    denoising='gaussian_denoising', gamma=2.2, bits=16):
     """(B,H,W) float32 raw on the GPU -> (B,3,H,W) float32, numpy semantics of the reference.
 
     Like the reference's if-chains (pipeline_numpy.py:110-122) a sharpening / denoising string that
     names no algorithm means "skip that stage"; algorithms the reference has but this library does not
     build (menon2007, unsharp_masking, median/fft/... denoising) raise instead of silently differing."""
-    raw = _f32c(raw, 'raw')
+    raw, denom = _raw_arg(raw, bits)
     assert raw.ndim == 3, f"needs dims (B, H, W), got {raw.shape}"
     known_sharp = {'sharpening_filter', 'unsharp_masking'}
     known_den = {'median_denoising', 'gaussian_denoising', 'fft_denoising', 'tv_chambolle', 'tv_bregman',
@@ -253,7 +287,24 @@ def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='shar
     B, H, W = raw.shape
     lib, stream = _lib.library_for(raw)
     out = torch.empty((B, 3, H, W), dtype=torch.float32, device=raw.device)
-    lib.check(lib.r2l_static_fwd(ptr(raw), ptr(out), B, H, W, cam, _DEBAYER[debayer],
-                                 _SHARPEN.get(sharpening, 0), _DENOISE.get(denoising, 0), float(gamma),
-                                 stream), 'r2l_static_fwd')
+    tail = (ptr(out), B, H, W, cam, _DEBAYER[debayer], _SHARPEN.get(sharpening, 0), _DENOISE.get(denoising, 0),
+            float(gamma), stream)
+    if denom is None:
+        lib.check(lib.r2l_static_fwd(ptr(raw), *tail), 'r2l_static_fwd')
+    else:
+        lib.check(lib.r2l_static_fwd_u16(ptr(raw), denom, *tail), 'r2l_static_fwd_u16')
+    return out
+
+
+def normalize(rgb, mean_std):
+    """(x - mean[c]) / std[c] on (B,3,H,W): torchvision's T.Normalize as applied after the static pipeline
+    (train.py:157-171); mean_std = float32[6] on the device of rgb."""
+    rgb = _f32c(rgb, 'rgb')
+    B, C, H, W = rgb.shape
+    assert C == 3
+    lib, stream = _lib.library_for(rgb)
+    ms = _f32c(mean_std.to(rgb.device), 'mean_std')
+    out = torch.empty_like(rgb)
+    lib.check(lib.r2l_stage_point(8, ptr(rgb), None, ptr(ms), None, None, ptr(out), None, None, 0, B, H, W,
+                                  stream), 'r2l_stage_point(normalize)')
     return out

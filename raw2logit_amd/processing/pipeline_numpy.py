@@ -65,7 +65,10 @@ class StaticProcessing(nn.Module):
     """Batched static pipeline as a ``processor`` module: (B,H,W) raw on the GPU -> (B,3,H,W).
 
     Equals RawProcessingPipeline applied to every frame followed by the optional T.Normalize(mean, std)
-    of train.py:157-171.  No trainable parameters, no gradient."""
+    of train.py:157-171.  No trainable parameters, no gradient.  Frames may be float32 in [0,1] or the
+    sensor's 16-bit containers (uint16 / int16 tensors, divided by 2**raw_bits - 1 inside the kernel)."""
+
+    raw_bits = 16
 
     def __init__(self, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
                  denoising='gaussian_denoising', gamma=2.2, mean=None, std=None):
@@ -78,10 +81,10 @@ class StaticProcessing(nn.Module):
         self.stages = None
         self.buffer = None
         if mean is not None:
-            self.register_buffer('mean', torch.as_tensor(mean, dtype=torch.float32).reshape(1, 3, 1, 1))
-            self.register_buffer('std', torch.as_tensor(std, dtype=torch.float32).reshape(1, 3, 1, 1))
+            self.register_buffer('mean_std', torch.cat([torch.as_tensor(mean, dtype=torch.float32).reshape(3),
+                                                        torch.as_tensor(std, dtype=torch.float32).reshape(3)]))
         else:
-            self.mean = self.std = None
+            self.mean_std = None
 
     @torch.no_grad()
     def forward(self, raw):
@@ -89,8 +92,8 @@ class StaticProcessing(nn.Module):
         self.stages = {}
         self.buffer = {}
         rgb = F_.static_pipeline(raw, self.camera_parameters, self.debayer, self.sharpening,
-                                 self.denoising, self.gamma)
-        if self.mean is not None:
-            rgb = (rgb - self.mean) / self.std
+                                 self.denoising, self.gamma, bits=self.raw_bits)
+        if self.mean_std is not None:
+            rgb = F_.normalize(rgb, self.mean_std)
         self.buffer['processed_rgb'] = rgb
         return rgb

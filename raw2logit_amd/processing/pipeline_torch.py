@@ -44,7 +44,12 @@ DEFAULT_CAMERA_PARAMS = (
 
 
 class RawToRGB(nn.Module):
-    """reference :43-80 -- raw (B,H,W) -> packed / zero-filled RGB via the raw2rgb kernel."""
+    """reference :43-80 -- raw (B,H,W) -> packed / zero-filled RGB via the raw2rgb kernel.
+
+    Frames may also be the sensor's 16-bit containers (uint16 / int16 tensors): they are divided by
+    2**raw_bits - 1 inside the kernel, which is what the reference's datasets do on the host (dataset.py:86-87)."""
+
+    raw_bits = 16
 
     def __init__(self, reduce_size=True, out_channels=3, track_stages=False, normalize_mosaic=None):
         super().__init__()
@@ -59,7 +64,7 @@ class RawToRGB(nn.Module):
         self.stages = {}
         self.buffer = {}
 
-        rgb = raw2rgb(raw, reduce_size=self.reduce_size, out_channels=self.out_channels)
+        rgb = F_.raw2rgb_bits(raw, None, self.reduce_size, self.out_channels, self.raw_bits)
         self.stages['demosaic'] = rgb
         if self.normalize_mosaic:
             rgb = self.normalize_mosaic(rgb)
@@ -77,6 +82,8 @@ class NNProcessing(nn.Module):
     """reference :83-126.  Only the raw2rgb front end is on this library's hot path; the U-Net++ body
     is the third-party segmentation_models_pytorch model the reference uses (SURVEY.md section 8a, a12:
     out of scope) and must be installed for this class to be constructed."""
+
+    raw_bits = 16
 
     def __init__(self, track_stages=False, normalize_mosaic=None, batch_norm_output=True):
         super().__init__()
@@ -101,7 +108,7 @@ class NNProcessing(nn.Module):
         self.stages = {}
         self.buffer = {}
 
-        rgb = raw2rgb(raw)
+        rgb = F_.raw2rgb_bits(raw, bits=self.raw_bits)
         if self.normalize_mosaic:
             rgb = self.normalize_mosaic(rgb)
         self.stages['demosaic'] = rgb
@@ -150,7 +157,11 @@ class ParametrizedProcessing(nn.Module):
     Extra attribute (not in the reference): ``process_group`` -- when set to a torch.distributed group of
     more than one rank, BatchNorm batch statistics (forward) and their backward sums are exchanged over
     RCCL so that every rank normalises with the statistics of the GLOBAL batch, which is what the
-    single-GPU reference computes for that batch."""
+    single-GPU reference computes for that batch.  ``raw_bits`` -- frames given as
+    uint16 / int16 tensors (the sensor's 16-bit containers) are divided by 2**raw_bits - 1 inside the kernels,
+    bit-identically to the host-side normalisation of the reference's datasets (dataset.py:86-87)."""
+
+    raw_bits = 16
 
     def __init__(self, camera_parameters=None, track_stages=False, batch_norm_output=True):
         super().__init__()

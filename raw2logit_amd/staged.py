@@ -9,7 +9,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import ptr
-from .functional import raw2rgb, _f32c, _group_size, gather_totals, bn_finalize
+from .functional import raw2rgb_bits, _f32c, _group_size, gather_totals, bn_finalize
 
 
 def _ws(lib, like):
@@ -240,7 +240,7 @@ class _BatchNorm(torch.autograd.Function):
 def staged_forward(module, raw):
     """The body of ParametrizedProcessing.forward (:183-217), stage by stage; fills module.stages."""
     m = module
-    rgb = raw2rgb(raw, black_level=m.black_level, reduce_size=False)                      # :183
+    rgb = raw2rgb_bits(raw, m.black_level, False, 3, getattr(m, 'raw_bits', 16))          # :183
     m.stages['demosaic'] = rgb
     rgb = _Conv33.apply(rgb, m.debayer.weight)                                           # :187
     rgb = _Mix3.apply(rgb, torch.diag(m.white_balance.reshape(3)))                       # :190

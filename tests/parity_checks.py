@@ -236,6 +236,53 @@ def check_grid_independence(device, B=40, H=64, W=64):
             assert np.abs(g1[n] - g0[n]).max() <= 2e-4 * (np.abs(g0[n]).max() + 1e-6), (env, n)
 
 
+def check_u16_ingest(device):
+    """16-bit containers normalised inside the kernels: the in-kernel division must be the
+    correctly rounded float32 quotient for EVERY code (so that the 16-bit entry points are bit-identical to the
+    float32 ones fed with the reference's host-side `img / (2**bits - 1)`, dataset.py:86-87)."""
+    codes = np.arange(65536, dtype=np.uint16).reshape(1, 256, 256)
+    for bits in (16, 12, 10, 8):
+        want = codes.astype(np.float32) / np.float32(2 ** bits - 1)      # numpy float32 division: exact rounding
+        for as_int16 in (False, True):
+            t = torch.from_numpy(codes.view(np.int16) if as_int16 else codes).to(device)
+            got = F_.raw2rgb_bits(t, None, False, 4, bits).sum(1).cpu().numpy()
+            assert np.array_equal(got, want), (bits, np.abs(got - want).max())
+    # fused forward + backward, BatchNorm train, an additive layer off: identical bits to the float32 path
+    B, H, W = 3, 64, 136
+    rng = np.random.default_rng(21)
+    u = rng.integers(0, 4096, (B, H, W)).astype(np.uint16)
+    rawf = torch.from_numpy(u.astype(np.float32) / np.float32(4095)).to(device)
+    rawu = torch.from_numpy(u).to(device)
+    cot = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(device)
+    outs = []
+    for raw in (rawf, rawu):
+        m = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).to(device).train()
+        m.raw_bits = 12
+        y = m(raw)
+        (y * cot).sum().backward()
+        outs.append((y.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for n in outs[0][1]:
+        assert torch.equal(outs[0][1][n], outs[1][1][n]), n
+    # staged kernels (track_stages) take 16-bit frames through raw2rgb
+    mt = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, track_stages=True, batch_norm_output=False).to(device)
+    mt.raw_bits = 12
+    with torch.no_grad():
+        assert torch.equal(mt(rawu), mt(rawf))
+    # static pipelines: row-streaming kernels (bilinear, Malvar) and the tile kernel (full chain), + Normalize
+    for deb, sh, dn in (('bilinear', 'none', 'none'), ('malvar2004', 'none', 'none'),
+                        ('bilinear', 'sharpening_filter', 'gaussian_denoising')):
+        a = F_.static_pipeline(rawf, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
+        b = F_.static_pipeline(rawu, orc.DRONE_CAMERA_PARAMS, deb, sh, dn, bits=12)
+        assert torch.equal(a, b), (deb, sh, dn)
+    mean, std = [0.3, 0.4, 0.5], [0.2, 0.25, 0.3]
+    sp = ppn.StaticProcessing(orc.DRONE_CAMERA_PARAMS, mean=mean, std=std).to(device)
+    sp.raw_bits = 12
+    ref = (F_.static_pipeline(rawf, orc.DRONE_CAMERA_PARAMS).cpu() -
+           torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    assert torch.equal(sp(rawu).cpu(), ref)
+
+
 def check_harness(golden, device):
     """LitModel-style composition (processor -> classifier -> CE loss -> Adam step, model.py:77-146):
     logits, loss and the ISP parameters after one optimiser step must match what the REFERENCE processor

@@ -52,3 +52,7 @@ GRAD_RAW_CASES = [c for c in PARAM_CASES if not c['track'] and c['name'] in (
 @pytest.mark.parametrize('case', GRAD_RAW_CASES, ids=[c['name'] for c in GRAD_RAW_CASES])
 def test_frames_requiring_grad_take_the_staged_kernels(case, golden, emulation):
     pc.check_staged_case(case, golden, 'cpu')
+
+
+def test_16bit_containers_are_bit_identical_to_host_normalised_frames(emulation):
+    pc.check_u16_ingest('cpu')
