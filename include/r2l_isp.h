@@ -147,12 +147,18 @@ int r2l_additive_bwd(const float *grad_out, const float *out, const float *bn_me
 
 /* ---- static pipeline, numpy semantics (processing(), processing/pipeline_numpy.py:70-141, batched):
  * remove_blacklv (:152-158) -> demosaicing_CFA_Bayer_{bilinear,Malvar2004} (:92-95) -> wb (:161-162) ->
- * CCM (:165-167) -> [sharpening_filter (:180-191)] -> [gaussian_denoising (:203-209)] -> clip[0,1] (:138)
- * -> x**(1/gamma) (:241-244).  Linear part in float64 like the reference, output (B,3,H,W) float32
- * (RawProcessingPipeline.__call__, :55-67).  camera_host: double[16] = black_level[4],
- * white_balance[3], colour_matrix[9] (host memory).                                             */
+ * CCM (:165-167) -> [sharpening_filter (:180-191)] -> [gaussian_denoising (:203-209) | median_denoising
+ * (:194-200)] -> clip[0,1] (:138) -> x**(1/gamma) (:241-244).  Linear part in float64 like the reference,
+ * output (B,3,H,W) float32 (RawProcessingPipeline.__call__, :55-67).  camera_host: double[16] =
+ * black_level[4], white_balance[3], colour_matrix[9] (host memory).
+ * The short chain (no sharpening, no denoising: BASELINE config 3) and bilinear + sharpening_filter +
+ * gaussian_denoising (the defaults of train.py:96-101) are single launches; the other combinations run as
+ * float64 luma-plane passes and need r2l_static_workspace_bytes() of device memory (0 for the fused ones;
+ * workspace may then be NULL) and W % 4 == 0.                                                          */
+size_t r2l_static_workspace_bytes(int B, int H, int W, int debayer, int sharpening, int denoising);
 int r2l_static_fwd(const float *raw, float *out, int B, int H, int W, const double *camera_host,
-                   int debayer, int sharpening, int denoising, double gamma, void *stream);
+                   int debayer, int sharpening, int denoising, double gamma, void *workspace,
+                   size_t workspace_bytes, void *stream);
 
 /* ---- 16-bit ingest.  The reference's datasets deliver the sensor's 16-bit
  * containers and normalise them on the host: img = load_image(path) / (2**bits - 1), float32
@@ -171,7 +177,7 @@ int r2l_raw2rgb_fwd_u16(const unsigned short *raw, float denom, const float *bla
                         int H, int W, int reduce_size, int out_channels, void *stream);
 int r2l_static_fwd_u16(const unsigned short *raw, float denom, float *out, int B, int H, int W,
                        const double *camera_host, int debayer, int sharpening, int denoising, double gamma,
-                       void *stream);
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- staged execution (track_stages=True, pipeline_torch.py:197-221): one entry point per materialised
  * stage, each with its VJP, so that autograd can hold every stage tensor (retain_grad) and d/d raw exists.

@@ -62,7 +62,8 @@ _SIGNATURES = {
                             [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     'r2l_static_fwd_u16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, _c_float_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
-                                          ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
+                                          ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.c_void_p]),
     'r2l_stage_workspace_bytes': (ctypes.c_size_t, []),
     'r2l_stage_conv33_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'r2l_stage_conv33_bwd': (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_void_p, ctypes.c_size_t] +
@@ -75,9 +76,11 @@ _SIGNATURES = {
                             [ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'r2l_stage_point': (ctypes.c_int, [ctypes.c_int] + [_c_float_p] * 7 + [ctypes.c_void_p, ctypes.c_size_t] +
                         [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    'r2l_static_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 6),
     'r2l_static_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
-                                      ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
+                                      ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -13,6 +13,7 @@
 #include "r2l_simple_kernels.h"
 #include "r2l_static_kernels.h"
 #include "r2l_static_stream.h"
+#include "r2l_static_planes.h"
 #include "r2l_staged_kernels.h"
 
 static thread_local std::string r2l_err;
@@ -156,14 +157,23 @@ R2L_KERNEL(r2l_launch_add_bwd, R2LAddBwdArgs, r2l_add_bwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_fwd, R2LRaw2RgbArgs, r2l_raw2rgb_fwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_bwd, R2LRaw2RgbArgs, r2l_raw2rgb_bwd_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L_STATIC_LDS_FLOATS)
-#define R2L_STREAM_BLOCK(name, DEB, U16)                                                                 \
+#define R2L_STREAM_BLOCK(name, DEB, U16, LUMA)                                                           \
   R2L_BLOCKFN void name(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {                  \
-    r2l_static_stream_block<DEB, U16>(sa, bid, nblk, lds);                                               \
+    r2l_static_stream_block<DEB, U16, LUMA>(sa, bid, nblk, lds);                                         \
   }
-R2L_STREAM_BLOCK(r2l_stream_block_bilinear, 0, false)
-R2L_STREAM_BLOCK(r2l_stream_block_malvar, 1, false)
-R2L_STREAM_BLOCK(r2l_stream_block_bilinear_u16, 0, true)
-R2L_STREAM_BLOCK(r2l_stream_block_malvar_u16, 1, true)
+R2L_STREAM_BLOCK(r2l_stream_block_bilinear, 0, false, false)
+R2L_STREAM_BLOCK(r2l_stream_block_malvar, 1, false, false)
+R2L_STREAM_BLOCK(r2l_stream_block_bilinear_u16, 0, true, false)
+R2L_STREAM_BLOCK(r2l_stream_block_malvar_u16, 1, true, false)
+R2L_STREAM_BLOCK(r2l_stream_block_bilinear_luma, 0, false, true)
+R2L_STREAM_BLOCK(r2l_stream_block_malvar_luma, 1, false, true)
+R2L_STREAM_BLOCK(r2l_stream_block_bilinear_luma_u16, 0, true, true)
+R2L_STREAM_BLOCK(r2l_stream_block_malvar_luma_u16, 1, true, true)
+R2L_KERNEL_NT(r2l_launch_static_luma_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma, R2L_STREAM_NT, 4)
+R2L_KERNEL_NT(r2l_launch_static_luma_malvar, R2LStaticStreamArgs, r2l_stream_block_malvar_luma, R2L_STREAM_NT, 3)
+R2L_KERNEL_NT(r2l_launch_static_luma_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma_u16, R2L_STREAM_NT, 4)
+R2L_KERNEL_NT(r2l_launch_static_luma_malvar_u16, R2LStaticStreamArgs, r2l_stream_block_malvar_luma_u16, R2L_STREAM_NT, 3)
+R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
 R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear, R2L_STREAM_NT, 4)
 R2L_KERNEL_NT(r2l_launch_static_stream_malvar, R2LStaticStreamArgs, r2l_stream_block_malvar, R2L_STREAM_NT, 3)
 R2L_KERNEL_NT(r2l_launch_static_stream_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_u16, R2L_STREAM_NT, 4)
@@ -510,8 +520,29 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
   return 0;
 }
 
+// chains the single-launch kernels cover: the short chain (any demosaic) and bilinear + sharpening_filter +
+// gaussian_denoising; everything else runs as luma-plane passes and needs two float64 planes of workspace
+static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoising) {
+  if (sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE) return true;
+  (void)W;
+  return debayer == R2L_DEBAYER_BILINEAR && sharpening == R2L_SHARPEN_FILTER && denoising == R2L_DENOISE_GAUSSIAN;
+}
+static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W) {
+  // one wavefront per (image, 256-column strip, row band); enough bands for ~16 wavefronts per CU, at least
+  // 16 rows each so the 2-4 halo rows re-read per band stay cheap
+  sa.nseg = (W + 255) / 256;
+  const long want = 256L * 16 * 2;
+  long nband = (want + (long)B * sa.nseg - 1) / ((long)B * sa.nseg);
+  nband = r2l_env_int("R2L_STREAM_BANDS", (int)nband);
+  if (nband > H / 16) nband = H / 16;
+  if (nband < 1) nband = 1;
+  sa.band_h = (int)((H + nband - 1) / nband);
+  sa.nband = (H + sa.band_h - 1) / sa.band_h;
+}
+
 static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int W, const double* camera_host,
-                               int debayer, int sharpening, int denoising, double gamma, void* stream) {
+                               int debayer, int sharpening, int denoising, double gamma, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (int e = r2l_check_raw(raw, W, "r2l_static_fwd")) return e;
   if (!out || !camera_host) return r2l_fail(-1, "r2l_static_fwd: null pointer");
@@ -519,31 +550,73 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     return r2l_fail(-1, "r2l_static_fwd: unknown debayer");
   if (sharpening != R2L_SHARPEN_NONE && sharpening != R2L_SHARPEN_FILTER)
     return r2l_fail(-1, "r2l_static_fwd: unknown sharpening");
-  if (denoising != R2L_DENOISE_NONE && denoising != R2L_DENOISE_GAUSSIAN)
-    return r2l_fail(-4, "r2l_static_fwd: only gaussian_denoising (or none) is built on the device");
+  if (denoising != R2L_DENOISE_NONE && denoising != R2L_DENOISE_GAUSSIAN && denoising != R2L_DENOISE_MEDIAN)
+    return r2l_fail(-4, "r2l_static_fwd: denoising must be none, gaussian_denoising or median_denoising");
   if (!(gamma > 0)) return r2l_fail(-1, "r2l_static_fwd: gamma must be > 0");
   R2LStaticArgs a;
   r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma);
   const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
-  if (a.full && debayer == R2L_DEBAYER_MALVAR2004)
-    return r2l_fail(-4, "r2l_static_fwd: Malvar2004 + sharpening/denoising (halo 5) is not built yet");
+  if (!r2l_static_is_fused(W, debayer, sharpening, denoising)) {
+    // luma-plane passes: raw -> Y | sharpen | denoise | raw + Y'' -> RGB
+    if (W & 3) return r2l_fail(-4, "r2l_static_fwd: this chain runs as plane passes, which need W % 4 == 0");
+    const size_t plane_bytes = sizeof(double) * (size_t)B * H * W;
+    if (!workspace || workspace_bytes < 2 * plane_bytes)
+      return r2l_fail(-2, "r2l_static_fwd: workspace too small (r2l_static_workspace_bytes)");
+    double* p0 = (double*)workspace;
+    double* p1 = p0 + (size_t)B * H * W;
+    R2LStaticStreamArgs sa;
+    sa.s = a;
+    r2l_stream_shape(sa, B, H, W);
+    const long nitems = (long)B * sa.nseg * sa.nband;
+    if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_static_fwd: batch too large");
+    sa.nitems = (int)nitems;
+    const int wpb = R2L_STREAM_NT / 64;
+    const int sgrid = (int)((nitems + wpb - 1) / wpb);
+    auto stream_pass = [&](const R2LStaticStreamArgs& x) {
+      if (raw.u16)
+        return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_luma_malvar_u16(x, sgrid, stream)
+                                                 : r2l_launch_static_luma_bilinear_u16(x, sgrid, stream);
+      return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_luma_malvar(x, sgrid, stream)
+                                               : r2l_launch_static_luma_bilinear(x, sgrid, stream);
+    };
+    sa.luma_out = p0;
+    sa.luma_in = nullptr;
+    if (int e = stream_pass(sa)) return e;
+    double* cur = p0;
+    double* other = p1;
+    const int ops[2] = {sharpening == R2L_SHARPEN_FILTER ? 1 : 0,
+                        denoising == R2L_DENOISE_GAUSSIAN ? 2 : (denoising == R2L_DENOISE_MEDIAN ? 3 : 0)};
+    for (int i = 0; i < 2; ++i) {
+      if (!ops[i]) continue;
+      R2LPlaneArgs pa;
+      pa.src = cur;
+      pa.dst = other;
+      pa.B = B;
+      pa.H = H;
+      pa.W = W;
+      pa.op = ops[i];
+      for (int k = 0; k < 5; ++k) pa.gk[k] = a.gk[k];
+      size_t g = ((size_t)B * H * W / 2 + R2L_NT - 1) / R2L_NT;
+      if (g > 16384) g = 16384;
+      if (int e = r2l_launch_plane_filter(pa, (int)g, stream)) return e;
+      double* t = cur;
+      cur = other;
+      other = t;
+    }
+    sa.luma_out = nullptr;
+    sa.luma_in = cur;
+    return stream_pass(sa);
+  }
   if (a.full) {
     const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC_FULL", 256));
     return r2l_launch_static_full(a, grid, stream);
   }
   if ((W & 3) == 0 && !r2l_env_int("R2L_STATIC_TILED", 0)) {
-    // row-streaming kernel: one wavefront per (image, 256-column strip, row band); enough bands for
-    // ~16 wavefronts per CU, at least 16 rows each so the 2-4 halo rows re-read per band stay cheap
     R2LStaticStreamArgs sa;
     sa.s = a;
-    sa.nseg = (W + 255) / 256;
-    const long want = 256L * 16 * 2;
-    long nband = (want + (long)B * sa.nseg - 1) / ((long)B * sa.nseg);
-    nband = r2l_env_int("R2L_STREAM_BANDS", (int)nband);
-    if (nband > H / 16) nband = H / 16;
-    if (nband < 1) nband = 1;
-    sa.band_h = (int)((H + nband - 1) / nband);
-    sa.nband = (H + sa.band_h - 1) / sa.band_h;
+    sa.luma_out = nullptr;
+    sa.luma_in = nullptr;
+    r2l_stream_shape(sa, B, H, W);
     const long nitems = (long)B * sa.nseg * sa.nband;
     if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_static_fwd: batch too large");
     sa.nitems = (int)nitems;
@@ -594,16 +667,21 @@ int r2l_raw2rgb_fwd_u16(const unsigned short* raw, float denom, const float* bla
   return r2l_raw2rgb_fwd_impl(r2l_raw_u16(raw, denom), black_level, out, B, H, W, reduce_size, out_channels,
                               stream);
 }
+size_t r2l_static_workspace_bytes(int B, int H, int W, int debayer, int sharpening, int denoising) {
+  if (B < 1 || H < 1 || W < 1 || r2l_static_is_fused(W, debayer, sharpening, denoising)) return 0;
+  return 2 * sizeof(double) * (size_t)B * H * W;
+}
 int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const double* camera_host,
-                   int debayer, int sharpening, int denoising, double gamma, void* stream) {
+                   int debayer, int sharpening, int denoising, double gamma, void* workspace,
+                   size_t workspace_bytes, void* stream) {
   return r2l_static_fwd_impl(r2l_raw_f32(raw), out, B, H, W, camera_host, debayer, sharpening, denoising, gamma,
-                             stream);
+                             workspace, workspace_bytes, stream);
 }
 int r2l_static_fwd_u16(const unsigned short* raw, float denom, float* out, int B, int H, int W,
                        const double* camera_host, int debayer, int sharpening, int denoising, double gamma,
-                       void* stream) {
+                       void* workspace, size_t workspace_bytes, void* stream) {
   return r2l_static_fwd_impl(r2l_raw_u16(raw, denom), out, B, H, W, camera_host, debayer, sharpening, denoising,
-                             gamma, stream);
+                             gamma, workspace, workspace_bytes, stream);
 }
 
 // ---- staged (track_stages=True) entry points -------------------------------------------------------

@@ -724,6 +724,9 @@ R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, in
         st.y = x[0][1];
         st.z = x[1][0];
         st.w = x[1][1];
+#ifdef R2L_EXP_NOSTORE
+        if (st.x == 123456.0f)
+#endif
         *(r2l_f4*)(ob + off) = st;
       } else {
         R2L_PRAGMA_UNROLL

@@ -1,0 +1,77 @@
+// r2l_static_planes.h -- luma-plane filters of the multi-pass static chains (numpy semantics, float64).
+//
+// The static alternates the reference offers on the Y channel (pipeline_numpy.py:110-122, :180-209):
+//   op 1  sharpening_filter   convolve2d(Y, [[0,-1,0],[-1,5,-1],[0,-1,0]], 'same', fill 0)          :180-191
+//   op 2  gaussian_denoising  scipy.ndimage.gaussian_filter(Y, 0.5): 5 taps per axis, 'reflect'        :203-209
+//   op 3  median_denoising    scipy.ndimage.median_filter(Y, 3): 3x3, 'reflect'                        :194-200
+// One lane per pixel pair, neighbours straight from global memory (the plane is L2-resident per row band);
+// borders by index arithmetic (scipy 'reflect' = symmetric: b a | a b).  These chains are the long tail of
+// `--sp_*` sweeps, not the throughput configuration (that one is fused: r2l_static_stream.h).
+#pragma once
+#include "r2l_static_kernels.h"
+
+struct R2LPlaneArgs {
+  const double* src;  // (B,H,W)
+  double* dst;
+  int B, H, W, op;
+  double gk[5];
+};
+R2L_HD void r2l_cswap(double& a, double& b) {
+  const double lo = fmin(a, b), hi = fmax(a, b);
+  a = lo;
+  b = hi;
+}
+// median of 9 (19 compare-exchanges)
+R2L_HD double r2l_median9(double p[9]) {
+  r2l_cswap(p[1], p[2]); r2l_cswap(p[4], p[5]); r2l_cswap(p[7], p[8]);
+  r2l_cswap(p[0], p[1]); r2l_cswap(p[3], p[4]); r2l_cswap(p[6], p[7]);
+  r2l_cswap(p[1], p[2]); r2l_cswap(p[4], p[5]); r2l_cswap(p[7], p[8]);
+  r2l_cswap(p[0], p[3]); r2l_cswap(p[5], p[8]); r2l_cswap(p[4], p[7]);
+  r2l_cswap(p[3], p[6]); r2l_cswap(p[1], p[4]); r2l_cswap(p[2], p[5]);
+  r2l_cswap(p[4], p[7]); r2l_cswap(p[4], p[2]); r2l_cswap(p[6], p[4]);
+  r2l_cswap(p[4], p[2]);
+  return p[4];
+}
+R2L_HD double r2l_plane_px(const R2LPlaneArgs& a, const double* img, int y, int x) {
+  if (a.op == 1) {  // zero-filled 5-point stencil (the kernel is symmetric: convolution == correlation)
+    const double c = img[(size_t)y * a.W + x];
+    const double n = y > 0 ? img[(size_t)(y - 1) * a.W + x] : 0.0;
+    const double s = y < a.H - 1 ? img[(size_t)(y + 1) * a.W + x] : 0.0;
+    const double w = x > 0 ? img[(size_t)y * a.W + x - 1] : 0.0;
+    const double e = x < a.W - 1 ? img[(size_t)y * a.W + x + 1] : 0.0;
+    return 5.0 * c - n - s - w - e;
+  }
+  if (a.op == 2) {  // axis 0 first, then axis 1, each as scipy's symmetric correlate1d
+    double t[5];
+    R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      const int xx = r2l_symmetric(x + j - 2, a.W);
+      const double c = img[(size_t)y * a.W + xx];
+      const double u1 = img[(size_t)r2l_symmetric(y - 1, a.H) * a.W + xx], d1 = img[(size_t)r2l_symmetric(y + 1, a.H) * a.W + xx];
+      const double u2 = img[(size_t)r2l_symmetric(y - 2, a.H) * a.W + xx], d2 = img[(size_t)r2l_symmetric(y + 2, a.H) * a.W + xx];
+      t[j] = a.gk[2] * c + (u1 + d1) * a.gk[1] + (u2 + d2) * a.gk[0];
+    }
+    return a.gk[2] * t[2] + (t[1] + t[3]) * a.gk[1] + (t[0] + t[4]) * a.gk[0];
+  }
+  double p[9];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j)
+    p[i * 3 + j] = img[(size_t)r2l_symmetric(y + i - 1, a.H) * a.W + r2l_symmetric(x + j - 1, a.W)];
+  return r2l_median9(p);
+}
+R2L_BLOCKFN void r2l_plane_filter_block(const R2LPlaneArgs& a, int bid, int nblk, float* lds) {
+  (void)lds;
+  const size_t hw = (size_t)a.H * a.W, n2 = (size_t)a.B * hw / 2;  // W is even
+  R2L_PHASE_BEGIN
+  for (size_t i2 = (size_t)bid * R2L_NT + tid; i2 < n2; i2 += (size_t)nblk * R2L_NT) {
+    const size_t e = i2 * 2;
+    const size_t b = e / hw, r = e - b * hw;
+    const int y = (int)(r / a.W), x = (int)(r - (size_t)y * a.W);
+    const double* img = a.src + b * hw;
+    a.dst[e] = r2l_plane_px(a, img, y, x);
+    a.dst[e + 1] = r2l_plane_px(a, img, y, x + 1);
+  }
+  R2L_PHASE_END
+}

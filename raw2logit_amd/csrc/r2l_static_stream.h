@@ -16,6 +16,11 @@
 struct R2LStaticStreamArgs {
   R2LStaticArgs s;
   int nseg, nband, band_h, nitems;
+  // multi-pass chains (LUMA instantiations): the first pass stops at the luma plane Y = (yuv_from_rgb * CCM *
+  // WB * demosaic)[0] in float64; filter passes (r2l_static_planes.h) rewrite it; the last pass recomputes the
+  // chroma from the raw frame, takes the filtered luma from the plane and finishes (YUV->RGB, clip, gamma)
+  double* luma_out;
+  const double* luma_in;
 };
 
 // raw values of columns x0-2 .. x0+5 of source row `ys` (symmetric extension at the image edges); with 16-bit
@@ -118,6 +123,44 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
   }
 }
 
+// first pass of a multi-pass chain: luma of the 4 pixels -> float64 plane
+R2L_HD void r2l_stream_luma_out_row(const R2LStaticArgs& a, const double d[4][3], double* yplane, size_t off) {
+  double y[4];
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) y[c] = a.T[0] * d[c][0] + a.T[1] * d[c][1] + a.T[2] * d[c][2];
+  double* o = yplane + off;
+  o[0] = y[0];
+  o[1] = y[1];
+  o[2] = y[2];
+  o[3] = y[3];
+}
+// last pass: chroma from the raw frame, filtered luma from the plane; rgb = rgb_from_yuv * (Y'', U, V)
+R2L_HD void r2l_stream_luma_in_row(const R2LStaticArgs& a, const double d[4][3], const double* yplane, float* outb,
+                                   size_t plane, size_t off) {
+  float x[3][4];
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) {
+    const double yy = yplane[off + c];
+    const double u = a.T[3] * d[c][0] + a.T[4] * d[c][1] + a.T[5] * d[c][2];
+    const double v = a.T[6] * d[c][0] + a.T[7] * d[c][1] + a.T[8] * d[c][2];
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      const double rgb = a.M2[k * 3] * yy + a.M2[k * 3 + 1] * u + a.M2[k * 3 + 2] * v;
+      const float xf = (float)fmin(fmax(rgb, 0.0), 1.0);
+      x[k][c] = (xf > 0.f) ? r2l_exp2(r2l_log2(xf) * a.inv_gamma) : 0.f;
+    }
+  }
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) {
+    r2l_f4 st;
+    st.x = x[k][0];
+    st.y = x[k][1];
+    st.z = x[k][2];
+    st.w = x[k][3];
+    *(r2l_f4*)(outb + (size_t)k * plane + off) = st;
+  }
+}
+
 // bilinear row: w0/w1/w2 = window rows y-1, y, y+1 (8 values each); tpy = their source row parities
 R2L_HD void r2l_stream_bilinear_row(const double* w0, const double* w1, const double* w2, const int tpy[3],
                                     bool le, bool re, double d[4][3]) {
@@ -157,7 +200,7 @@ R2L_HD void r2l_stream_malvar_row(const double* w0, const double* w1, const doub
 }
 
 // one lane's work item: image b, column strip seg (256 columns), row band
-template <int DEB, bool U16>
+template <int DEB, bool U16, bool LUMA>
 R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int lane) {
   const R2LStaticArgs& a = sa.s;
   constexpr int HALO = DEB ? 2 : 1, NR = 2 * HALO + 1;
@@ -219,19 +262,24 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
             r2l_stream_malvar_row<0>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], win[(k + 3) % NR],
                                      win[(k + 4) % NR], d);
         }
-        r2l_stream_finish_row(a, d, outb, plane, (size_t)y * a.W + x0);
+        if (LUMA && sa.luma_out)
+          r2l_stream_luma_out_row(a, d, sa.luma_out, img + (size_t)y * a.W + x0);
+        else if (LUMA)
+          r2l_stream_luma_in_row(a, d, sa.luma_in + img, outb, plane, (size_t)y * a.W + x0);
+        else
+          r2l_stream_finish_row(a, d, outb, plane, (size_t)y * a.W + x0);
       }
     }
   }
 }
 
 #define R2L_STREAM_NT 256  // 4 independent wavefronts per workgroup
-template <int DEB, bool U16>
+template <int DEB, bool U16, bool LUMA>
 R2L_BLOCKFN void r2l_static_stream_block(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {
   (void)lds;
   (void)nblk;
   R2L_PHASE_BEGIN_N(R2L_STREAM_NT)
   const int item = bid * (R2L_STREAM_NT / 64) + (tid >> 6);  // one work item per wavefront
-  if (item < sa.nitems) r2l_static_stream_item<DEB, U16>(sa, item, tid & 63);
+  if (item < sa.nitems) r2l_static_stream_item<DEB, U16, LUMA>(sa, item, tid & 63);
   R2L_PHASE_END
 }

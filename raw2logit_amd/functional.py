@@ -261,7 +261,7 @@ def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
 # --------------------------------------------------------------------------------------------------
 _DEBAYER = {'bilinear': 0, 'malvar2004': 1}
 _SHARPEN = {'sharpening_filter': 1}
-_DENOISE = {'gaussian_denoising': 1}
+_DENOISE = {'gaussian_denoising': 1, 'median_denoising': 2}
 
 
 def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
@@ -287,8 +287,10 @@ def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='shar
     B, H, W = raw.shape
     lib, stream = _lib.library_for(raw)
     out = torch.empty((B, 3, H, W), dtype=torch.float32, device=raw.device)
-    tail = (ptr(out), B, H, W, cam, _DEBAYER[debayer], _SHARPEN.get(sharpening, 0), _DENOISE.get(denoising, 0),
-            float(gamma), stream)
+    codes = (_DEBAYER[debayer], _SHARPEN.get(sharpening, 0), _DENOISE.get(denoising, 0))
+    nws = lib.r2l_static_workspace_bytes(B, H, W, *codes)      # 0 for the single-launch chains
+    ws = torch.empty(nws, dtype=torch.uint8, device=raw.device) if nws else None
+    tail = (ptr(out), B, H, W, cam, *codes, float(gamma), ptr(ws), nws, stream)
     if denom is None:
         lib.check(lib.r2l_static_fwd(ptr(raw), *tail), 'r2l_static_fwd')
     else:

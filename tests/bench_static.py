@@ -16,3 +16,11 @@ for deb, sh, dn in (('bilinear', 'none', 'none'), ('malvar2004', 'none', 'none')
     for l in buf.value.decode().splitlines():
         n, c, ms = l.split(); us = 1e3 * float(ms) / int(c)
         print(f'{deb:10s} {sh[:6]:6s} {dn[:6]:6s} {n:36s} {us:9.1f} us  {B*S*S*16/us/1e3:8.1f} GB/s  {B*S*S/us/1e3:7.1f} Gpix/s  ({100*B*S*S*16/us/1e3/8000:.1f} % of 8 TB/s)')
+# the multi-pass chains (luma-plane passes): whole-call time
+import time
+for deb, sh, dn in (('malvar2004', 'sharpening_filter', 'gaussian_denoising'), ('bilinear', 'sharpening_filter', 'median_denoising')):
+    for _ in range(2): F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
+    torch.cuda.synchronize(); us = (time.perf_counter() - t0) / 5 * 1e6
+    print(f'{deb:10s} {sh[:6]:6s} {dn[:6]:6s} {"4 launches (luma-plane passes)":36s} {us:9.1f} us  {B*S*S/us/1e3:7.1f} Gpix/s')

@@ -165,6 +165,25 @@ def check_static_case(case, golden, device, atol=1e-5):
     return float(err.max())
 
 
+def check_static_combinations(device):
+    """every demosaic x sharpening x denoising combination the device builds (single-launch chains and
+    luma-plane passes) against the oracle (the reference's own arithmetic on scipy), float32 and 16-bit input."""
+    for (B, H, W) in ((2, 40, 72), (1, 34, 264)):
+        u = np.random.default_rng(H).integers(0, 4096, (B, H, W)).astype(np.uint16)
+        raw_np = u.astype(np.float32) / np.float32(4095)
+        raw = torch.from_numpy(raw_np).to(device)
+        for deb in ('bilinear', 'malvar2004'):
+            for sh in ('none', 'sharpening_filter'):
+                for dn in ('none', 'gaussian_denoising', 'median_denoising'):
+                    ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
+                    out = F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
+                    err = np.abs(out.cpu().numpy() - ref).max()
+                    assert err <= 1e-5, (deb, sh, dn, (B, H, W), err)
+                    out16 = F_.static_pipeline(torch.from_numpy(u).to(device), orc.DRONE_CAMERA_PARAMS, deb, sh, dn,
+                                               bits=12)
+                    assert torch.equal(out16, out), (deb, sh, dn)
+
+
 def check_ragged_and_properties(device, B=2, H=70, W=134):
     """size-independent properties of the fused path: (i) the batch dimension is independent,
     (ii) eval-mode BatchNorm is an affine map of the no-BatchNorm output, (iii) stats-only + apply ==

@@ -28,6 +28,16 @@ off = al(4 * 267) + al(106 * 1024 * 4) + al(49 * 1024 * 4) + al(8 * 1024 * 4) + 
 dbg = ws[off:off + 3 * 8 * 1024 * 4].view(torch.float32).view(3, 1024, 8).double().cpu()
 names = {0: ['store', 'Y', 'YP', 'fill', 'pixels'], 1: ['store', 'Y', 'YP', 'fill', 'pixels'],
          2: ['store', 'adjblur', 'Y+fold', 'pixels', 'blockred', 'tree', 'unfold']}
+def report(k, kn, dbg):
+    pass
+
+
+if os.environ.get('R2L_STAMPS_STATS'):      # the statistics-only forward pass instead of the apply pass
+    st7 = torch.empty(7, dtype=torch.float64, device=dev)
+    for _ in range(3):
+        lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(P), None, None, None, ptr(st7), ptr(ws), n, B, H, W, 1, s), 'fwd stats')
+    torch.cuda.synchronize()
+    dbg = ws[off:off + 3 * 8 * 1024 * 4].view(torch.float32).view(3, 1024, 8).double().cpu()
 for k, kn in enumerate(['fwd', 'bwd1', 'bwd2']):
     d = dbg[k]
     nb = int((d.sum(1) > 0).sum())

@@ -7,8 +7,7 @@ import pytest
 from oracle.golden_cases import PARAM_CASES, STATIC_CASES
 import parity_checks as pc
 
-DEVICE_STATIC = [c for c in STATIC_CASES if c['denoising'] != 'median_denoising'
-                 and not (c['debayer'] == 'malvar2004' and c['sharpening'] == 'sharpening_filter')]
+DEVICE_STATIC = list(STATIC_CASES)   # every chain of the golden set is built for the device
 
 
 @pytest.mark.parametrize('case', PARAM_CASES, ids=[c['name'] for c in PARAM_CASES])
@@ -56,3 +55,7 @@ def test_frames_requiring_grad_take_the_staged_kernels(case, golden, emulation):
 
 def test_16bit_containers_are_bit_identical_to_host_normalised_frames(emulation):
     pc.check_u16_ingest('cpu')
+
+
+def test_static_chain_combinations(emulation):
+    pc.check_static_combinations('cpu')

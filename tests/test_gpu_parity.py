@@ -11,8 +11,7 @@ import parity_checks as pc
 
 pytestmark = pytest.mark.gpu
 
-DEVICE_STATIC = [c for c in STATIC_CASES if c['denoising'] != 'median_denoising'
-                 and not (c['debayer'] == 'malvar2004' and c['sharpening'] == 'sharpening_filter')]
+DEVICE_STATIC = list(STATIC_CASES)   # every chain of the golden set is built for the device
 
 
 @pytest.fixture(scope='module')
@@ -139,3 +138,7 @@ def test_frames_requiring_grad_take_the_staged_kernels(case, golden, dev):
 
 def test_16bit_containers_are_bit_identical_to_host_normalised_frames(dev):
     pc.check_u16_ingest(dev)
+
+
+def test_static_chain_combinations(dev):
+    pc.check_static_combinations(dev)
