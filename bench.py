@@ -58,6 +58,10 @@ def parse():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--workload', choices=('parametrized', 'static'), default='parametrized',
+                    help='parametrized = the headline metric (BASELINE config 2); static = the fused static chain '
+                         'demosaic->WB->CCM->clip->gamma on 256x1024x1024 frames per GPU (BASELINE config 3)')
+    ap.add_argument('--debayer', choices=('bilinear', 'malvar2004'), default='bilinear')
     ap.add_argument('--raw-u16', action='store_true',
                     help='feed the 12-bit frames as uint16 containers (2 B/px ingest, normalised in-kernel; '
                          'SURVEY.md section 8f) instead of float32: a separate variant, not the headline config')
@@ -89,8 +93,101 @@ def cpu_baseline(size):
                       f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
 
 
+def cpu_baseline_static(debayer):
+    """numpy oracle of processing() (pipeline_numpy.py:70-141, float64 like the reference) on BASELINE config 1
+    frames (256x256), short chain, one host thread, repeated for ~10 s."""
+    import numpy as np
+    from oracle import isp_oracle as orc
+    raw = orc.synth_raw(16, 256, 256, seed=0, kind='uniform')
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        orc.static_batch(raw, orc.DRONE_CAMERA_PARAMS, debayer, 'none', 'none')
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0:
+            break
+    return {'value': round(n * raw.size / dt / 1e6, 3), 'unit': 'Mpix/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} x 16x256x256 frames ({debayer}, short chain), numpy/scipy oracle float64, '
+                      f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
+
+
+def main_static(args):
+    """BASELINE config 3: one step = the fused static chain over 256x1024x1024 frames per GPU (no exchange between
+    ranks: static mode needs no collective)."""
+    import torch
+    import torch.distributed as dist
+    from oracle import isp_oracle as orc
+    from raw2logit_amd import _lib, functional as F_
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+    lib = _lib.device_library()
+    B, S = (args.batch if args.batch != 64 else 256), (args.size if args.size != 512 else 1024)
+    gen = torch.Generator(dev).manual_seed(rank)
+    u = torch.randint(0, 4096, (B, S, S), device=dev, generator=gen, dtype=torch.int32)
+    raw = u.to(torch.uint16) if args.raw_u16 else u.to(torch.float32) / 4095.0
+
+    def step():
+        return F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, args.debayer, 'none', 'none', bits=12)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    px = world * B * S * S
+    lib.r2l_timing_enable(1)
+    for _ in range(args.steps):
+        step()
+    barrier()
+    buf = ctypes.create_string_buffer(1 << 14)
+    lib.r2l_timing_report(buf, len(buf))
+    lib.r2l_timing_enable(0)
+    name, cnt, ms = buf.value.decode().split()
+    avg_us = 1e3 * float(ms) / int(cnt)
+    bpp = 14.0 if args.raw_u16 else 16.0
+    ach = B * S * S * bpp / (avg_us * 1e-6) / 1e9
+    if rank == 0:
+        out = {'metric': 'ISP Mpix/s (static fwd: demosaic->WB->CCM->clip->gamma) on 1024x1024 raw batches',
+               'value': round(px * args.steps / dt / 1e6, 1), 'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': f'static short chain ({args.debayer}), {B}x{S}x{S} 12-bit RGGB frames per GPU'
+                                      + (' as uint16 containers' if args.raw_u16 else '') + ', Drone camera parameters',
+                          'global_batch': world * B, 'frame': [S, S],
+                          'parallelism': f'batch shard x{world}, no collective' if world > 1 else 'single GPU'},
+               'roofline': {'bound': 'hbm', 'kernel': name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                            'avg_us': round(avg_us, 1), 'algo_bytes_per_px': bpp}}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_static(args.debayer)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload == 'static':
+        return main_static(args)
     import torch
     import torch.distributed as dist
     import numpy as np
