@@ -227,11 +227,8 @@ def main():
         if world > 1:                                # data-parallel sum of the 132-float ISP gradient
             flat = torch.cat([p.grad.reshape(-1) for p in params])
             dist.all_reduce(flat)
-            off = 0
-            for p in params:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+            torch._foreach_copy_([p.grad for p in params],
+                                 [c.view_as(p.grad) for c, p in zip(flat.split([p.numel() for p in params]), params)])
 
     def barrier():
         if world > 1:

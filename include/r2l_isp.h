@@ -107,19 +107,24 @@ int r2l_isp_fwd(const float *raw, const float *params, const float *additive,
                 size_t workspace_bytes, int B, int H, int W, int flags, void *stream);
 
 /* BatchNorm2d(3, affine=False) bookkeeping of train mode (:216-217) without a host round trip.
- * totals double[7] = the `stats` vector of r2l_isp_fwd summed over all ranks, followed by the total pixel
- * count per channel n.  Writes bn_mean_istd float[6] (for the apply pass), optionally moments double[6] =
- * batch mean[3], biased variance[3], and optionally updates running_mean / running_var float[3] the way
- * nn.BatchNorm2d does (momentum, unbiased variance).  num_batches_tracked (device int64, optional) is
- * incremented; momentum < 0 selects the cumulative moving average 1/num_batches_tracked
- * (nn.BatchNorm2d(momentum=None)).                                                              */
-int r2l_bn_finalize(const double *totals, float *bn_mean_istd, double *moments, float *running_mean,
-                    float *running_var, long long *num_batches_tracked, double eps, double momentum,
-                    void *stream);
+ * stats double[nranks][7] = the `stats` vectors of r2l_isp_fwd of all ranks (nranks = 1: this rank's own;
+ * several GPUs: the all-gathered vectors), added here in rank order so that every rank derives bit-identical
+ * statistics, equal to the single-GPU statistics of the global batch.  Writes bn_mean_istd float[6] (for the
+ * apply pass), optionally moments double[7] = batch mean[3], biased variance[3], global pixel count, and
+ * optionally updates running_mean / running_var float[3] the way nn.BatchNorm2d does (momentum, unbiased
+ * variance).  num_batches_tracked (device int64, optional) is incremented; momentum < 0 selects the cumulative
+ * moving average 1/num_batches_tracked (nn.BatchNorm2d(momentum=None)).                                  */
+int r2l_bn_finalize(const double *stats, int nranks, float *bn_mean_istd, double *moments,
+                    float *running_mean, float *running_var, long long *num_batches_tracked, double eps,
+                    double momentum, void *stream);
+
+/* Several GPUs: gathered_sums double[nranks][6] = the `sums` vectors of r2l_bn_bwd_reduce of all ranks, added in
+ * rank order and divided by *n (global pixel count, moments[6]) -> bn_bwd float[6] for r2l_isp_bwd.      */
+int r2l_bn_bwd_means(const double *gathered_sums, int nranks, const double *n, float *bn_bwd, void *stream);
 
 /* BatchNorm backward reduction (nn.BatchNorm2d backward in train mode, :216-217):
  * sums double[6] = sum_c(g)[3], sum_c(g*xhat)[3] with xhat == the saved forward output; with `totals`
- * (double[7], totals[6] = pixel count of the global batch) and bn_bwd (float[6]) also the means
+ * (double[7], totals[6] = pixel count of the global batch: the moments of r2l_bn_finalize) and bn_bwd (float[6]) also the means
  * bn_bwd = sums / n that r2l_isp_bwd consumes (single GPU; with several GPUs the caller all-reduces
  * `sums` and divides itself).  flags: R2L_F_FOLDED_VALID = the workspace went through r2l_isp_fwd /
  * r2l_isp_bwd before (the reduction then finishes inside the same launch).                        */

@@ -125,6 +125,7 @@ static_assert(R2L_LDS3(GBwd2) >= R2L_RED_FLOATS, "reduction scratch must fit");
 R2L_KERNEL(r2l_launch_fold, R2LFoldArgs, r2l_fold_block, 4)
 R2L_KERNEL(r2l_launch_unfold, R2LUnfoldArgs, r2l_unfold_block, 4 + 2 * R2L_NSUMS + 2 * R2L_UNFOLD_TG + R2L_P_COUNT + 4)
 R2L_KERNEL(r2l_launch_bn_finalize, R2LBnFinalizeArgs, r2l_bn_finalize_block, 4)
+R2L_KERNEL(r2l_launch_bn_bwd_means, R2LBnBwdMeansArgs, r2l_bn_bwd_means_block, 4)
 R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 * R2L_NT + 64)
 #ifndef R2L_OCC_FWD
 #define R2L_OCC_FWD 4
@@ -363,14 +364,22 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
   return 0;
 }
 
-int r2l_bn_finalize(const double* totals, float* bn_mean_istd, double* moments, float* running_mean,
+int r2l_bn_finalize(const double* stats, int nranks, float* bn_mean_istd, double* moments, float* running_mean,
                     float* running_var, long long* num_batches_tracked, double eps, double momentum,
                     void* stream) {
-  if (!totals || !bn_mean_istd) return r2l_fail(-1, "r2l_bn_finalize: null pointer");
+  const double* totals = stats;
+  if (!totals || !bn_mean_istd || nranks < 1) return r2l_fail(-1, "r2l_bn_finalize: null pointer / nranks < 1");
   if ((running_mean == nullptr) != (running_var == nullptr))
     return r2l_fail(-1, "r2l_bn_finalize: running_mean and running_var go together");
-  R2LBnFinalizeArgs a{totals, bn_mean_istd, moments, running_mean, running_var, eps, momentum, num_batches_tracked};
+  R2LBnFinalizeArgs a{totals, nranks, bn_mean_istd, moments, running_mean, running_var, eps, momentum,
+                      num_batches_tracked};
   return r2l_launch_bn_finalize(a, 1, stream);
+}
+
+int r2l_bn_bwd_means(const double* gathered_sums, int nranks, const double* n, float* bn_bwd, void* stream) {
+  if (!gathered_sums || !n || !bn_bwd || nranks < 1) return r2l_fail(-1, "r2l_bn_bwd_means: null pointer / nranks < 1");
+  R2LBnBwdMeansArgs a{gathered_sums, nranks, n, bn_bwd};
+  return r2l_launch_bn_bwd_means(a, 1, stream);
 }
 
 int r2l_bn_bwd_reduce(const float* grad_out, const float* out, const double* totals, double* sums,

@@ -43,7 +43,8 @@ R2L_BLOCKFN void r2l_unfold_block(const R2LUnfoldArgs& a, int bid, int nblk, flo
 //   moments[6]  = mean[3], var_biased[3] (float64)
 //   running_mean / running_var (optional): nn.BatchNorm2d update with `momentum`, unbiased variance
 struct R2LBnFinalizeArgs {
-  const double* tot;
+  const double* tot;  // [nranks][7]: the statistics vectors of all ranks, added here in rank order
+  int nranks;
   float* bn;
   double* moments;
   float* running_mean;
@@ -59,9 +60,14 @@ R2L_BLOCKFN void r2l_bn_finalize_block(const R2LBnFinalizeArgs& a, int bid, int 
   if (tid < 3) {
     const long long nbt = a.num_batches_tracked ? *a.num_batches_tracked + 1 : 1;
     const double mom = a.momentum < 0.0 ? 1.0 / (double)nbt : a.momentum;
-    const double n = a.tot[6];
-    const double m1 = a.tot[tid] / n;
-    double var = a.tot[3 + tid] / n - m1 * m1;
+    double n = 0.0, s1 = 0.0, s2 = 0.0;  // rank order: every rank computes bit-identical statistics
+    for (int r = 0; r < a.nranks; ++r) {
+      n += a.tot[r * 7 + 6];
+      s1 += a.tot[r * 7 + tid];
+      s2 += a.tot[r * 7 + 3 + tid];
+    }
+    const double m1 = s1 / n;
+    double var = s2 / n - m1 * m1;
     var = var < 0.0 ? 0.0 : var;
     const double mean = m1 + 0.5;
     a.bn[tid] = (float)mean;
@@ -69,6 +75,7 @@ R2L_BLOCKFN void r2l_bn_finalize_block(const R2LBnFinalizeArgs& a, int bid, int 
     if (a.moments) {
       a.moments[tid] = mean;
       a.moments[3 + tid] = var;
+      a.moments[6] = n;  // pixel count of the global batch (the BatchNorm backward divides by it)
     }
     if (a.running_mean) {
       const double unb = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
@@ -79,6 +86,26 @@ R2L_BLOCKFN void r2l_bn_finalize_block(const R2LBnFinalizeArgs& a, int bid, int 
   R2L_PHASE_END
   R2L_PHASE_BEGIN  // after every lane has read the counter
   if (tid == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+  R2L_PHASE_END
+}
+
+// ---- BatchNorm backward means of the global batch: gathered[nranks][6] summed in rank order, / n -----
+struct R2LBnBwdMeansArgs {
+  const double* gathered;
+  int nranks;
+  const double* n;  // pixel count of the global batch
+  float* bn_bwd;    // mean_c(g)[3], mean_c(g*xhat)[3]
+};
+R2L_BLOCKFN void r2l_bn_bwd_means_block(const R2LBnBwdMeansArgs& a, int bid, int nblk, float* lds) {
+  (void)bid;
+  (void)nblk;
+  (void)lds;
+  R2L_PHASE_BEGIN
+  if (tid < 6) {
+    double s = 0.0;
+    for (int r = 0; r < a.nranks; ++r) s += a.gathered[r * 6 + tid];
+    a.bn_bwd[tid] = (float)(s / *a.n);
+  }
   R2L_PHASE_END
 }
 

@@ -114,33 +114,42 @@ PARAM_LAYOUT = (('black_level', 0, 4), ('white_balance', 4, 3), ('colour_correct
                 ('gaussian_blur.weight', 107, 25))
 
 
-def gather_totals(stats7, group=None):
-    """(sum(x-.5)[3], sum((x-.5)^2)[3], pixel count) of this rank -> the same sums over all ranks.
+def gather_ranks(vec, group=None):
+    """this rank's small float64 vector -> (all ranks' vectors, rank-major in one flat tensor, nranks), over
+    RCCL/xGMI.  The kernels that consume it add the rows in rank order, so every rank computes bit-identical
+    results, equal to the single-GPU result for the global batch."""
+    n = _group_size(group)
+    if n == 1:
+        return vec, 1
+    out = torch.empty(n * vec.numel(), dtype=vec.dtype, device=vec.device)   # rank-major, flat (gloo wants 1-D)
+    dist.all_gather_into_tensor(out, vec, group=group)
+    return out, n
 
-    With several ranks the 7-vectors are all-gathered over RCCL/xGMI and added in rank order, so every rank
-    gets bit-identical statistics, equal to the single-GPU statistics of the global batch."""
-    if _group_size(group) > 1:
-        gathered = [torch.empty_like(stats7) for _ in range(dist.get_world_size(group))]
-        dist.all_gather(gathered, stats7, group=group)
-        return torch.stack(gathered, 0).sum(0)
-    return stats7
 
-
-def bn_finalize(lib, stream, totals, bn_module, eps, momentum, want_moments=True):
-    """totals -> (mean, istd) float32[6] (+ moments float64[6]); updates the module's running statistics and
-    num_batches_tracked on the device the way nn.BatchNorm2d does in train mode."""
-    dev = totals.device
+def bn_finalize(lib, stream, stats, nranks, bn_module, eps, momentum):
+    """statistics vectors of all ranks -> (mean, istd) float32[6], moments float64[7] (mean, biased var, global
+    pixel count); updates the module's running statistics and num_batches_tracked on the device the way
+    nn.BatchNorm2d does in train mode."""
+    dev = stats.device
     bn = torch.empty(6, dtype=torch.float32, device=dev)
-    moments = torch.empty(6, dtype=torch.float64, device=dev) if want_moments else None
+    moments = torch.empty(7, dtype=torch.float64, device=dev)
     rm = rv = nbt = None
     if bn_module is not None and bn_module.track_running_stats and bn_module.running_mean is not None:
         rm, rv, nbt = bn_module.running_mean, bn_module.running_var, bn_module.num_batches_tracked
         if rm.device != dev or nbt.dtype != torch.int64:
             raise RuntimeError('BatchNorm buffers must live on the device of the frames')
-    lib.check(lib.r2l_bn_finalize(ptr(totals), ptr(bn), ptr(moments), ptr(rm), ptr(rv), ptr(nbt), float(eps),
-                                  float(momentum) if momentum is not None else -1.0, stream),
+    lib.check(lib.r2l_bn_finalize(ptr(stats), nranks, ptr(bn), ptr(moments), ptr(rm), ptr(rv), ptr(nbt),
+                                  float(eps), float(momentum) if momentum is not None else -1.0, stream),
               'r2l_bn_finalize')
     return bn, moments
+
+
+def bn_bwd_means(lib, stream, sums, moments, group):
+    """several ranks: the BatchNorm backward sums cross ranks (all-gather, added in rank order in the kernel)"""
+    gathered, n = gather_ranks(sums, group)
+    bn_bwd = torch.empty(6, dtype=torch.float32, device=sums.device)
+    lib.check(lib.r2l_bn_bwd_means(ptr(gathered), n, ptr(moments[6:]), ptr(bn_bwd), stream), 'r2l_bn_bwd_means')
+    return bn_bwd
 
 
 def _isp_fwd(lib, raw, denom, *rest):
@@ -182,9 +191,9 @@ class _IspFused(torch.autograd.Function):
             lib.check(_isp_fwd(lib, raw, denom, ptr(packed), ptr(additive), None, None, ptr(stats),
                                ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream), 'r2l_isp_fwd(stats)')
             folded = _lib.R2L_F_FOLDED_VALID
-            totals = gather_totals(stats, group)
-            bn, moments = bn_finalize(lib, stream, totals, bn_module, eps, momentum)
-            ctx.totals = totals
+            gathered, nranks = gather_ranks(stats, group)
+            bn, moments = bn_finalize(lib, stream, gathered, nranks, bn_module, eps, momentum)
+            ctx.totals = moments       # [6] = pixel count of the global batch
         elif bn_mode == BN_EVAL:
             mean = bn_module.running_mean.detach().to(device=dev, dtype=torch.float64)
             var = bn_module.running_var.detach().to(device=dev, dtype=torch.float64)
@@ -222,8 +231,7 @@ class _IspFused(torch.autograd.Function):
                                             ptr(ws), nws, B, H, W, _lib.R2L_F_FOLDED_VALID, stream),
                       'r2l_bn_bwd_reduce')
             if _group_size(ctx.group) > 1:
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
-                bn_bwd = (sums / ctx.totals[6]).to(torch.float32)
+                bn_bwd = bn_bwd_means(lib, stream, sums, ctx.totals, ctx.group)
         grads = [None] * 7
         if any(ctx.needs_input_grad[1:8]):
             gp = torch.empty(_lib.R2L_P_NTRAIN, dtype=torch.float32, device=raw.device)

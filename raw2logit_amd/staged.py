@@ -9,7 +9,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import ptr
-from .functional import raw2rgb_bits, _f32c, _group_size, gather_totals, bn_finalize
+from .functional import raw2rgb_bits, _f32c, _group_size, gather_ranks, bn_finalize, bn_bwd_means
 
 
 def _ws(lib, like):
@@ -205,10 +205,9 @@ class _BatchNorm(torch.autograd.Function):
             _, sm = _point(lib, s, 7, x, x=x, out=False, sums=True)
             stats = torch.cat([sm.to(torch.float64),
                                torch.full((1,), float(B * H * W), dtype=torch.float64, device=dev)])
-            totals = gather_totals(stats, group)
-            bn, _ = bn_finalize(lib, s, totals, bn_module if bn_module.track_running_stats else None,
-                                bn_module.eps, bn_module.momentum, want_moments=False)
-            ctx.n_total = totals[6]
+            gathered, nranks = gather_ranks(stats, group)
+            bn, moments = bn_finalize(lib, s, gathered, nranks, bn_module, bn_module.eps, bn_module.momentum)
+            ctx.moments = moments
         else:
             mean = bn_module.running_mean.detach().to(device=dev, dtype=torch.float64)
             var = bn_module.running_var.detach().to(device=dev, dtype=torch.float64)
@@ -230,9 +229,7 @@ class _BatchNorm(torch.autograd.Function):
             ws = torch.empty(n, dtype=torch.uint8, device=g.device)
             lib.check(lib.r2l_bn_bwd_reduce(ptr(g), ptr(y), None, ptr(sums), None, ptr(ws), n, B, H, W, 0, s),
                       'bn_bwd_reduce')
-            if _group_size(ctx.group) > 1:
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
-            coef = (sums / ctx.n_total).to(torch.float32)
+            coef = bn_bwd_means(lib, s, sums, ctx.moments, ctx.group)   # (one rank: just sums / n)
         gx, _ = _point(lib, s, 6, g, g=g, w=bn, aux=y, aux2=coef)
         return gx, None, None, None
 

@@ -42,8 +42,16 @@ def _worker(rank, world, port, emul_path, out_dir):
     (y * cot[lo:hi]).sum().backward()
     flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
     dist.all_reduce(flat)                      # data-parallel sum of the ISP gradient
+    # the staged kernels (track_stages=True) exchange the same statistics
+    mt = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, track_stages=True, batch_norm_output=True).train()
+    mt.process_group = dist.group.WORLD
+    yt = mt(raw[lo:hi])
+    (yt * cot[lo:hi]).sum().backward()
+    flat_t = torch.cat([p.grad.reshape(-1) for p in mt.parameters()])
+    dist.all_reduce(flat_t)
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), y=y.detach().numpy(), g=flat.numpy(),
-             rm=m.batch_norm.running_mean.numpy(), rv=m.batch_norm.running_var.numpy())
+             rm=m.batch_norm.running_mean.numpy(), rv=m.batch_norm.running_var.numpy(),
+             yt=yt.detach().numpy(), gt=flat_t.numpy())
     dist.destroy_process_group()
 
 
@@ -65,6 +73,9 @@ def test_two_rank_shard_equals_single_process(emulation, tmp_path):
     assert np.abs(y_sharded - y.detach().numpy()).max() < 2e-5
     assert np.array_equal(r[0]['g'], r[1]['g'])
     assert np.abs(r[0]['g'] - g).max() <= 2e-4 * (np.abs(g).max() + 1e-6)
+    yt_sharded = np.concatenate([r[0]['yt'], r[1]['yt']])
+    assert np.abs(yt_sharded - y.detach().numpy()).max() < 5e-5       # staged == fused == single process
+    assert np.abs(r[0]['gt'] - g).max() <= 3e-3 * (np.abs(g).max() + 1e-6)
     for k in range(world):
         np.testing.assert_allclose(r[k]['rm'], m.batch_norm.running_mean.numpy(), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(r[k]['rv'], m.batch_norm.running_var.numpy(), rtol=1e-5, atol=1e-7)
