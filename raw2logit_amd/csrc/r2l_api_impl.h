@@ -392,7 +392,7 @@ int r2l_bn_bwd_reduce(const float* grad_out, const float* out, const double* tot
   if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_bn_bwd_reduce: workspace too small");
   const size_t hw = (size_t)H * W;
   const size_t nitems = (size_t)3 * B * ((hw + R2L_SEG - 1) / R2L_SEG);
-  const int cap = r2l_tile_grid(R2L_MAX_BLOCKS, r2l_env_int("R2L_GRID_BNR", R2L_MAX_BLOCKS));
+  const int cap = r2l_tile_grid(R2L_MAX_BLOCKS, r2l_env_int("R2L_GRID_BNR", 512));
   int grid = nitems < (size_t)cap ? (int)nitems : cap;
   // a workspace that went through r2l_isp_fwd / r2l_isp_bwd has valid arrival counters: the last workgroups
   // of the launch finish the reduction; otherwise a second, tiny launch does

@@ -198,11 +198,9 @@ R2L_BLOCKFN void r2l_bn_reduce_block(const R2LBnReduceArgs& a, int bid, int nblk
   const size_t hw = (size_t)a.H * a.W;
   const int nsegpp = (int)((hw + R2L_SEG - 1) / R2L_SEG);
   const int nitems = 3 * a.B * nsegpp;
-  for (int item = bid; item < nitems; item += nblk) {
-    R2L_PHASE_BEGIN
-    r2l_bn_reduce_item(tid, a, item, nsegpp, R2L_TREG(regs));
-    R2L_PHASE_END
-  }
+  R2L_PHASE_BEGIN  // one phase: the wavefronts stream independently (a barrier per item would cap the loads in flight)
+  for (int item = bid; item < nitems; item += nblk) r2l_bn_reduce_item(tid, a, item, nsegpp, R2L_TREG(regs));
+  R2L_PHASE_END
   R2L_BLOCK_REDUCE(6, regs, lds, a.partial, bid, nblk)
   if (a.tree.counters) {
     double* sl = (double*)(lds + 4);
