@@ -211,6 +211,27 @@ int r2l_stage_point(int op, const float *x, const float *g, const float *w, cons
                     const float *aux2, float *y, float *sums6, void *workspace, size_t workspace_bytes,
                     int B, int H, int W, void *stream);
 
+/* ---- adversarial auxiliary losses between the outputs of two processors (SURVEY.md section 8f rank 2;
+ * AuxLoss, utils/base.py:346-358: img1 = the default processor's output, img2 = the adversarial processor's).
+ *   r2l_ssim_fwd   mean of the SSIM map, window_size 11, sigma 1.5, zero padding, per channel
+ *                  (utils/ssim.py:9-39, SSIM(window_size=11), size_average=True) -> ssim_mean double[1]
+ *                  keep_for_backward: also leave dS/d(mu2, E[y^2], E[xy]) of every pixel in the workspace
+ *   r2l_ssim_bwd   grad_img2 = grad_ssim[0] * d mean-SSIM / d img2   (grad_ssim: device float scalar);
+ *                  workspace_has_dmaps: the workspace is the one a keep_for_backward forward filled (else the
+ *                  maps are recomputed first)
+ *   r2l_l2_fwd     ((x - y) ** 2).sum() (utils/base.py:342-343) -> sum double[1]; n elements, n % 4 == 0
+ *   r2l_l2_bwd     grad_y = grad_sum[0] * 2 (y - x)
+ * Images are (B,C,H,W) float32; workspace from r2l_aux_workspace_bytes().                              */
+size_t r2l_aux_workspace_bytes(int B, int C, int H, int W);
+int r2l_ssim_fwd(const float *img1, const float *img2, double *ssim_mean, void *workspace,
+                 size_t workspace_bytes, int keep_for_backward, int B, int C, int H, int W, void *stream);
+int r2l_ssim_bwd(const float *img1, const float *img2, const float *grad_ssim, float *grad_img2,
+                 void *workspace, size_t workspace_bytes, int workspace_has_dmaps, int B, int C, int H, int W,
+                 void *stream);
+int r2l_l2_fwd(const float *x, const float *y, double *sum, void *workspace, size_t workspace_bytes, size_t n,
+               void *stream);
+int r2l_l2_bwd(const float *x, const float *y, const float *grad_sum, float *grad_y, size_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from oracle import isp_oracle as orc  # noqa: E402
-from oracle.golden_cases import (PARAM_CASES, RAW2RGB_CASES, STATIC_CASES, SAMPLE_STRIDE)  # noqa: E402
+from oracle.golden_cases import (PARAM_CASES, RAW2RGB_CASES, STATIC_CASES, SAMPLE_STRIDE,  # noqa: E402
+                                 AUX_CASES, aux_inputs)
 from oracle import harness  # noqa: E402
 
 
@@ -239,12 +240,37 @@ def gen_harness(ppt, out):
         out['harness/logits_eval_after'] = clf(proc(torch.from_numpy(raw_np))).numpy()
 
 
+def gen_aux(_mod, out):
+    """utils/ssim.py SSIM(window_size=11) and utils/base.py l2_regularization, run as they are (pure torch;
+    loaded by file path because the `utils` package itself needs MLflow/Lightning)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_ssim', os.path.join(REF, 'utils', 'ssim.py'))
+    ref_ssim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_ssim)
+    for case in AUX_CASES:
+        x, y = aux_inputs(case)
+        ty = torch.from_numpy(y).requires_grad_(True)
+        v = ref_ssim.SSIM(window_size=11)(torch.from_numpy(x), ty)
+        v.backward()
+        name = case['name']
+        out[f'{name}/ssim'] = np.float32(v.item())
+        out[f'{name}/ssim_grad'] = ty.grad.numpy().copy()
+        ty2 = torch.from_numpy(y).requires_grad_(True)
+        l2 = ((torch.from_numpy(x) - ty2) ** 2).sum()          # utils/base.py:342-343
+        l2.backward()
+        out[f'{name}/l2'] = np.float32(l2.item())
+        out[f'{name}/l2_grad'] = ty2.grad.numpy().copy()
+        ov, og = orc.ssim(x, y)
+        print(f'  {name:24s} oracle-vs-reference: ssim {abs(ov - v.item()):.2e}  grad {np.abs(og - ty.grad.numpy()).max():.2e}')
+
+
 def main():
     ppn, ppt = import_reference()
     gold = os.path.join(REPO, 'tests', 'golden')
     os.makedirs(gold, exist_ok=True)
     for fname, fn, mod in [('param_cases.npz', gen_param_cases, ppt), ('raw2rgb.npz', gen_raw2rgb, ppt),
-                           ('static_cases.npz', gen_static, ppn), ('harness.npz', gen_harness, ppt)]:
+                           ('static_cases.npz', gen_static, ppn), ('harness.npz', gen_harness, ppt),
+                           ('aux_losses.npz', gen_aux, None)]:
         out = {}
         print(fname)
         fn(mod, out)

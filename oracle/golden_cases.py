@@ -78,3 +78,21 @@ STATIC_CASES = [
     dict(name='tiny_4x4', seed=9, shape=(1, 4, 4), kind='uniform', camera='drone',
          debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
 ]
+
+
+# adversarial auxiliary losses (utils/ssim.py, utils/base.py:342-358): img1 = reference-processor output,
+# img2 = adversarial-processor output (the one that receives the gradient)
+AUX_CASES = [
+    dict(name='ssim_small', seed=0, shape=(2, 3, 24, 40), noise=0.1),
+    dict(name='ssim_tile_edges', seed=1, shape=(1, 3, 70, 134), noise=0.05),     # ragged tiles, several tiles
+    dict(name='ssim_tiny', seed=2, shape=(1, 3, 8, 12), noise=0.3),              # smaller than the window
+    dict(name='ssim_one_channel', seed=3, shape=(2, 1, 32, 32), noise=0.2),
+]
+
+
+def aux_inputs(case):
+    import numpy as np
+    rng = np.random.default_rng(100 + case['seed'])
+    x = rng.random(case['shape']).astype(np.float32)
+    y = np.clip(x + case['noise'] * rng.standard_normal(case['shape']), 0.0, 1.0).astype(np.float32)
+    return x, y

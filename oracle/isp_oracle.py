@@ -615,3 +615,58 @@ def static_batch(raw, camera_parameters, debayer='bilinear', sharpening='sharpen
                        sharpening=sharpening, denoising=denoising, gamma=gamma)
         out.append(o.transpose(2, 0, 1).astype(np.float32))
     return np.stack(out)
+
+
+# --------------------------------------------------------------------------------------------------------
+# adversarial auxiliary losses: utils/ssim.py:9-39, utils/base.py:342-358
+# --------------------------------------------------------------------------------------------------------
+def ssim_window(window_size=11, sigma=1.5, dtype=np.float32):
+    """utils/ssim.py:9-17: normalised 1-D Gaussian (float32) and its outer product."""
+    g = np.array([np.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)],
+                 dtype=np.float32)
+    g = (g / g.sum(dtype=np.float32)).astype(np.float32)
+    return g.astype(dtype), np.outer(g, g).astype(np.float32).astype(dtype)
+
+
+def _ssim_blur(x, w2):
+    """depthwise F.conv2d(x, window, padding=window_size//2) (zero padding), x (B,C,H,W)."""
+    K = w2.shape[0]
+    p = K // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (p, p), (p, p)))
+    H, W = x.shape[2:]
+    out = np.zeros_like(x)
+    for i in range(K):
+        for j in range(K):
+            out += w2[i, j] * xp[:, :, i:i + H, j:j + W]
+    return out
+
+
+def ssim(img1, img2, window_size=11, dtype=np.float64):
+    """utils/ssim.py:19-39 with size_average=True: returns (mean SSIM, d mean / d img2)."""
+    x = np.asarray(img1, dtype=dtype)
+    y = np.asarray(img2, dtype=dtype)
+    _, w2 = ssim_window(window_size, dtype=dtype)
+    C1, C2 = dtype(0.01 ** 2), dtype(0.03 ** 2)
+    mu1, mu2 = _ssim_blur(x, w2), _ssim_blur(y, w2)
+    s11 = _ssim_blur(x * x, w2) - mu1 * mu1
+    s22 = _ssim_blur(y * y, w2) - mu2 * mu2
+    s12 = _ssim_blur(x * y, w2) - mu1 * mu2
+    A1, A2 = 2 * mu1 * mu2 + C1, 2 * s12 + C2
+    B1, B2 = mu1 * mu1 + mu2 * mu2 + C1, s11 + s22 + C2
+    S = A1 * A2 / (B1 * B2)
+    n = S.size
+    # reverse pass w.r.t. img2 through (mu2, E[y^2], E[xy]); the window is symmetric, so the adjoint of the
+    # zero-padded correlation is the same correlation
+    dA1, dA2, dB1, dB2 = A2 / (B1 * B2), A1 / (B1 * B2), -S / B1, -S / B2
+    d_mu2 = dA1 * 2 * mu1 + dA2 * (-2 * mu1) + dB1 * 2 * mu2 + dB2 * (-2 * mu2)
+    d_eyy = dB2                      # s22 = E[y^2] - mu2^2
+    d_exy = dA2 * 2                  # s12 = E[xy] - mu1 mu2
+    grad = (_ssim_blur(d_mu2, w2) + 2 * y * _ssim_blur(d_eyy, w2) + x * _ssim_blur(d_exy, w2)) / n
+    return S.mean(), grad
+
+
+def l2_regularization(x, y):
+    """utils/base.py:342-343: ((x - y) ** 2).sum(); returns (value, d value / d y)."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    return ((x - y) ** 2).sum(), 2 * (y - x)

@@ -66,6 +66,14 @@ _SIGNATURES = {
                                           ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_void_p]),
+    'r2l_aux_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),
+    'r2l_ssim_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t] +
+                     [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    'r2l_ssim_bwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p,
+                                    ctypes.c_size_t] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    'r2l_l2_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                  ctypes.c_size_t, ctypes.c_void_p]),
+    'r2l_l2_bwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_size_t, ctypes.c_void_p]),
     'r2l_stage_workspace_bytes': (ctypes.c_size_t, []),
     'r2l_stage_conv33_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'r2l_stage_conv33_bwd': (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_void_p, ctypes.c_size_t] +

@@ -15,6 +15,7 @@
 #include "r2l_static_stream.h"
 #include "r2l_static_planes.h"
 #include "r2l_staged_kernels.h"
+#include "r2l_aux_kernels.h"
 
 static thread_local std::string r2l_err;
 static int r2l_fail(int code, const std::string& msg) {
@@ -189,6 +190,9 @@ R2L_KERNEL(r2l_launch_mix3_bwd, R2LStageArgs, r2l_mix3_bwd_block, R2L_RED_FLOATS
 R2L_KERNEL(r2l_launch_pconv_fwd, R2LStageArgs, r2l_pconv_fwd_block, 4)
 R2L_KERNEL(r2l_launch_pconv_bwd, R2LStageArgs, r2l_pconv_bwd_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_point, R2LPointArgs, r2l_point_block, R2L_RED_FLOATS)
+R2L_KERNEL(r2l_launch_ssim, R2LSsimArgs, r2l_ssim_block, R2L_SSIM_LDS_FLOATS)
+R2L_KERNEL(r2l_launch_ssim_bwd, R2LSsimBwdArgs, r2l_ssim_bwd_block, R2L_SSIM_BWD_LDS_FLOATS)
+R2L_KERNEL(r2l_launch_l2, R2LL2Args, r2l_l2_block, R2L_RED_FLOATS_N(1))
 
 // ---- grid sizing ------------------------------------------------------------------------------
 static_assert(R2L_MAX_BLOCKS == 1024, "partials are laid out for at most 1024 workgroups");
@@ -771,6 +775,102 @@ int r2l_stage_point(int op, const float* x, const float* g, const float* w, cons
   R2LPointArgs a{x, g, w, aux, aux2, y, reduces ? (float*)workspace : nullptr, B, H, W, op};
   if (int e = r2l_launch_point(a, grid, stream)) return e;
   return reduces ? r2l_stage_finish((const float*)workspace, 6, grid, sums6, stream) : 0;
+}
+
+// ---- adversarial auxiliary losses (utils/ssim.py, utils/base.py:342-358) -------------------------------
+static void r2l_ssim_gauss(float* g) {  // utils/ssim.py:9-11, float32 like torch.Tensor([...]) / sum
+  float w[R2L_SSIM_K], sum = 0.f;
+  for (int x = 0; x < R2L_SSIM_K; ++x) {
+    const double d = x - R2L_SSIM_K / 2;
+    w[x] = (float)exp(-(d * d) / (2.0 * 1.5 * 1.5));
+    sum += w[x];
+  }
+  for (int x = 0; x < R2L_SSIM_K; ++x) g[x] = w[x] / sum;
+}
+size_t r2l_aux_workspace_bytes(int B, int C, int H, int W) {
+  if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
+  return r2l_align_up(sizeof(float) * R2L_MAX_BLOCKS) + sizeof(float) * 3 * (size_t)B * C * H * W;
+}
+static int r2l_aux_check(const void* a, const void* b, int B, int C, int H, int W, const char* who) {
+  if (!a || !b) return r2l_fail(-1, std::string(who) + ": null pointer");
+  if (B < 1 || C < 1 || H < 1 || W < 1 || (size_t)B * C > (1u << 24) || (size_t)H * W > ((size_t)1 << 29))
+    return r2l_fail(-1, std::string(who) + ": bad dimensions");
+  return 0;
+}
+static int r2l_ssim_launch(const float* img1, const float* img2, float* partial, float* dmaps, int mode, int B,
+                           int C, int H, int W, void* stream, int* grid_out) {
+  R2LSsimArgs a;
+  a.img1 = img1;
+  a.img2 = img2;
+  r2l_ssim_gauss(a.g);
+  a.partial = partial;
+  a.dmaps = dmaps;
+  a.nplanes = B * C;
+  a.H = H;
+  a.W = W;
+  a.mode = mode;
+  const int ntiles = B * C * ((H + R2L_SSIM_T - 1) / R2L_SSIM_T) * ((W + R2L_SSIM_T - 1) / R2L_SSIM_T);
+  *grid_out = ntiles < 512 ? ntiles : 512;
+  return r2l_launch_ssim(a, *grid_out, stream);
+}
+int r2l_ssim_fwd(const float* img1, const float* img2, double* ssim_mean, void* workspace, size_t workspace_bytes,
+                 int keep_for_backward, int B, int C, int H, int W, void* stream) {
+  if (int e = r2l_aux_check(img1, img2, B, C, H, W, "r2l_ssim_fwd")) return e;
+  if (!ssim_mean || !workspace || workspace_bytes < r2l_aux_workspace_bytes(B, C, H, W))
+    return r2l_fail(-2, "r2l_ssim_fwd: workspace too small / null output");
+  float* partial = (float*)workspace;
+  float* dmaps = (float*)((char*)workspace + r2l_align_up(sizeof(float) * R2L_MAX_BLOCKS));
+  int grid = 0;
+  if (int e = r2l_ssim_launch(img1, img2, partial, dmaps, keep_for_backward ? 3 : 1, B, C, H, W, stream, &grid))
+    return e;
+  R2LReduceRowsArgs r{partial, ssim_mean, grid, 1.0 / ((double)B * C * H * W), nullptr};
+  return r2l_launch_reduce_rows(r, 1, stream);
+}
+int r2l_ssim_bwd(const float* img1, const float* img2, const float* grad_ssim, float* grad_img2, void* workspace,
+                 size_t workspace_bytes, int workspace_has_dmaps, int B, int C, int H, int W, void* stream) {
+  if (int e = r2l_aux_check(img1, img2, B, C, H, W, "r2l_ssim_bwd")) return e;
+  if (!grad_ssim || !grad_img2 || !workspace || workspace_bytes < r2l_aux_workspace_bytes(B, C, H, W))
+    return r2l_fail(-2, "r2l_ssim_bwd: workspace too small / null pointer");
+  float* dmaps = (float*)((char*)workspace + r2l_align_up(sizeof(float) * R2L_MAX_BLOCKS));
+  int grid = 0;
+  if (!workspace_has_dmaps) {
+    if (int e = r2l_ssim_launch(img1, img2, nullptr, dmaps, 2, B, C, H, W, stream, &grid)) return e;
+  } else {
+    const int ntiles = B * C * ((H + R2L_SSIM_T - 1) / R2L_SSIM_T) * ((W + R2L_SSIM_T - 1) / R2L_SSIM_T);
+    grid = ntiles < 512 ? ntiles : 512;
+  }
+  R2LSsimBwdArgs b;
+  b.img1 = img1;
+  b.img2 = img2;
+  b.dmaps = dmaps;
+  b.gup = grad_ssim;
+  b.scale = (float)(1.0 / ((double)B * C * H * W));
+  b.grad = grad_img2;
+  r2l_ssim_gauss(b.g);
+  b.nplanes = B * C;
+  b.H = H;
+  b.W = W;
+  return r2l_launch_ssim_bwd(b, grid, stream);
+}
+int r2l_l2_fwd(const float* x, const float* y, double* sum, void* workspace, size_t workspace_bytes, size_t n,
+               void* stream) {
+  if (!x || !y || !sum || !workspace) return r2l_fail(-1, "r2l_l2_fwd: null pointer");
+  if (n == 0 || (n & 3)) return r2l_fail(-1, "r2l_l2_fwd: the element count must be a positive multiple of 4");
+  if (workspace_bytes < sizeof(float) * R2L_MAX_BLOCKS) return r2l_fail(-2, "r2l_l2_fwd: workspace too small");
+  size_t g = (n / 4 + R2L_NT - 1) / R2L_NT;
+  if (g > R2L_MAX_BLOCKS) g = R2L_MAX_BLOCKS;
+  R2LL2Args a{x, y, nullptr, nullptr, (float*)workspace, n};
+  if (int e = r2l_launch_l2(a, (int)g, stream)) return e;
+  R2LReduceRowsArgs r{a.partial, sum, (int)g, 1.0, nullptr};
+  return r2l_launch_reduce_rows(r, 1, stream);
+}
+int r2l_l2_bwd(const float* x, const float* y, const float* grad_sum, float* grad_y, size_t n, void* stream) {
+  if (!x || !y || !grad_sum || !grad_y) return r2l_fail(-1, "r2l_l2_bwd: null pointer");
+  if (n == 0 || (n & 3)) return r2l_fail(-1, "r2l_l2_bwd: the element count must be a positive multiple of 4");
+  size_t g = (n / 4 + R2L_NT - 1) / R2L_NT;
+  if (g > 4096) g = 4096;
+  R2LL2Args a{x, y, grad_sum, grad_y, nullptr, n};
+  return r2l_launch_l2(a, (int)g, stream);
 }
 
 }  // extern "C"

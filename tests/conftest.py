@@ -44,4 +44,4 @@ def golden():
     import numpy as np
     d = os.path.join(REPO, 'tests', 'golden')
     return {n: np.load(os.path.join(d, n + '.npz'), allow_pickle=False)
-            for n in ('param_cases', 'raw2rgb', 'static_cases', 'harness')}
+            for n in ('param_cases', 'raw2rgb', 'static_cases', 'harness', 'aux_losses')}

@@ -6,7 +6,7 @@ import torch
 
 from oracle import isp_oracle as orc
 from oracle.gen_golden import build_params
-from oracle.golden_cases import SAMPLE_STRIDE
+from oracle.golden_cases import SAMPLE_STRIDE, AUX_CASES, aux_inputs
 from raw2logit_amd.processing import pipeline_torch as ppt
 from raw2logit_amd.processing import pipeline_numpy as ppn
 from raw2logit_amd import functional as F_
@@ -300,6 +300,62 @@ def check_u16_ingest(device):
     ref = (F_.static_pipeline(rawf, orc.DRONE_CAMERA_PARAMS).cpu() -
            torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
     assert torch.equal(sp(rawu).cpu(), ref)
+
+
+def check_aux_losses(golden, device):
+    """SSIM(window_size=11) and l2_regularization (train.py:259-262) against the reference's own utils/ssim.py /
+    utils/base.py run on the same inputs (tests/golden/aux_losses.npz), forward value and gradient w.r.t. the
+    adversarial processor's output; then the AuxLoss composition of two processors."""
+    from raw2logit_amd import losses
+    g = golden['aux_losses']
+    for case in AUX_CASES:
+        x_np, y_np = aux_inputs(case)
+        x = torch.from_numpy(x_np).to(device)
+        y = torch.from_numpy(y_np).to(device).requires_grad_(True)
+        v = losses.SSIM(window_size=11)(x, y)
+        (3.0 * v).backward()
+        name = case['name']
+        assert abs(v.item() - float(g[name + '/ssim'])) <= 5e-6, (name, v.item(), float(g[name + '/ssim']))
+        gref = 3.0 * g[name + '/ssim_grad']
+        err = np.abs(y.grad.cpu().numpy() - gref).max()
+        assert err <= 2e-3 * np.abs(gref).max() + 1e-9, (name, err, np.abs(gref).max())
+        if x_np.size % 4 == 0:
+            y2 = torch.from_numpy(y_np).to(device).requires_grad_(True)
+            l2 = losses.l2_regularization(x, y2)
+            (0.5 * l2).backward()
+            assert abs(l2.item() - float(g[name + '/l2'])) <= 2e-6 * float(g[name + '/l2'])
+            assert np.abs(y2.grad.cpu().numpy() - 0.5 * g[name + '/l2_grad']).max() <= 1e-6
+    # C ABI: the backward also works from a workspace that holds no D maps (it recomputes them first)
+    from raw2logit_amd import _lib
+    from raw2logit_amd._lib import ptr
+    x_np, y_np = aux_inputs(AUX_CASES[1])
+    x, y = torch.from_numpy(x_np).to(device), torch.from_numpy(y_np).to(device)
+    lib, stream = _lib.library_for(x)
+    B, C, H, W = x.shape
+    nws = lib.r2l_aux_workspace_bytes(B, C, H, W)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    grad = torch.empty_like(y)
+    one = torch.ones(1, dtype=torch.float32, device=x.device)
+    lib.check(lib.r2l_ssim_bwd(ptr(x), ptr(y), ptr(one), ptr(grad), ptr(ws), nws, 0, B, C, H, W, stream), 'ssim_bwd')
+    gref = g[AUX_CASES[1]['name'] + '/ssim_grad']
+    assert np.abs(grad.cpu().numpy() - gref).max() <= 2e-3 * np.abs(gref).max()
+    # AuxLoss: default processor under no_grad, adversarial processor (perturbed) with grad (utils/base.py:346-358)
+    raw = torch.from_numpy(orc.synth_raw(2, 64, 72, seed=31, kind='scene')).to(device)
+    p_def = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=False).to(device)
+    p_adv = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=False).to(device)
+    with torch.no_grad():
+        p_adv.gamma_correct.fill_(2.0)
+        p_adv.white_balance.mul_(1.1)
+    aux = losses.AuxLoss(losses.SSIM(window_size=11), p_adv, p_def, weight=0.7)
+    out_adv = p_adv(raw)
+    loss = aux(raw)
+    loss.backward()
+    with torch.no_grad():
+        ref_v, ref_g = orc.ssim(p_def(raw).cpu().numpy(), out_adv.detach().cpu().numpy())
+    assert abs(loss.item() - 0.7 * ref_v) <= 5e-6
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in p_adv.parameters())
+    assert float(p_adv.gamma_correct.grad.abs().sum()) > 0
+    assert all(p.grad is None for p in p_def.parameters())
 
 
 def check_harness(golden, device):

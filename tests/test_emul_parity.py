@@ -59,3 +59,7 @@ def test_16bit_containers_are_bit_identical_to_host_normalised_frames(emulation)
 
 def test_static_chain_combinations(emulation):
     pc.check_static_combinations('cpu')
+
+
+def test_adversarial_aux_losses(golden, emulation):
+    pc.check_aux_losses(golden, 'cpu')

@@ -142,3 +142,7 @@ def test_16bit_containers_are_bit_identical_to_host_normalised_frames(dev):
 
 def test_static_chain_combinations(dev):
     pc.check_static_combinations(dev)
+
+
+def test_adversarial_aux_losses(golden, dev):
+    pc.check_aux_losses(golden, dev)

@@ -131,3 +131,17 @@ def test_reference_constants_pin_the_third_party_restatements():
     mosaic = orc.raw2rgb(cfa[None], None, reduce_size=False)
     t = orc.conv2d(mosaic, P.debayer, 'mirror')[0].transpose(1, 2, 0)
     assert np.abs(d[1:-1, 1:-1] - t[1:-1, 1:-1]).max() < 1e-12
+
+
+def test_aux_loss_oracle_matches_reference(golden):
+    """oracle SSIM / l2 (value and gradient) against the reference's utils/ssim.py / utils/base.py outputs"""
+    from oracle.golden_cases import AUX_CASES, aux_inputs
+    g = golden['aux_losses']
+    for case in AUX_CASES:
+        x, y = aux_inputs(case)
+        v, grad = orc.ssim(x, y)
+        assert abs(v - float(g[case['name'] + '/ssim'])) < 5e-7
+        assert np.abs(grad - g[case['name'] + '/ssim_grad']).max() < 1e-7
+        l2, l2g = orc.l2_regularization(x, y)
+        assert abs(l2 - float(g[case['name'] + '/l2'])) <= 2e-6 * l2
+        assert np.abs(l2g - g[case['name'] + '/l2_grad']).max() < 1e-6
