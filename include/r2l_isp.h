@@ -118,6 +118,14 @@ int r2l_bn_finalize(const double *stats, int nranks, float *bn_mean_istd, double
                     float *running_mean, float *running_var, long long *num_batches_tracked, double eps,
                     double momentum, void *stream);
 
+/* One rank: the statistics pass of r2l_isp_fwd (R2L_F_STATS_ONLY) and r2l_bn_finalize in ONE launch -- the
+ * workgroup that finishes the reduction also derives mean / 1/std and updates the running statistics.  The
+ * workspace is initialised by this call; the apply pass follows with R2L_F_FOLDED_VALID.                 */
+int r2l_isp_fwd_stats_bn(const float *raw, const float *params, const float *additive, double *stats,
+                         float *bn_mean_istd, double *moments, float *running_mean, float *running_var,
+                         long long *num_batches_tracked, double eps, double momentum, void *workspace,
+                         size_t workspace_bytes, int B, int H, int W, void *stream);
+
 /* Several GPUs: gathered_sums double[nranks][6] = the `sums` vectors of r2l_bn_bwd_reduce of all ranks, added in
  * rank order and divided by *n (global pixel count, moments[6]) -> bn_bwd float[6] for r2l_isp_bwd.      */
 int r2l_bn_bwd_means(const double *gathered_sums, int nranks, const double *n, float *bn_bwd, void *stream);
@@ -178,6 +186,10 @@ int r2l_isp_bwd_u16(const unsigned short *raw, float denom, const float *params,
                     const float *bn_mean_istd, const float *bn_bwd, const float *grad_out,
                     float *grad_params, void *workspace, size_t workspace_bytes, int B, int H, int W,
                     int flags, void *stream);
+int r2l_isp_fwd_stats_bn_u16(const unsigned short *raw, float denom, const float *params, const float *additive,
+                             double *stats, float *bn_mean_istd, double *moments, float *running_mean,
+                             float *running_var, long long *num_batches_tracked, double eps, double momentum,
+                             void *workspace, size_t workspace_bytes, int B, int H, int W, void *stream);
 int r2l_raw2rgb_fwd_u16(const unsigned short *raw, float denom, const float *black_level, float *out, int B,
                         int H, int W, int reduce_size, int out_channels, void *stream);
 int r2l_static_fwd_u16(const unsigned short *raw, float denom, float *out, int B, int H, int W,

@@ -44,6 +44,15 @@ _SIGNATURES = {
     'r2l_bn_finalize': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_float_p, ctypes.c_void_p, _c_float_p,
                                        _c_float_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_void_p]),
+    'r2l_isp_fwd_stats_bn': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p,
+                                            ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'r2l_isp_fwd_stats_bn_u16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, _c_float_p, _c_float_p,
+                                                ctypes.c_void_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p,
+                                                ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                                ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_void_p]),
     'r2l_bn_bwd_means': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, _c_float_p, ctypes.c_void_p]),
     'r2l_bn_bwd_reduce': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p,
                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,

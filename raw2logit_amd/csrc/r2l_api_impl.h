@@ -324,7 +324,8 @@ static int r2l_check_raw(const R2LRaw& raw, int W, const char* who) {
 
 static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float* additive,
                             const float* bn_mean_istd, float* out, double* stats, void* workspace,
-                            size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
+                            size_t workspace_bytes, int B, int H, int W, int flags, void* stream,
+                            const R2LBnFinalizeArgs* fin = nullptr) {
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (int e = r2l_check_raw(raw, W, "r2l_isp_fwd")) return e;
   if (!params || !workspace) return r2l_fail(-1, "r2l_isp_fwd: null pointer");
@@ -356,6 +357,10 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
   // are valid: this call or an earlier one on this workspace ran the fold kernel)
   a.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6};
   a.stats_out = stats;
+  if (fin)
+    a.fin = *fin;
+  else
+    a.fin.bn = nullptr;
   const bool exact = (H % GFwd::TH == 0) && (W % GFwd::TW == 0);
   int e;
   if (raw.u16)
@@ -650,6 +655,34 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
                 size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
   return r2l_isp_fwd_impl(r2l_raw_f32(raw), params, additive, bn_mean_istd, out, stats, workspace, workspace_bytes,
                           B, H, W, flags, stream);
+}
+// statistics pass + BatchNorm bookkeeping in one launch (one rank: no exchange between the two)
+static int r2l_isp_fwd_stats_bn_impl(const R2LRaw& raw, const float* params, const float* additive, double* stats,
+                                     float* bn_mean_istd, double* moments, float* running_mean, float* running_var,
+                                     long long* num_batches_tracked, double eps, double momentum, void* workspace,
+                                     size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (!stats || !bn_mean_istd) return r2l_fail(-1, "r2l_isp_fwd_stats_bn: null pointer");
+  if ((running_mean == nullptr) != (running_var == nullptr))
+    return r2l_fail(-1, "r2l_isp_fwd_stats_bn: running_mean and running_var go together");
+  R2LBnFinalizeArgs f{stats, 1, bn_mean_istd, moments, running_mean, running_var, eps, momentum, num_batches_tracked};
+  return r2l_isp_fwd_impl(raw, params, additive, nullptr, nullptr, stats, workspace, workspace_bytes, B, H, W,
+                          R2L_F_STATS_ONLY, stream, &f);
+}
+int r2l_isp_fwd_stats_bn(const float* raw, const float* params, const float* additive, double* stats,
+                         float* bn_mean_istd, double* moments, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, double eps, double momentum, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, void* stream) {
+  return r2l_isp_fwd_stats_bn_impl(r2l_raw_f32(raw), params, additive, stats, bn_mean_istd, moments, running_mean,
+                                   running_var, num_batches_tracked, eps, momentum, workspace, workspace_bytes, B,
+                                   H, W, stream);
+}
+int r2l_isp_fwd_stats_bn_u16(const unsigned short* raw, float denom, const float* params, const float* additive,
+                             double* stats, float* bn_mean_istd, double* moments, float* running_mean,
+                             float* running_var, long long* num_batches_tracked, double eps, double momentum,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  return r2l_isp_fwd_stats_bn_impl(r2l_raw_u16(raw, denom), params, additive, stats, bn_mean_istd, moments,
+                                   running_mean, running_var, num_batches_tracked, eps, momentum, workspace,
+                                   workspace_bytes, B, H, W, stream);
 }
 int r2l_isp_fwd_u16(const unsigned short* raw, float denom, const float* params, const float* additive,
                     const float* bn_mean_istd, float* out, double* stats, void* workspace,

@@ -641,6 +641,55 @@ R2L_HD void r2l_chroma_row2(const float vw[3][6], const FT& F, r2l_p2 u[2], r2l_
   }
 }
 
+// ---- BatchNorm bookkeeping on the device (no host round trip) ---------------------------------------
+// tot[7] = sum_c(x-.5)[3], sum_c((x-.5)^2)[3], n  (already summed over ranks)  ->
+//   bn[6]       = mean[3], 1/sqrt(var_biased + eps)[3]                (what the apply pass consumes)
+//   moments[6]  = mean[3], var_biased[3] (float64)
+//   running_mean / running_var (optional): nn.BatchNorm2d update with `momentum`, unbiased variance
+struct R2LBnFinalizeArgs {
+  const double* tot;  // [nranks][7]: the statistics vectors of all ranks, added here in rank order
+  int nranks;
+  float* bn;
+  double* moments;
+  float* running_mean;
+  float* running_var;
+  double eps, momentum;  // momentum < 0: cumulative moving average, 1 / num_batches_tracked (after its increment)
+  long long* num_batches_tracked;  // optional, incremented by one
+};
+R2L_BLOCKFN void r2l_bn_finalize_phases(const R2LBnFinalizeArgs& a) {
+  R2L_PHASE_BEGIN
+  if (tid < 3) {
+    const long long nbt = a.num_batches_tracked ? *a.num_batches_tracked + 1 : 1;
+    const double mom = a.momentum < 0.0 ? 1.0 / (double)nbt : a.momentum;
+    double n = 0.0, s1 = 0.0, s2 = 0.0;  // rank order: every rank computes bit-identical statistics
+    for (int r = 0; r < a.nranks; ++r) {
+      n += a.tot[r * 7 + 6];
+      s1 += a.tot[r * 7 + tid];
+      s2 += a.tot[r * 7 + 3 + tid];
+    }
+    const double m1 = s1 / n;
+    double var = s2 / n - m1 * m1;
+    var = var < 0.0 ? 0.0 : var;
+    const double mean = m1 + 0.5;
+    a.bn[tid] = (float)mean;
+    a.bn[3 + tid] = (float)(1.0 / sqrt(var + a.eps));
+    if (a.moments) {
+      a.moments[tid] = mean;
+      a.moments[3 + tid] = var;
+      a.moments[6] = n;  // pixel count of the global batch (the BatchNorm backward divides by it)
+    }
+    if (a.running_mean) {
+      const double unb = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+      a.running_mean[tid] = (float)((1.0 - mom) * (double)a.running_mean[tid] + mom * mean);
+      a.running_var[tid] = (float)((1.0 - mom) * (double)a.running_var[tid] + mom * unb);
+    }
+  }
+  R2L_PHASE_END
+  R2L_PHASE_BEGIN  // after every lane has read the counter
+  if (tid == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+  R2L_PHASE_END
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -655,6 +704,7 @@ struct R2LFwdArgs {
   float* debug;  // diagnostic builds
   R2LTree tree;  // in-kernel final reduction of the statistics -> stats_out[0..6), stats_out[6] = B*H*W
   double* stats_out;
+  R2LBnFinalizeArgs fin;  // fin.bn != null (one rank): the last workgroup also runs the BatchNorm bookkeeping
 };
 
 // Two forward workgroups share a CU; the hardware favours the older one's waves, so left alone the younger
@@ -864,11 +914,21 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   R2L_STAMP_FLUSH(a.debug, bid)
   if (a.stat_partial) {
     R2L_BLOCK_REDUCE_F(6, R2L_ACC_FWD, regs, lds, a.stat_partial, bid, nblk)
-    if (a.tree.counters && r2l_tree_finish<6>(a.tree, bid, nblk, lds, a.stats_out, (double*)(lds + 512),
+    double* sl = (double*)(lds + 4);  // totals in LDS: the bookkeeping below reads them back
+    if (a.tree.counters && r2l_tree_finish<6>(a.tree, bid, nblk, lds, sl, (double*)(lds + 512),
                                               (R2L_RED_FLOATS - 512) / 2)) {
       R2L_PHASE_BEGIN
-      if (tid == 0) a.stats_out[6] = (double)a.B * (double)a.H * (double)a.W;
+      if (tid == 0) sl[6] = (double)a.B * (double)a.H * (double)a.W;
       R2L_PHASE_END
+      R2L_PHASE_BEGIN
+      if (tid < 7) a.stats_out[tid] = sl[tid];
+      R2L_PHASE_END
+      if (a.fin.bn) {
+        R2LBnFinalizeArgs f = a.fin;
+        f.tot = sl;
+        f.nranks = 1;
+        r2l_bn_finalize_phases(f);
+      }
     }
   }
 }

@@ -126,6 +126,16 @@ def gather_ranks(vec, group=None):
     return out, n
 
 
+def _bn_buffers(bn_module, dev):
+    """(running_mean, running_var, num_batches_tracked) of a BatchNorm module that tracks them, else Nones"""
+    if bn_module is not None and bn_module.track_running_stats and bn_module.running_mean is not None:
+        rm, rv, nbt = bn_module.running_mean, bn_module.running_var, bn_module.num_batches_tracked
+        if rm.device != dev or nbt.dtype != torch.int64:
+            raise RuntimeError('BatchNorm buffers must live on the device of the frames')
+        return rm, rv, nbt
+    return None, None, None
+
+
 def bn_finalize(lib, stream, stats, nranks, bn_module, eps, momentum):
     """statistics vectors of all ranks -> (mean, istd) float32[6], moments float64[7] (mean, biased var, global
     pixel count); updates the module's running statistics and num_batches_tracked on the device the way
@@ -133,11 +143,7 @@ def bn_finalize(lib, stream, stats, nranks, bn_module, eps, momentum):
     dev = stats.device
     bn = torch.empty(6, dtype=torch.float32, device=dev)
     moments = torch.empty(7, dtype=torch.float64, device=dev)
-    rm = rv = nbt = None
-    if bn_module is not None and bn_module.track_running_stats and bn_module.running_mean is not None:
-        rm, rv, nbt = bn_module.running_mean, bn_module.running_var, bn_module.num_batches_tracked
-        if rm.device != dev or nbt.dtype != torch.int64:
-            raise RuntimeError('BatchNorm buffers must live on the device of the frames')
+    rm, rv, nbt = _bn_buffers(bn_module, dev)
     lib.check(lib.r2l_bn_finalize(ptr(stats), nranks, ptr(bn), ptr(moments), ptr(rm), ptr(rv), ptr(nbt),
                                   float(eps), float(momentum) if momentum is not None else -1.0, stream),
               'r2l_bn_finalize')
@@ -188,11 +194,23 @@ class _IspFused(torch.autograd.Function):
         ctx.totals = None
         if bn_mode == BN_TRAIN:
             stats = torch.empty(7, dtype=torch.float64, device=dev)
-            lib.check(_isp_fwd(lib, raw, denom, ptr(packed), ptr(additive), None, None, ptr(stats),
-                               ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream), 'r2l_isp_fwd(stats)')
+            if _group_size(group) == 1:
+                # one rank: statistics + BatchNorm bookkeeping in one launch
+                bn = torch.empty(6, dtype=torch.float32, device=dev)
+                moments = torch.empty(7, dtype=torch.float64, device=dev)
+                rm, rv, nbt = _bn_buffers(bn_module, dev)
+                tail = (ptr(packed), ptr(additive), ptr(stats), ptr(bn), ptr(moments), ptr(rm), ptr(rv), ptr(nbt),
+                        float(eps), float(momentum) if momentum is not None else -1.0, ptr(ws), nws, B, H, W, stream)
+                if denom is None:
+                    lib.check(lib.r2l_isp_fwd_stats_bn(ptr(raw), *tail), 'r2l_isp_fwd_stats_bn')
+                else:
+                    lib.check(lib.r2l_isp_fwd_stats_bn_u16(ptr(raw), denom, *tail), 'r2l_isp_fwd_stats_bn_u16')
+            else:
+                lib.check(_isp_fwd(lib, raw, denom, ptr(packed), ptr(additive), None, None, ptr(stats),
+                                   ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream), 'r2l_isp_fwd(stats)')
+                gathered, nranks = gather_ranks(stats, group)
+                bn, moments = bn_finalize(lib, stream, gathered, nranks, bn_module, eps, momentum)
             folded = _lib.R2L_F_FOLDED_VALID
-            gathered, nranks = gather_ranks(stats, group)
-            bn, moments = bn_finalize(lib, stream, gathered, nranks, bn_module, eps, momentum)
             ctx.totals = moments       # [6] = pixel count of the global batch
         elif bn_mode == BN_EVAL:
             mean = bn_module.running_mean.detach().to(device=dev, dtype=torch.float64)
