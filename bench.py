@@ -117,8 +117,7 @@ def main_static(args):
     ranks: static mode needs no collective)."""
     import torch
     import torch.distributed as dist
-    from oracle import isp_oracle as orc
-    from raw2logit_amd import _lib, functional as F_
+    from raw2logit_amd import _lib, cameras, functional as F_
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -134,7 +133,7 @@ def main_static(args):
     raw = u.to(torch.uint16) if args.raw_u16 else u.to(torch.float32) / 4095.0
 
     def step():
-        return F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, args.debayer, 'none', 'none', bits=12)
+        return F_.static_pipeline(raw, cameras.DRONE, args.debayer, 'none', 'none', bits=12)
 
     def barrier():
         if world > 1:
@@ -191,8 +190,7 @@ def main():
     import torch
     import torch.distributed as dist
     import numpy as np
-    from oracle import isp_oracle as orc           # synthetic inputs only (and cpu_baseline)
-    from raw2logit_amd import _lib
+    from raw2logit_amd import _lib, cameras         # (the oracle is only touched by the cpu_baseline leg)
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -207,12 +205,11 @@ def main():
     lib = _lib.device_library()                     # raises if the HIP extension is missing
 
     B, S = args.batch, args.size
-    raw_np = orc.synth_raw(B, S, S, seed=rank, kind='uniform')      # float32 = u16 / 4095
-    if args.raw_u16:
-        raw_np = np.rint(raw_np.astype(np.float64) * 4095.0).astype(np.uint16)
-    raw = torch.from_numpy(raw_np).to(dev)
+    # SURVEY.md section 8d "perf" distribution: uniform 12-bit codes, raw = u16 / 4095 (float32)
+    u16 = np.random.default_rng(rank).integers(0, 4096, (B, S, S)).astype(np.uint16)
+    raw = torch.from_numpy(u16 if args.raw_u16 else u16.astype(np.float32) / np.float32(4095)).to(dev)
     cot = torch.randn((B, 3, S, S), device=dev, generator=torch.Generator(dev).manual_seed(1 + rank))
-    model = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, track_stages=False, batch_norm_output=True)
+    model = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True)
     model = model.to(dev).train()
     model.raw_bits = 12
     if world > 1:
