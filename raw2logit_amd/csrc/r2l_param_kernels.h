@@ -987,15 +987,13 @@ struct R2LGoutPre {
   r2l_f4 g[2][3];
 };
 template <class G>
-R2L_HD void r2l_bwd1_fetch_gout(int tid, const R2LBwd1Args& a, const R2LTile& t, R2LGoutPre& gp) {
+R2L_HD void r2l_bwd1_fetch_gout(int tid, const R2LBwd1Args& a, const R2LTile& t, R2LGoutPre& gp, int r) {
   int tx, row0, py;
   G::thread_tile(tid, tx, row0, py);
   const unsigned plane = (unsigned)a.H * (unsigned)a.W;
   const float* gb = a.gout + (size_t)t.b * 3 * plane;
   const unsigned pix0 = (unsigned)(t.oy + row0) * (unsigned)a.W + (unsigned)(t.ox + 4 * tx);
   R2L_PRAGMA_UNROLL
-  for (int r = 0; r < 2; ++r)
-    R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k)
     gp.g[r][k] = *(const r2l_f4*)(gb + (unsigned)k * plane + pix0 + (unsigned)(2 * r) * (unsigned)a.W);
 }
@@ -1193,7 +1191,9 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
-    if (!MAYBE_RAGGED) r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre));  // consumed in the pixel phase
+    // consumed in the pixel phase; one row per stencil phase (six loads per lane at once queue up in the
+    // texture-address path and hold every wave at its next instruction)
+    if (!MAYBE_RAGGED) r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 0);
     if (t.border)
       r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     else
@@ -1201,6 +1201,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     R2L_PHASE_END
     R2L_STAMP(1)
     R2L_PHASE_BEGIN
+    if (!MAYBE_RAGGED) r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 1);
     r2l_compute_yp<G>(tid, Y, YP, F);
     R2L_PHASE_END
     R2L_STAMP(2)
