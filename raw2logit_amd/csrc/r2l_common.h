@@ -3,7 +3,7 @@
 // Every kernel body is written as a sequence of PHASES: functions of (tid, LDS, per-thread
 // registers) separated by workgroup barriers.  libr2l_isp.so compiles them with hipcc for gfx950.
 // The same phase functions also compile as plain C++ when R2L_EMUL is defined: tests/_build/
-// libr2l_emul.so then runs every phase for tid = 0..255 in a loop, which lets the CPU-only test
+// libr2l_emul.so then runs every phase for tid = 0..511 in a loop, which lets the CPU-only test
 // suite check tiling / halo / indexing logic of the REAL kernel source against the oracle.  The
 // emulation is test infrastructure: the product loader (raw2logit_amd/_lib.py) refuses it.
 #pragma once
@@ -282,16 +282,6 @@ R2L_HD const R2LFolded* r2l_opaque(const R2LFolded* p) {
   return p;
 }
 
-// T = M_RGB_2_YUV * colour_correction * diag(white_balance), float64
-R2L_HD void r2l_fold_T(const float* P, double T[3][3]) {
-  for (int k = 0; k < 3; ++k)
-    for (int c = 0; c < 3; ++c) {
-      double s = 0;
-      for (int j = 0; j < 3; ++j)
-        s += (double)P[R2L_P_M_RGB2YUV + k * 3 + j] * (double)P[R2L_P_CCM + j * 3 + c];
-      T[k][c] = s * (double)P[R2L_P_WHITE_BALANCE + c];
-    }
-}
 // element (k, c) of T = M_RGB_2_YUV * colour_correction * diag(white_balance), float64
 R2L_HD double r2l_fold_T_one(const float* P, int k, int c) {
   double s = 0;

@@ -1,15 +1,16 @@
 // r2l_param_kernels.h -- fused parametrized ISP (torch semantics), forward and backward.
 //
 // Replaces ParametrizedProcessing.forward (processing/pipeline_torch.py:175-225) and the autograd
-// graph behind it.  One workgroup (256 threads = 4 wavefronts) owns a TW x TH output tile and a
+// graph behind it.  One workgroup (512 threads = 8 wavefronts) owns a TW x TH output tile and a
 // FRAME of (TW+8) x (TH+8) positions around it (halo 4 = 1 debayer + 1 sharpen + 2 blur).  Three
 // float planes of the frame live in LDS:
 //     V   black-level-corrected raw value, mirror-extended outside the image      (:183, :233)
 //     Y   luma after debayer/WB/CCM/RGB->YUV, ZERO outside the image                (:187-195 padding=1)
 //     YP  sharpened luma, mirror-extended outside the image                         (:195, :165 reflect)
 // Only the luma plane carries a halo, so the recomputed-halo cost is 2 x 9 FMA per frame pixel; the
-// heavy per-pixel work (5x5 blur, chroma, YUV->RGB, clip, gamma, BatchNorm) runs once per pixel on a
-// 4x4 register micro-tile per thread, reading LDS with 128-bit accesses.
+// heavy per-pixel work (5x5 blur, chroma, YUV->RGB, clip, gamma, BatchNorm) runs once per pixel, 4 columns
+// x 2 rows per thread, two adjacent pixels per packed-f32 instruction, reading LDS with 128-bit accesses.
+// DESIGN.md section 3.2 has the whole picture (phases, pipeline, tile walk, reductions).
 #pragma once
 #include "r2l_common.h"
 
@@ -287,25 +288,6 @@ R2L_HD void r2l_store_plane_s2(int tid, float* Pl, const R2LPrefetch<G>& pf) {
   }
 }
 
-// walk of work items laid out as NROW rows of CPR items, ids tid, tid+256, ...
-template <int CPR>
-struct R2LItemWalk {
-  static constexpr int DROW = R2L_NT / CPR, DCOL = R2L_NT % CPR;
-  int row, col;
-  R2L_MEMBER void init(int tid) {
-    row = tid / CPR;
-    col = tid - row * CPR;
-  }
-  R2L_MEMBER void next() {
-    row += DROW;
-    col += DCOL;
-    if (col >= CPR) {
-      col -= CPR;
-      row += 1;
-    }
-  }
-};
-
 // (RPI + 2) rows x 6 columns window around a 4-wide x RPI-tall item at (fy0, fx): rows fy0-1..fy0+RPI,
 // columns fx-1..fx+4 of an UNSHIFTED plane.  Rows past the end of the plane (items of the last row group)
 // are clamped: their values only feed output rows that are not stored.
@@ -474,39 +456,6 @@ R2L_HD void r2l_rows_3x6(const float* Pl, int tx, int frow, float w[3][6]) {
     w[i][3] = m.z;
     w[i][4] = m.w;
     w[i][5] = h.x;
-  }
-}
-
-R2L_HD void r2l_blur_row(const float yw[5][8], R2LFoldedRef F, float ypp[4]) {
-  R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) ypp[c] = 0.f;
-  R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 5; ++i)
-    R2L_PRAGMA_UNROLL
-  for (int j = 0; j < 5; ++j) {
-    const float w = F.blur[i * 5 + j];
-    R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) ypp[c] = fmaf(w, yw[i][c + j], ypp[c]);
-  }
-}
-
-// chroma of one output row with row parity PY (pixel column parity = c & 1)
-template <int PY>
-R2L_HD void r2l_chroma_row(const float vw[3][6], R2LFoldedRef F, float u[4], float v[4]) {
-  R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) u[c] = v[c] = 0.f;
-  R2L_PRAGMA_UNROLL
-  for (int px = 0; px < 2; ++px)
-    R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 3; ++i)
-    R2L_PRAGMA_UNROLL
-  for (int j = 0; j < 3; ++j) {
-    const float wu = F.AU[PY * 2 + px][i * 3 + j], wv = F.AV[PY * 2 + px][i * 3 + j];
-    R2L_PRAGMA_UNROLL
-    for (int c = px; c < 4; c += 2) {
-      u[c] = fmaf(wu, vw[i][c + j], u[c]);
-      v[c] = fmaf(wv, vw[i][c + j], v[c]);
-    }
   }
 }
 
