@@ -156,6 +156,11 @@ def library_for(t):
     """the library that may touch tensor `t`, plus the stream handle to enqueue on."""
     if t.is_cuda:
         lib = device_library()
+        if t.device.index is not None and t.device.index != torch.cuda.current_device():
+            # kernels are launched on the calling thread's current HIP device (one process per GPU is the
+            # supported layout: torch.cuda.set_device(local_rank) at start-up)
+            raise R2LError(f'the tensor lives on {t.device} but the current device is cuda:'
+                           f'{torch.cuda.current_device()}; use torch.cuda.set_device / torch.cuda.device(...)')
         return lib, ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     if _EMUL_LIB is not None:
         return _EMUL_LIB, ctypes.c_void_p(0)
