@@ -52,7 +52,7 @@ enum {
 
 /* static-pipeline selectors (processing/pipeline_numpy.py:92-122) */
 enum { R2L_DEBAYER_BILINEAR = 0, R2L_DEBAYER_MALVAR2004 = 1 };
-enum { R2L_SHARPEN_NONE = 0, R2L_SHARPEN_FILTER = 1 };
+enum { R2L_SHARPEN_NONE = 0, R2L_SHARPEN_FILTER = 1, R2L_SHARPEN_UNSHARP = 2 };
 enum { R2L_DENOISE_NONE = 0, R2L_DENOISE_GAUSSIAN = 1, R2L_DENOISE_MEDIAN = 2 };
 
 int r2l_abi_version(void);
@@ -160,7 +160,7 @@ int r2l_additive_bwd(const float *grad_out, const float *out, const float *bn_me
 
 /* ---- static pipeline, numpy semantics (processing(), processing/pipeline_numpy.py:70-141, batched):
  * remove_blacklv (:152-158) -> demosaicing_CFA_Bayer_{bilinear,Malvar2004} (:92-95) -> wb (:161-162) ->
- * CCM (:165-167) -> [sharpening_filter (:180-191)] -> [gaussian_denoising (:203-209) | median_denoising
+ * CCM (:165-167) -> [sharpening_filter (:180-191) | unsharp_masking (:170-177)] -> [gaussian_denoising (:203-209) | median_denoising
  * (:194-200)] -> clip[0,1] (:138) -> x**(1/gamma) (:241-244).  Linear part in float64 like the reference,
  * output (B,3,H,W) float32 (RawProcessingPipeline.__call__, :55-67).  camera_host: double[16] =
  * black_level[4], white_balance[3], colour_matrix[9] (host memory).

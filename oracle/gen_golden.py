@@ -38,7 +38,7 @@ def import_reference():
         m.__all__ = []
         sys.modules[n] = m
     sys.modules['numpy.lib.function_base'].interp = np.interp
-    sys.modules['skimage.filters'].unsharp_mask = None
+    sys.modules['skimage.filters'].unsharp_mask = orc.unsharp_mask     # restated, see its docstring
     for n in ['rgb2hsv', 'hsv2rgb']:
         setattr(sys.modules['skimage.color'], n, None)
     # third-party arithmetic: published algorithms restated in the oracle
@@ -54,12 +54,19 @@ def import_reference():
     sys.modules['dataset'].Subset = object
     sys.modules['utils.base'].np2torch = None
     sys.modules['utils.base'].torch2np = None
-    sys.path.insert(0, REF)
+    # this repository ships its own drop-in `processing` package (a regular package, which would win over the
+    # reference's namespace package whatever the path order): keep the repository off sys.path while importing
+    saved_path = list(sys.path)
+    sys.path = [REF] + [p for p in sys.path if os.path.abspath(p or os.getcwd()) != REPO]
+    for name in [n for n in sys.modules if n == 'processing' or n.startswith('processing.')]:
+        del sys.modules[name]
     cwd = os.getcwd()
     os.chdir(REF)          # pipeline_torch.py:5-6 chdir's if README.md is not in cwd
     import processing.pipeline_numpy as ppn
     import processing.pipeline_torch as ppt
     os.chdir(cwd)
+    sys.path = saved_path
+    assert ppn.__file__.startswith(REF) and ppt.__file__.startswith(REF), (ppn.__file__, ppt.__file__)
     return ppn, ppt
 
 

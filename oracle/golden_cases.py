@@ -77,6 +77,11 @@ STATIC_CASES = [
          debayer='bilinear', sharpening='sharpening_filter', denoising='median_filter'),
     dict(name='tiny_4x4', seed=9, shape=(1, 4, 4), kind='uniform', camera='drone',
          debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    # the class defaults of RawProcessingPipeline (pipeline_numpy.py:40): unsharp_masking, no denoising
+    dict(name='drone_unsharp_class_default', seed=10, shape=(1, 32, 40), kind='scene', camera='drone',
+         debayer='bilinear', sharpening='unsharp_masking', denoising='gaussian'),
+    dict(name='drone_malvar_unsharp_median', seed=11, shape=(1, 24, 32), kind='scene', camera='drone',
+         debayer='malvar2004', sharpening='unsharp_masking', denoising='median_denoising'),
 ]
 
 

@@ -20,6 +20,7 @@ What is restated (all citations relative to /root/reference):
     sharpening_filter          :180-191
     gaussian_denoising         :203-209
     median_denoising           :194-200
+    unsharp_masking            :170-177
     adjust_gamma               :241-244
 
 Pinning status
@@ -39,6 +40,10 @@ Pinning status
       pinned by the reference's own K_G / K_RB restatement (pipeline_torch.py:13-19).
     - scikit-image==0.18.1 (environment.yml:343): rgb2yuv / yuv2rgb (call sites :184-189, :205-207).
       Pinned by M_RGB_2_YUV / M_YUV_2_RGB in pipeline_torch.py:21-26 (inverse agrees to 3.8e-8).
+    - scikit-image==0.18.1 unsharp_mask (call site :174, reached with multichannel=True from :117): restated
+      in unsharp_mask() below from the package's published source; nothing in the reference tree pins it.
+* adversarial auxiliary losses (utils/ssim.py SSIM / ssim, utils/base.py l2_regularization): PINNED --
+  both are pure torch and run unmodified in gen_golden.py (tests/golden/aux_losses.npz).
   The reference has no tests and no golden vectors of its own.
 """
 from __future__ import annotations
@@ -557,6 +562,40 @@ def sharpening_filter(image, kernel=np.array([[0, -1, 0], [-1, 5, -1], [0, -1, 0
     return yuv2rgb(img_yuv)
 
 
+def unsharp_mask(image, radius=1.0, amount=1.0, multichannel=False, preserve_range=False):
+    """scikit-image 0.18.1 `skimage.filters.unsharp_mask` restated (the package is absent from the image and
+    from the reference tree: PARITY UNPINNED): result = image + (image - gaussian(image, sigma=radius,
+    mode='reflect')) * amount, the Gaussian being scipy.ndimage.gaussian_filter with truncate=4.0; with
+    multichannel=True the filter runs separately on every slice along the LAST axis; preserve_range=False clips
+    to [0,1] / [-1,1].  The reference calls it with multichannel=True on the 2-D luma plane
+    (pipeline_numpy.py:117, :170-177), so each image COLUMN is a "channel" and is blurred along the rows only:
+    a vertical 9-tap unsharp mask."""
+    from scipy import ndimage
+    fimg = np.asarray(image, dtype=float)
+    vrange = None
+    if not preserve_range:
+        vrange = (-1.0, 1.0) if np.any(fimg < 0) else (0.0, 1.0)
+
+    def single(ch):
+        blurred = ndimage.gaussian_filter(ch, radius, mode='reflect', truncate=4.0)
+        res = ch + (ch - blurred) * amount
+        return np.clip(res, *vrange) if vrange is not None else res
+    if multichannel:
+        out = np.empty_like(fimg)
+        for c in range(fimg.shape[-1]):
+            out[..., c] = single(fimg[..., c])
+        return out
+    return single(fimg)
+
+
+def unsharp_masking(img, radius=1.0, amount=1.0, multichannel=True, preserve_range=True):
+    """pipeline_numpy.py:170-177 as processing() calls it (:117: multichannel=True)."""
+    img = rgb2yuv(img)
+    img[:, :, 0] = unsharp_mask(img[:, :, 0], radius=radius, amount=amount, multichannel=multichannel,
+                                preserve_range=preserve_range)
+    return yuv2rgb(img)
+
+
 def gaussian_denoising(img, sigma=0.5):
     """pipeline_numpy.py:203-209."""
     from scipy import ndimage
@@ -595,6 +634,8 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
     img = np.einsum('ijk,lk->ijl', img, np.array(colour_matrix).reshape(3, 3))
     if sharpening == "sharpening_filter":
         img = sharpening_filter(img)
+    if sharpening == "unsharp_masking":
+        img = unsharp_masking(img, radius=1.0, amount=1.0, multichannel=True)
     if denoising == "median_denoising":
         img = median_denoising(img)
     if denoising == "gaussian_denoising":

@@ -566,7 +566,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
   if (!out || !camera_host) return r2l_fail(-1, "r2l_static_fwd: null pointer");
   if (debayer != R2L_DEBAYER_BILINEAR && debayer != R2L_DEBAYER_MALVAR2004)
     return r2l_fail(-1, "r2l_static_fwd: unknown debayer");
-  if (sharpening != R2L_SHARPEN_NONE && sharpening != R2L_SHARPEN_FILTER)
+  if (sharpening != R2L_SHARPEN_NONE && sharpening != R2L_SHARPEN_FILTER && sharpening != R2L_SHARPEN_UNSHARP)
     return r2l_fail(-1, "r2l_static_fwd: unknown sharpening");
   if (denoising != R2L_DENOISE_NONE && denoising != R2L_DENOISE_GAUSSIAN && denoising != R2L_DENOISE_MEDIAN)
     return r2l_fail(-4, "r2l_static_fwd: denoising must be none, gaussian_denoising or median_denoising");
@@ -602,7 +602,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     if (int e = stream_pass(sa)) return e;
     double* cur = p0;
     double* other = p1;
-    const int ops[2] = {sharpening == R2L_SHARPEN_FILTER ? 1 : 0,
+    const int ops[2] = {sharpening == R2L_SHARPEN_FILTER ? 1 : (sharpening == R2L_SHARPEN_UNSHARP ? 4 : 0),
                         denoising == R2L_DENOISE_GAUSSIAN ? 2 : (denoising == R2L_DENOISE_MEDIAN ? 3 : 0)};
     for (int i = 0; i < 2; ++i) {
       if (!ops[i]) continue;
@@ -614,6 +614,12 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
       pa.W = W;
       pa.op = ops[i];
       for (int k = 0; k < 5; ++k) pa.gk[k] = a.gk[k];
+      {  // scipy _gaussian_kernel1d(sigma = 1, radius = int(4 * 1 + 0.5) = 4), normalised
+        double w[9], sum = 0;
+        for (int k = -4; k <= 4; ++k) sum += (w[k + 4] = exp(-0.5 * k * k));
+        for (int k = 0; k <= 4; ++k) pa.uk[k] = w[4 + k] / sum;
+        pa.amount = 1.0;
+      }
       size_t g = ((size_t)B * H * W / 2 + R2L_NT - 1) / R2L_NT;
       if (g > 16384) g = 16384;
       if (int e = r2l_launch_plane_filter(pa, (int)g, stream)) return e;

@@ -4,6 +4,10 @@
 //   op 1  sharpening_filter   convolve2d(Y, [[0,-1,0],[-1,5,-1],[0,-1,0]], 'same', fill 0)          :180-191
 //   op 2  gaussian_denoising  scipy.ndimage.gaussian_filter(Y, 0.5): 5 taps per axis, 'reflect'        :203-209
 //   op 3  median_denoising    scipy.ndimage.median_filter(Y, 3): 3x3, 'reflect'                        :194-200
+//   op 4  unsharp_masking     skimage.filters.unsharp_mask(Y, radius 1, amount 1, multichannel=True) as the
+//                             reference calls it (:117, :170-177): every COLUMN is a "channel", so the Gaussian
+//                             (sigma 1, 9 taps, 'reflect') runs along the rows only; Y + (Y - blurred)   [unpinned:
+//                             scikit-image is absent, see oracle/isp_oracle.py unsharp_mask]
 // One lane per pixel pair, neighbours straight from global memory (the plane is L2-resident per row band);
 // borders by index arithmetic (scipy 'reflect' = symmetric: b a | a b).  These chains are the long tail of
 // `--sp_*` sweeps, not the throughput configuration (that one is fused: r2l_static_stream.h).
@@ -15,6 +19,8 @@ struct R2LPlaneArgs {
   double* dst;
   int B, H, W, op;
   double gk[5];
+  double uk[5];      // op 4: half of the 9-tap Gaussian (sigma 1): uk[0] = centre tap ... uk[4] = offset +-4
+  double amount;     // op 4
 };
 R2L_HD void r2l_cswap(double& a, double& b) {
   const double lo = fmin(a, b), hi = fmax(a, b);
@@ -52,6 +58,14 @@ R2L_HD double r2l_plane_px(const R2LPlaneArgs& a, const double* img, int y, int 
       t[j] = a.gk[2] * c + (u1 + d1) * a.gk[1] + (u2 + d2) * a.gk[0];
     }
     return a.gk[2] * t[2] + (t[1] + t[3]) * a.gk[1] + (t[0] + t[4]) * a.gk[0];
+  }
+  if (a.op == 4) {
+    const double c = img[(size_t)y * a.W + x];
+    double blurred = a.uk[0] * c;  // scipy correlate1d, symmetric kernel: w0*c + sum_k (up_k + down_k) * w_k
+    R2L_PRAGMA_UNROLL
+    for (int k = 1; k <= 4; ++k)
+      blurred += (img[(size_t)r2l_symmetric(y - k, a.H) * a.W + x] + img[(size_t)r2l_symmetric(y + k, a.H) * a.W + x]) * a.uk[k];
+    return c + (c - blurred) * a.amount;
   }
   double p[9];
   R2L_PRAGMA_UNROLL

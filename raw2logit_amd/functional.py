@@ -286,7 +286,7 @@ def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
 # static pipeline (processing(), pipeline_numpy.py:70-141), batched
 # --------------------------------------------------------------------------------------------------
 _DEBAYER = {'bilinear': 0, 'malvar2004': 1}
-_SHARPEN = {'sharpening_filter': 1}
+_SHARPEN = {'sharpening_filter': 1, 'unsharp_masking': 2}
 _DENOISE = {'gaussian_denoising': 1, 'median_denoising': 2}
 
 

@@ -173,7 +173,7 @@ def check_static_combinations(device):
         raw_np = u.astype(np.float32) / np.float32(4095)
         raw = torch.from_numpy(raw_np).to(device)
         for deb in ('bilinear', 'malvar2004'):
-            for sh in ('none', 'sharpening_filter'):
+            for sh in ('none', 'sharpening_filter', 'unsharp_masking'):
                 for dn in ('none', 'gaussian_denoising', 'median_denoising'):
                     ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
                     out = F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
