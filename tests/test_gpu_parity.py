@@ -8,6 +8,7 @@ import torch
 from oracle import isp_oracle as orc
 from oracle.golden_cases import PARAM_CASES, STATIC_CASES
 import parity_checks as pc
+from raw2logit_amd.processing import pipeline_torch as ppt
 
 pytestmark = pytest.mark.gpu
 
@@ -146,3 +147,24 @@ def test_static_chain_combinations(dev):
 
 def test_adversarial_aux_losses(golden, dev):
     pc.check_aux_losses(golden, dev)
+
+
+def test_survives_hip_graph_capture(dev):
+    """Every call only enqueues on the current stream (no host round trip, no allocation outside torch's
+    allocator, arrival counters left at zero), so forward + backward can be captured and replayed as HIP graphs."""
+    import copy
+    raw = torch.from_numpy(orc.synth_raw(4, 128, 128, seed=41, kind='scene')).to(dev)
+    cot = torch.randn((4, 3, 128, 128), device=dev, generator=torch.Generator(dev).manual_seed(3))
+    m = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).to(dev).train()
+    m2 = copy.deepcopy(m)
+    graphed = torch.cuda.make_graphed_callables(m2, (raw,))
+    for _ in range(3):          # replays
+        for p in list(m.parameters()) + list(m2.parameters()):
+            p.grad = None
+        y0 = m(raw)
+        y1 = graphed(raw)
+        y0.backward(cot)
+        y1.backward(cot)
+        assert torch.equal(y0, y1)
+        for p, q in zip(m.parameters(), m2.parameters()):
+            assert torch.equal(p.grad, q.grad)
