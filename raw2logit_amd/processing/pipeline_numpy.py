@@ -32,6 +32,10 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
     name no algorithm skip their stage (the signature default denoising="median_filter" is one)."""
     if gaussian_sigma != 0.5 and denoising == 'gaussian_denoising':
         raise NotImplementedError('only gaussian_sigma=0.5 (the reference default) is built')
+    if median_kernel_size != 3 and denoising == 'median_denoising':
+        raise NotImplementedError('only median_kernel_size=3 (the reference default) is built')
+    if (sharp_radius != 1.0 or sharp_amount != 1.0) and sharpening == 'unsharp_masking':
+        raise NotImplementedError('only sharp_radius=1.0, sharp_amount=1.0 (the reference defaults) are built')
     raw = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None].to(_device())
     out = F_.static_pipeline(raw, (black_level, white_balance, colour_matrix), debayer=debayer,
                              sharpening=sharpening, denoising=denoising, gamma=gamma)
