@@ -165,6 +165,32 @@ def check_static_case(case, golden, device, atol=1e-5):
     return float(err.max())
 
 
+def check_static_wrappers(golden, device):
+    """the per-image API of the reference: processing() (numpy in, (H,W,3) float64 out, black level removed from
+    the caller's array in place, :152-158) and RawProcessingPipeline.__call__ ((3,H,W) float32 tensor, :55-67),
+    including the class defaults (unsharp_masking, denoising string that names no algorithm)."""
+    from oracle.golden_cases import STATIC_CASES
+    g = golden['static_cases']
+    for case in STATIC_CASES:
+        if device != 'cpu' and not torch.cuda.is_available():
+            break
+        name = case['name']
+        cam = orc.CAMERAS[case['camera']]
+        img = g[name + '/raw'][0].astype(np.float64).copy()
+        keep = img.copy()
+        out = ppn.processing(img, *cam, debayer=case['debayer'], sharpening=case['sharpening'],
+                             denoising=case['denoising'])
+        assert out.dtype == np.float64 and out.shape == img.shape + (3,)
+        assert np.abs(out - g[name + '/out_hwc_f64'][0]).max() <= 1e-5
+        bl = cam[0]
+        assert np.allclose(img[0::2, 0::2], keep[0::2, 0::2] - bl[0]) and np.allclose(img[1::2, 1::2], keep[1::2, 1::2] - bl[3])
+        pipe = ppn.RawProcessingPipeline(cam, debayer=case['debayer'], sharpening=case['sharpening'],
+                                         denoising=case['denoising'])
+        t = pipe(g[name + '/raw'][0].astype(np.float64).copy())
+        assert t.dtype == torch.float32 and tuple(t.shape) == (3,) + img.shape
+        assert np.abs(t.numpy() - g[name + '/pipeline_chw_f32']).max() <= 1e-5
+
+
 def check_static_combinations(device):
     """every demosaic x sharpening x denoising combination the device builds (single-launch chains and
     luma-plane passes) against the oracle (the reference's own arithmetic on scipy), float32 and 16-bit input."""

@@ -63,3 +63,7 @@ def test_static_chain_combinations(emulation):
 
 def test_adversarial_aux_losses(golden, emulation):
     pc.check_aux_losses(golden, 'cpu')
+
+
+def test_static_per_image_wrappers(golden, emulation):
+    pc.check_static_wrappers(golden, 'cpu')

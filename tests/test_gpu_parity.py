@@ -168,3 +168,7 @@ def test_survives_hip_graph_capture(dev):
         assert torch.equal(y0, y1)
         for p, q in zip(m.parameters(), m2.parameters()):
             assert torch.equal(p.grad, q.grad)
+
+
+def test_static_per_image_wrappers(golden, dev):
+    pc.check_static_wrappers(golden, dev)
