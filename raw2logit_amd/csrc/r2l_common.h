@@ -217,6 +217,17 @@ R2L_HD r2l_p2 r2l_pmul(r2l_p2 a, r2l_p2 b) { return a * b; }
 R2L_HD r2l_p2 r2l_padd(r2l_p2 a, r2l_p2 b) { return a + b; }
 #endif
 R2L_HD r2l_p2 r2l_splat2(float a) { return r2l_mk2(a, a); }
+// {a[1], b[0]}: the pair that straddles two aligned pairs, as ONE v_pk_mov_b32 (left to itself hipcc emits two
+// v_mov_b32 whenever both halves come out of the same 128-bit load)
+R2L_HD r2l_p2 r2l_straddle(r2l_p2 a, r2l_p2 b) {
+#ifdef R2L_EMUL
+  return r2l_mk2(a[1], b[0]);
+#else
+  r2l_p2 d;
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#endif
+}
 
 // torch 'reflect' (mirror without repeating the edge: c b | a b c), clamped for far-out indices
 R2L_HD int r2l_mirror(int i, int n) {

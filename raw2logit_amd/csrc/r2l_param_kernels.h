@@ -564,12 +564,19 @@ template <class FT>
 R2L_HD void r2l_blur_row2(const float yw[5][8], const FT& F, r2l_p2 ypp[2]) {
   ypp[0] = ypp[1] = r2l_splat2(0.f);
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 5; ++i) {
+    // aligned pairs P[k] = columns (2k, 2k+1) of the window row, straddling pairs O[k] = (2k+1, 2k+2)
+    r2l_p2 P[4], O[3];
     R2L_PRAGMA_UNROLL
-  for (int j = 0; j < 5; ++j) {
-    const r2l_p2 w = r2l_splat2(F.blur[i * 5 + j]);
+    for (int k = 0; k < 4; ++k) P[k] = r2l_mk2(yw[i][2 * k], yw[i][2 * k + 1]);
     R2L_PRAGMA_UNROLL
-    for (int p = 0; p < 2; ++p) ypp[p] = r2l_pfma(w, r2l_mk2(yw[i][2 * p + j], yw[i][2 * p + j + 1]), ypp[p]);
+    for (int k = 0; k < 3; ++k) O[k] = r2l_straddle(P[k], P[k + 1]);
+    R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      const r2l_p2 w = r2l_splat2(F.blur[i * 5 + j]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) ypp[p] = r2l_pfma(w, (j & 1) ? O[p + j / 2] : P[p + j / 2], ypp[p]);
+    }
   }
 }
 template <int PY, class FT>
