@@ -223,6 +223,16 @@ int r2l_stage_point(int op, const float *x, const float *g, const float *w, cons
                     const float *aux2, float *y, float *sums6, void *workspace, size_t workspace_bytes,
                     int B, int H, int W, void *stream);
 
+/* ---- augmentation of the ISP output (utils/augmentation.py:8-31, :70-74;
+ * applied between processor and classifier, model.py:79-81).  x is N planes of H x W float32.
+ *   r2l_augment    y = rot90^k(vflip(hflip(x))), k counted like x.rot90(k, dims=(-1, -2)); y is N planes of
+ *                  H x W (even k) or W x H (odd k).  inverse != 0: x has y's shape and the inverse map is
+ *                  applied (the VJP).  The random draws stay on the host, in the reference's order.
+ *   r2l_add_noise  y = x + noise * std (AddGaussianNoise; the caller draws `noise`)                      */
+int r2l_augment(const float *x, float *y, int N, int H, int W, int hflip, int vflip, int k, int inverse,
+                void *stream);
+int r2l_add_noise(const float *x, const float *noise, float std, float *y, size_t n, void *stream);
+
 /* ---- adversarial auxiliary losses between the outputs of two processors (SURVEY.md section 8f rank 2;
  * AuxLoss, utils/base.py:346-358: img1 = the default processor's output, img2 = the adversarial processor's).
  *   r2l_ssim_fwd   mean of the SSIM map, window_size 11, sigma 1.5, zero padding, per channel

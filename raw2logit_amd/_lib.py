@@ -75,6 +75,9 @@ _SIGNATURES = {
                                           ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_void_p]),
+    'r2l_augment': (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
+    'r2l_add_noise': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_float, _c_float_p, ctypes.c_size_t,
+                                     ctypes.c_void_p]),
     'r2l_aux_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'r2l_ssim_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t] +
                      [ctypes.c_int] * 5 + [ctypes.c_void_p]),

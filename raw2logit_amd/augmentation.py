@@ -1,0 +1,191 @@
+"""Drop-in for the reference's ``utils/augmentation.py`` (weak set) with the pixel moves on the GPU.
+
+``augmentation_weak`` = RandomHorizontalFlip, RandomVerticalFlip, RandomRotate90 (utils/augmentation.py:70-74),
+applied to the processor's output batch between ISP and classifier (model.py:79-81) and, for segmentation, to
+the masks with the same random state (``retain_state`` / ``mask_transform``, :36-67).  The random draws are made
+on the host exactly where torchvision / the reference make them (``torch.rand(1) < p``, ``random.randint``), so a
+seeded run takes the same decisions; the three moves of a call are then fused into ONE permutation kernel
+(``r2l_augment``) instead of up to three passes, with the inverse permutation as its VJP.
+
+``augmentation_strong`` additionally needs torchvision's RandomRotation / RandomAdjustSharpness (absent from
+the image, resampling ops outside the ISP path): not built -- ``get_augmentation('strong')`` raises."""
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr
+from .functional import _f32c
+
+
+class _FlipRot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, hflip, vflip, k):
+        x = _f32c(x, 'x')
+        H, W = x.shape[-2:]
+        N = x.numel() // (H * W)
+        lib, stream = _lib.library_for(x)
+        out_shape = tuple(x.shape[:-2]) + ((W, H) if (k & 1) else (H, W))
+        y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+        lib.check(lib.r2l_augment(ptr(x), ptr(y), N, H, W, int(hflip), int(vflip), int(k), 0, stream), 'r2l_augment')
+        ctx.meta = (N, H, W, int(hflip), int(vflip), int(k), tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, hflip, vflip, k, shape = ctx.meta
+        g = _f32c(g, 'g')
+        lib, stream = _lib.library_for(g)
+        gx = torch.empty(shape, dtype=torch.float32, device=g.device)
+        lib.check(lib.r2l_augment(ptr(g), ptr(gx), N, H, W, hflip, vflip, k, 1, stream), 'r2l_augment(inverse)')
+        return gx, None, None, None
+
+
+def flip_rot(x, hflip=False, vflip=False, k=0):
+    """rot90^k(vflip(hflip(x))) over the last two axes, k as in ``x.rot90(k, dims=(-1, -2))``; one kernel."""
+    if not (hflip or vflip or (k & 3)):
+        return x
+    return _FlipRot.apply(x, bool(hflip), bool(vflip), int(k) & 3)
+
+
+class _Pending:
+    """moves decided by the transforms of one ComposeState call, applied together at the end"""
+
+    def __init__(self):
+        self.hflip = self.vflip = False
+        self.k = 0
+
+    def flush(self, x):
+        x = flip_rot(x, self.hflip, self.vflip, self.k)
+        self.__init__()
+        return x
+
+
+class RandomHorizontalFlip:
+    """torchvision.transforms.RandomHorizontalFlip: one draw per call, the whole batch flips (:71)."""
+
+    def __init__(self, p=0.5):
+        self.p = p
+
+    def decide(self, pending):
+        if torch.rand(1) < self.p:
+            if pending.k:            # a flip after a rotation does not commute: apply what is pending first
+                return True
+            pending.hflip = not pending.hflip
+        return False
+
+    def __call__(self, x):
+        return flip_rot(x, hflip=bool(torch.rand(1) < self.p))
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}(p={self.p})'
+
+
+class RandomVerticalFlip(RandomHorizontalFlip):
+    """torchvision.transforms.RandomVerticalFlip (:72)."""
+
+    def decide(self, pending):
+        if torch.rand(1) < self.p:
+            if pending.k:
+                return True
+            pending.vflip = not pending.vflip
+        return False
+
+    def __call__(self, x):
+        return flip_rot(x, vflip=bool(torch.rand(1) < self.p))
+
+
+class RandomRotate90:  # Note: not the same as T.RandomRotation(90)
+    """utils/augmentation.py:8-14."""
+
+    def decide(self, pending):
+        pending.k = (pending.k + random.randint(0, 3)) & 3
+        return False
+
+    def __call__(self, x):
+        return flip_rot(x, k=random.randint(0, 3))
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+class AddGaussianNoise:
+    """utils/augmentation.py:17-31 (the noise is drawn by torch.randn_like on the device, the add is a kernel)."""
+
+    def __init__(self, std=0.01):
+        self.std = std
+
+    def __call__(self, x):
+        x = _f32c(x, 'x')
+        noise = torch.randn_like(x)
+        lib, stream = _lib.library_for(x)
+        y = torch.empty_like(x)
+        lib.check(lib.r2l_add_noise(ptr(x), ptr(noise), float(self.std), ptr(y), x.numel(), stream), 'r2l_add_noise')
+        return y
+
+    def __repr__(self):
+        return self.__class__.__name__ + f'(std={self.std})'
+
+
+def set_global_seed(seed):
+    """utils/augmentation.py:34-37."""
+    torch.random.manual_seed(seed)
+    np.random.seed(seed % (2**32 - 1))
+    random.seed(seed)
+
+
+class ComposeState:
+    """utils/augmentation.py:40-67: a Compose that can replay its random state for the masks."""
+
+    def __init__(self, transforms):
+        self.transforms = []
+        self.mask_transforms = []
+        for t in transforms:
+            apply_for_mask = True
+            if isinstance(t, tuple):
+                t, apply_for_mask = t
+            self.transforms.append(t)
+            if apply_for_mask:
+                self.mask_transforms.append(t)
+        self.seed = None
+
+    def __call__(self, x, retain_state=False, mask_transform=False):
+        if self.seed is not None:   # retain previous state
+            set_global_seed(self.seed)
+        if retain_state:    # save state for next call
+            self.seed = self.seed or torch.seed()
+            set_global_seed(self.seed)
+        else:
+            self.seed = None    # reset / ignore state
+        transforms = self.transforms if not mask_transform else self.mask_transforms
+        pending = _Pending()
+        for t in transforms:
+            if hasattr(t, 'decide'):          # flip / rot90: drawn now (reference order), moved once at the end
+                if t.decide(pending):         # the move does not commute with what is pending: flush, then redo
+                    x = pending.flush(x)
+                    if isinstance(t, RandomVerticalFlip):
+                        pending.vflip = True
+                    else:
+                        pending.hflip = True
+            else:
+                x = t(pending.flush(x))
+        return pending.flush(x)
+
+
+augmentation_weak = ComposeState([
+    RandomHorizontalFlip(),
+    RandomVerticalFlip(),
+    RandomRotate90(),
+])
+
+
+def get_augmentation(type):
+    """utils/augmentation.py:87-93."""
+    if type == 'none':
+        return None
+    if type == 'weak':
+        return augmentation_weak
+    if type == 'strong':
+        raise NotImplementedError("augmentation 'strong' needs torchvision's RandomRotation / RandomAdjustSharpness "
+                                  "(resampling ops, not installed): only 'none' and 'weak' are built")

@@ -190,6 +190,8 @@ R2L_KERNEL(r2l_launch_mix3_bwd, R2LStageArgs, r2l_mix3_bwd_block, R2L_RED_FLOATS
 R2L_KERNEL(r2l_launch_pconv_fwd, R2LStageArgs, r2l_pconv_fwd_block, 4)
 R2L_KERNEL(r2l_launch_pconv_bwd, R2LStageArgs, r2l_pconv_bwd_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_point, R2LPointArgs, r2l_point_block, R2L_RED_FLOATS)
+R2L_KERNEL(r2l_launch_aug, R2LAugArgs, r2l_aug_block, 4)
+R2L_KERNEL(r2l_launch_axpy, R2LAxpyArgs, r2l_axpy_block, 4)
 R2L_KERNEL(r2l_launch_ssim, R2LSsimArgs, r2l_ssim_block, R2L_SSIM_LDS_FLOATS)
 R2L_KERNEL(r2l_launch_ssim_bwd, R2LSsimBwdArgs, r2l_ssim_bwd_block, R2L_SSIM_BWD_LDS_FLOATS)
 R2L_KERNEL(r2l_launch_l2, R2LL2Args, r2l_l2_block, R2L_RED_FLOATS_N(1))
@@ -814,6 +816,23 @@ int r2l_stage_point(int op, const float* x, const float* g, const float* w, cons
   R2LPointArgs a{x, g, w, aux, aux2, y, reduces ? (float*)workspace : nullptr, B, H, W, op};
   if (int e = r2l_launch_point(a, grid, stream)) return e;
   return reduces ? r2l_stage_finish((const float*)workspace, 6, grid, sums6, stream) : 0;
+}
+
+// ---- augmentation after the ISP (utils/augmentation.py) -------------------------------------------------
+int r2l_augment(const float* x, float* y, int N, int H, int W, int hflip, int vflip, int k, int inverse,
+                void* stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1) return r2l_fail(-1, "r2l_augment: null pointer / bad dimensions");
+  R2LAugArgs a{x, y, N, H, W, hflip != 0, vflip != 0, k & 3, inverse != 0};
+  size_t g = ((size_t)N * H * W + R2L_NT - 1) / R2L_NT;
+  if (g > 8192) g = 8192;
+  return r2l_launch_aug(a, (int)g, stream);
+}
+int r2l_add_noise(const float* x, const float* noise, float std, float* y, size_t n, void* stream) {
+  if (!x || !noise || !y || n == 0) return r2l_fail(-1, "r2l_add_noise: null pointer / empty");
+  R2LAxpyArgs a{x, noise, y, std, n};
+  size_t g = (n + R2L_NT - 1) / R2L_NT;
+  if (g > 8192) g = 8192;
+  return r2l_launch_axpy(a, (int)g, stream);
 }
 
 // ---- adversarial auxiliary losses (utils/ssim.py, utils/base.py:342-358) -------------------------------

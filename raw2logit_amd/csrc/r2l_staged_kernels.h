@@ -323,3 +323,62 @@ R2L_BLOCKFN void r2l_point_block(const R2LPointArgs& a, int bid, int nblk, float
     R2L_BLOCK_REDUCE(6, regs, lds, a.partial, bid, nblk)
   }
 }
+
+// ---- weak augmentation (utils/augmentation.py:8-14, :70-74): horizontal flip, vertical flip, rot90 --------
+// y = rot90^k(vflip^v(hflip^h(x))) over the last two axes of (N, H, W) planes, k counted the way
+// `x.rot90(k, dims=(-1, -2))` counts (the reference's RandomRotate90); inverse != 0 applies the inverse map
+// (the VJP of a permutation is its inverse).  Out is (N, H, W) for even k and (N, W, H) for odd k.
+struct R2LAugArgs {
+  const float* x;
+  float* y;
+  int N, H, W;  // input plane size
+  int hflip, vflip, k, inverse;
+};
+// forward map of one input coordinate: (r, c) in H x W -> (r2, c2) in Ho x Wo
+R2L_HD void r2l_aug_map(int H, int W, int hflip, int vflip, int k, int r, int c, int& r2, int& c2) {
+  if (hflip) c = W - 1 - c;
+  if (vflip) r = H - 1 - r;
+  int h = H, w = W;
+  for (int i = 0; i < (k & 3); ++i) {  // one rot90 with dims=(-1,-2): out[j][h-1-i'] ... (i, j) -> (j, h - 1 - i)
+    const int nr = c, nc = h - 1 - r;
+    r = nr;
+    c = nc;
+    const int t = h;
+    h = w;
+    w = t;
+  }
+  r2 = r;
+  c2 = c;
+}
+R2L_BLOCKFN void r2l_aug_block(const R2LAugArgs& a, int bid, int nblk, float* lds) {
+  (void)lds;
+  const size_t hw = (size_t)a.H * a.W, n = (size_t)a.N * hw;
+  const int Wo = (a.k & 1) ? a.H : a.W;
+  R2L_PHASE_BEGIN
+  for (size_t e = (size_t)bid * R2L_NT + tid; e < n; e += (size_t)nblk * R2L_NT) {
+    const size_t pl = e / hw, rem = e - pl * hw;
+    const int r = (int)(rem / a.W), c = (int)(rem - (size_t)r * a.W);
+    int r2, c2;
+    r2l_aug_map(a.H, a.W, a.hflip, a.vflip, a.k, r, c, r2, c2);
+    const size_t o = pl * hw + (size_t)r2 * Wo + c2;
+    if (a.inverse)
+      a.y[e] = a.x[o];   // x is the augmented-shape gradient, y the input-shape gradient
+    else
+      a.y[o] = a.x[e];
+  }
+  R2L_PHASE_END
+}
+// ---- AddGaussianNoise (utils/augmentation.py:17-31): y = x + noise * std, noise drawn by the caller ------
+struct R2LAxpyArgs {
+  const float* x;
+  const float* noise;
+  float* y;
+  float std;
+  size_t n;
+};
+R2L_BLOCKFN void r2l_axpy_block(const R2LAxpyArgs& a, int bid, int nblk, float* lds) {
+  (void)lds;
+  R2L_PHASE_BEGIN
+  for (size_t e = (size_t)bid * R2L_NT + tid; e < a.n; e += (size_t)nblk * R2L_NT) a.y[e] = a.x[e] + a.noise[e] * a.std;
+  R2L_PHASE_END
+}

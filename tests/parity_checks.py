@@ -384,6 +384,67 @@ def check_aux_losses(golden, device):
     assert all(p.grad is None for p in p_def.parameters())
 
 
+def check_augmentation(device):
+    """utils/augmentation.py weak set: the fused flip/rot90 kernel against the torch ops the reference composes
+    (x.flip / x.rot90(k, dims=(-1, -2))), its VJP against autograd through those ops, and ComposeState's
+    seeded decisions (same draws in the same order as torchvision's transforms + RandomRotate90)."""
+    import random
+    from raw2logit_amd import augmentation as aug
+    rng = np.random.default_rng(5)
+    for shape in ((2, 3, 6, 10), (1, 3, 8, 8), (3, 1, 5, 4)):
+        x_np = rng.standard_normal(shape).astype(np.float32)
+        for h in (False, True):
+            for v in (False, True):
+                for k in range(4):
+                    x = torch.from_numpy(x_np).to(device).requires_grad_(True)
+                    y = aug.flip_rot(x, h, v, k)
+                    xr = torch.from_numpy(x_np).requires_grad_(True)
+                    yr = xr
+                    if h:
+                        yr = yr.flip(-1)
+                    if v:
+                        yr = yr.flip(-2)
+                    yr = yr.rot90(k, dims=(-1, -2))
+                    assert tuple(y.shape) == tuple(yr.shape) and torch.equal(y.detach().cpu(), yr.detach())
+                    cot = torch.from_numpy(rng.standard_normal(tuple(yr.shape)).astype(np.float32))
+                    if y.requires_grad:
+                        (y * cot.to(device)).sum().backward()
+                        (yr * cot).sum().backward()
+                        assert torch.equal(x.grad.cpu(), xr.grad)
+    # seeded composition, as LitModel uses it (model.py:79-81, :90-92): image with retain_state, mask replay
+    x = torch.from_numpy(rng.standard_normal((2, 3, 8, 12)).astype(np.float32)).to(device)
+    mask = torch.from_numpy(rng.standard_normal((2, 8, 12)).astype(np.float32)).to(device)
+
+    def eager(t):       # what T.RandomHorizontalFlip / T.RandomVerticalFlip / RandomRotate90 do, in order
+        if torch.rand(1) < 0.5:
+            t = t.flip(-1)
+        if torch.rand(1) < 0.5:
+            t = t.flip(-2)
+        return t.rot90(random.randint(0, 3), dims=(-1, -2))
+    seen = set()
+    for seed in range(12):
+        aug.set_global_seed(seed)
+        ref = eager(x.cpu())
+        aug.set_global_seed(seed)
+        got = aug.augmentation_weak(x)
+        assert torch.equal(got.cpu(), ref)
+        seen.add(tuple(got.shape))
+        # retain_state: the mask call replays the image call's draws
+        w = aug.get_augmentation('weak')
+        gi = w(x, retain_state=True)
+        seed_used = w.seed
+        gm = w(mask, mask_transform=True)
+        assert gm.shape[-2:] == gi.shape[-2:] and w.seed is None
+        aug.set_global_seed(seed_used)
+        assert torch.equal(gm.cpu(), eager(mask.cpu()))
+    assert len(seen) == 2            # both orientations occurred
+    n = aug.AddGaussianNoise(std=0.25)
+    torch.manual_seed(3)
+    y = n(x)
+    torch.manual_seed(3)
+    assert torch.allclose(y, x + torch.randn_like(x) * 0.25, rtol=0, atol=1e-7)
+
+
 def check_harness(golden, device):
     """LitModel-style composition (processor -> classifier -> CE loss -> Adam step, model.py:77-146):
     logits, loss and the ISP parameters after one optimiser step must match what the REFERENCE processor

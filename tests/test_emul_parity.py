@@ -67,3 +67,7 @@ def test_adversarial_aux_losses(golden, emulation):
 
 def test_static_per_image_wrappers(golden, emulation):
     pc.check_static_wrappers(golden, 'cpu')
+
+
+def test_weak_augmentation(emulation):
+    pc.check_augmentation('cpu')

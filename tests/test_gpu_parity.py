@@ -172,3 +172,7 @@ def test_survives_hip_graph_capture(dev):
 
 def test_static_per_image_wrappers(golden, dev):
     pc.check_static_wrappers(golden, dev)
+
+
+def test_weak_augmentation(dev):
+    pc.check_augmentation(dev)
