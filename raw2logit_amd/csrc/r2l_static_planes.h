@@ -75,17 +75,91 @@ R2L_HD double r2l_plane_px(const R2LPlaneArgs& a, const double* img, int y, int 
     p[i * 3 + j] = img[(size_t)r2l_symmetric(y + i - 1, a.H) * a.W + r2l_symmetric(x + j - 1, a.W)];
   return r2l_median9(p);
 }
+// Interior fast path: the two adjacent pixels (x, x+1) of a lane share their window, which is fetched with
+// aligned 16-byte loads (x is even) and no border arithmetic; lanes whose window leaves the image take the
+// per-pixel path above.  `r` = window radius of the op.
+struct r2l_d2 {
+  double x, y;
+};
+R2L_HD r2l_d2 r2l_ld2(const double* p) {
+#ifdef R2L_EMUL
+  r2l_d2 v;
+  v.x = p[0];
+  v.y = p[1];
+  return v;
+#else
+  const double2 t = *(const double2*)p;
+  r2l_d2 v;
+  v.x = t.x;
+  v.y = t.y;
+  return v;
+#endif
+}
+R2L_HD void r2l_plane_px2(const R2LPlaneArgs& a, const double* img, int y, int x, double& o0, double& o1) {
+  const size_t W = (size_t)a.W;
+  const double* c = img + (size_t)y * W + x;
+  if (a.op == 1) {
+    const r2l_d2 l = r2l_ld2(c - 2), m = r2l_ld2(c), rr = r2l_ld2(c + 2), n = r2l_ld2(c - W), s = r2l_ld2(c + W);
+    o0 = 5.0 * m.x - n.x - s.x - l.y - m.y;
+    o1 = 5.0 * m.y - n.y - s.y - m.x - rr.x;
+    return;
+  }
+  if (a.op == 2) {
+    double t[6];  // vertical pass at columns x-2 .. x+3
+    R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      const double* q = c + 2 * j - 2;
+      const r2l_d2 m = r2l_ld2(q), u1 = r2l_ld2(q - W), d1 = r2l_ld2(q + W), u2 = r2l_ld2(q - 2 * W), d2 = r2l_ld2(q + 2 * W);
+      t[2 * j] = a.gk[2] * m.x + (u1.x + d1.x) * a.gk[1] + (u2.x + d2.x) * a.gk[0];
+      t[2 * j + 1] = a.gk[2] * m.y + (u1.y + d1.y) * a.gk[1] + (u2.y + d2.y) * a.gk[0];
+    }
+    o0 = a.gk[2] * t[2] + (t[1] + t[3]) * a.gk[1] + (t[0] + t[4]) * a.gk[0];
+    o1 = a.gk[2] * t[3] + (t[2] + t[4]) * a.gk[1] + (t[1] + t[5]) * a.gk[0];
+    return;
+  }
+  if (a.op == 4) {
+    const r2l_d2 m = r2l_ld2(c);
+    double b0 = a.uk[0] * m.x, b1 = a.uk[0] * m.y;
+    R2L_PRAGMA_UNROLL
+    for (int k = 1; k <= 4; ++k) {
+      const r2l_d2 u = r2l_ld2(c - (size_t)k * W), d = r2l_ld2(c + (size_t)k * W);
+      b0 += (u.x + d.x) * a.uk[k];
+      b1 += (u.y + d.y) * a.uk[k];
+    }
+    o0 = m.x + (m.x - b0) * a.amount;
+    o1 = m.y + (m.y - b1) * a.amount;
+    return;
+  }
+  double p0[9], p1[9];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    const double* q = c + ((size_t)i * W) - W;
+    const r2l_d2 l = r2l_ld2(q - 2), m = r2l_ld2(q), rr = r2l_ld2(q + 2);
+    p0[i * 3] = l.y, p0[i * 3 + 1] = m.x, p0[i * 3 + 2] = m.y;
+    p1[i * 3] = m.x, p1[i * 3 + 1] = m.y, p1[i * 3 + 2] = rr.x;
+  }
+  o0 = r2l_median9(p0);
+  o1 = r2l_median9(p1);
+}
 R2L_BLOCKFN void r2l_plane_filter_block(const R2LPlaneArgs& a, int bid, int nblk, float* lds) {
   (void)lds;
   const size_t hw = (size_t)a.H * a.W, n2 = (size_t)a.B * hw / 2;  // W is even
+  const int r = (a.op == 4) ? 4 : (a.op == 2 ? 2 : 1), rx = (a.op == 4) ? 0 : 2;  // window reach in y / loads in x
   R2L_PHASE_BEGIN
   for (size_t i2 = (size_t)bid * R2L_NT + tid; i2 < n2; i2 += (size_t)nblk * R2L_NT) {
     const size_t e = i2 * 2;
-    const size_t b = e / hw, r = e - b * hw;
-    const int y = (int)(r / a.W), x = (int)(r - (size_t)y * a.W);
+    const size_t b = e / hw, rem = e - b * hw;
+    const int y = (int)(rem / a.W), x = (int)(rem - (size_t)y * a.W);
     const double* img = a.src + b * hw;
-    a.dst[e] = r2l_plane_px(a, img, y, x);
-    a.dst[e + 1] = r2l_plane_px(a, img, y, x + 1);
+    double o0, o1;
+    if (y >= r && y + r < a.H && x >= rx && x + 1 + rx < a.W) {
+      r2l_plane_px2(a, img, y, x, o0, o1);
+    } else {
+      o0 = r2l_plane_px(a, img, y, x);
+      o1 = r2l_plane_px(a, img, y, x + 1);
+    }
+    a.dst[e] = o0;
+    a.dst[e + 1] = o1;
   }
   R2L_PHASE_END
 }
