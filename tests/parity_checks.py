@@ -445,6 +445,49 @@ def check_augmentation(device):
     assert torch.allclose(y, x + torch.randn_like(x) * 0.25, rtol=0, atol=1e-7)
 
 
+def check_error_behaviour(device):
+    """bad arguments fail loudly, with the reference's exception types where it has any (AssertionError
+    on wrong rank / out_channels) and R2LError / ValueError / NotImplementedError with a message elsewhere."""
+    import pytest
+    from raw2logit_amd import _lib, losses
+    from raw2logit_amd._lib import ptr
+    m = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS).to(device)
+    raw = torch.rand((2, 16, 16), device=device)
+    with pytest.raises(AssertionError):
+        m(raw[0])                                            # needs (B, H, W)               :176
+    with pytest.raises(AssertionError):
+        F_.raw2rgb(raw, out_channels=5)                      #                               :252
+    with pytest.raises(_lib.R2LError):
+        m(torch.rand((1, 15, 16), device=device))            # odd height: no Bayer quads
+    with pytest.raises(TypeError):
+        m(raw.double())
+    ppt.append_additive_layer(m)
+    m.additive_layer.data = m.additive_layer.data.to(device)
+    with pytest.raises(RuntimeError):
+        m(raw)                                               # (1,3,256,256) does not broadcast to 16x16 (:213)
+    with pytest.raises(ValueError):
+        F_.static_pipeline(torch.zeros((1, 8, 6), dtype=torch.int16, device=device), orc.DRONE_CAMERA_PARAMS)
+    with pytest.raises(NotImplementedError):
+        F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, debayer='menon2007')
+    with pytest.raises(NotImplementedError):
+        F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, denoising='fft_denoising')
+    with pytest.raises(NotImplementedError):
+        losses.SSIM(window_size=7)
+    with pytest.raises(ValueError):
+        losses.ssim(torch.rand((1, 3, 8, 8), device=device), torch.rand((1, 3, 8, 9), device=device))
+    # C ABI: negative return code + message, nothing enqueued
+    lib, stream = _lib.library_for(raw)
+    out = torch.empty((2, 3, 16, 16), device=device)
+    rc = lib.r2l_isp_fwd(ptr(raw), None, None, None, ptr(out), None, None, 0, 2, 16, 16, 0, stream)
+    assert rc < 0 and b'null pointer' in lib.r2l_last_error()
+    packed = m.packed_parameters()
+    ws = torch.empty(16, dtype=torch.uint8, device=device)
+    rc = lib.r2l_isp_fwd(ptr(raw), ptr(packed), None, None, ptr(out), None, ptr(ws), 16, 2, 16, 16, 0, stream)
+    assert rc == -2 and b'workspace too small' in lib.r2l_last_error()
+    assert lib.r2l_static_workspace_bytes(2, 16, 16, 1, 1, 1) == 2 * 8 * 2 * 16 * 16
+    assert lib.r2l_static_workspace_bytes(2, 16, 16, 0, 1, 1) == 0          # the fused default chain
+
+
 def check_harness(golden, device):
     """LitModel-style composition (processor -> classifier -> CE loss -> Adam step, model.py:77-146):
     logits, loss and the ISP parameters after one optimiser step must match what the REFERENCE processor

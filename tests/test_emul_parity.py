@@ -71,3 +71,7 @@ def test_static_per_image_wrappers(golden, emulation):
 
 def test_weak_augmentation(emulation):
     pc.check_augmentation('cpu')
+
+
+def test_error_behaviour(emulation):
+    pc.check_error_behaviour('cpu')

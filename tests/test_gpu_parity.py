@@ -176,3 +176,7 @@ def test_static_per_image_wrappers(golden, dev):
 
 def test_weak_augmentation(dev):
     pc.check_augmentation(dev)
+
+
+def test_error_behaviour(dev):
+    pc.check_error_behaviour(dev)
