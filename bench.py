@@ -112,6 +112,22 @@ def cpu_baseline_static(debayer):
                       f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
 
 
+def _init_distributed(torch, dist, world, local_rank):
+    """one process per GPU over RCCL (backend "nccl").  R2L_BENCH_BACKEND=gloo lets the N > 1 code path be
+    exercised with several processes on ONE GPU (a functional check, not a measurement)."""
+    index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(index)
+    dev = torch.device('cuda', index)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        backend = os.environ.get('R2L_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    return dev
+
+
 def main_static(args):
     """BASELINE config 3: one step = the fused static chain over 256x1024x1024 frames per GPU (no exchange between
     ranks: static mode needs no collective)."""
@@ -121,11 +137,7 @@ def main_static(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+    dev = _init_distributed(torch, dist, world, local_rank)
     lib = _lib.device_library()
     B, S = (args.batch if args.batch != 64 else 256), (args.size if args.size != 512 else 1024)
     gen = torch.Generator(dev).manual_seed(rank)
@@ -196,12 +208,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+    dev = _init_distributed(torch, dist, world, local_rank)
     lib = _lib.device_library()                     # raises if the HIP extension is missing
 
     B, S = args.batch, args.size
