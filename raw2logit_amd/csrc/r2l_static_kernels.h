@@ -190,19 +190,18 @@ R2L_HD void r2l_malvar_px(const double w[5][5], int py, int px, double d[3]) {
 // black-level-corrected float64 window of N x N raw values whose element (i,j) sits at global
 // (gy0 - HALO + i, gx0 - HALO + j); rp/cp receive the site parities of the rows / columns.
 // PAR0 = parity of gy0 and of gx0 (known at compile time: tiles and micro-tiles start on even pixels)
-template <class G, int N, int HALO, bool BORDER, int PAR0>
+template <class G, int NR, int NC, int HALO, bool BORDER, int PAR0>
 R2L_HD void r2l_static_window(const float* V, int fy0, int fx0, int gy0, int gx0,
-                              const R2LStaticArgs& a, double w[N][N], int rp[N], int cp[N]) {
+                              const R2LStaticArgs& a, double w[NR][NC], int rp[NR], int cp[NC]) {
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < N; ++i) {
-    rp[i] = BORDER ? (r2l_symmetric(gy0 - HALO + i, a.H) & 1) : ((PAR0 + i + HALO) & 1);
-    cp[i] = BORDER ? (r2l_symmetric(gx0 - HALO + i, a.W) & 1) : ((PAR0 + i + HALO) & 1);
-  }
+  for (int i = 0; i < NR; ++i) rp[i] = BORDER ? (r2l_symmetric(gy0 - HALO + i, a.H) & 1) : ((PAR0 + i + HALO) & 1);
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < N; ++i) {
+  for (int i = 0; i < NC; ++i) cp[i] = BORDER ? (r2l_symmetric(gx0 - HALO + i, a.W) & 1) : ((PAR0 + i + HALO) & 1);
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < NR; ++i) {
     const float* r = V + (fy0 - HALO + i) * G::FS + fx0 - HALO;
     R2L_PRAGMA_UNROLL
-    for (int j = 0; j < N; ++j) {
+    for (int j = 0; j < NC; ++j) {
       double bl;
       if (BORDER) {
         const double b0 = rp[i] ? a.bl[2] : a.bl[0], b1 = rp[i] ? a.bl[3] : a.bl[1];
@@ -215,16 +214,18 @@ R2L_HD void r2l_static_window(const float* V, int fy0, int fx0, int gy0, int gx0
   }
 }
 
-// demosaiced RGB (float64) of the 4x4 micro-tile at frame (fy0, fx0) / global (gy0, gx0)
+// demosaiced RGB (float64) of the 4-wide x MR-tall micro-tile at frame (fy0, fx0) / global (gy0, gx0)
+#define R2L_STATIC_MR 2  // rows per micro-tile: 16 x 32 micro-tiles = all 512 lanes of the workgroup
 template <class G, bool BORDER>
 R2L_HD void r2l_static_demosaic_4x4(const float* V, int fy0, int fx0, int gy0, int gx0,
-                                    const R2LStaticArgs& a, double d[4][4][3]) {
+                                    const R2LStaticArgs& a, double d[R2L_STATIC_MR][4][3]) {
+  constexpr int MR = R2L_STATIC_MR;
   if (a.debayer == R2L_DEBAYER_MALVAR2004) {
-    double w[8][8];
-    int rp[8], cp[8];
-    r2l_static_window<G, 8, 2, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
+    double w[MR + 4][8];
+    int rp[MR + 4], cp[8];
+    r2l_static_window<G, MR + 4, 8, 2, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
     R2L_PRAGMA_UNROLL
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < MR; ++r)
       R2L_PRAGMA_UNROLL
     for (int c = 0; c < 4; ++c) {
       double n[5][5];
@@ -235,11 +236,11 @@ R2L_HD void r2l_static_demosaic_4x4(const float* V, int fy0, int fx0, int gy0, i
       r2l_malvar_px(n, r & 1, c & 1, d[r][c]);
     }
   } else {
-    double w[6][6];
-    int rp[6], cp[6];
-    r2l_static_window<G, 6, 1, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
+    double w[MR + 2][6];
+    int rp[MR + 2], cp[6];
+    r2l_static_window<G, MR + 2, 6, 1, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
     R2L_PRAGMA_UNROLL
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < MR; ++r)
       R2L_PRAGMA_UNROLL
     for (int c = 0; c < 4; ++c) {
       double n[3][3];
@@ -257,7 +258,7 @@ R2L_HD void r2l_static_demosaic_4x4(const float* V, int fy0, int fx0, int gy0, i
 }
 
 R2L_HD bool r2l_static_touches_border(int gy0, int gx0, int halo, int H, int W) {
-  return gy0 - halo < 0 || gx0 - halo < 0 || gy0 + 3 + halo >= H || gx0 + 3 + halo >= W;
+  return gy0 - halo < 0 || gx0 - halo < 0 || gy0 + R2L_STATIC_MR - 1 + halo >= H || gx0 + 3 + halo >= W;
 }
 
 // ---- full chain, phase B: luma on frame [1, F-1) quads -> Y (float64, zero outside the image) -------
@@ -267,7 +268,7 @@ R2L_HD void r2l_static_y_quad(const float* V, double* Y, int fy, int fx, int gy,
   // 2x2 quad at ODD frame coordinates (fy, fx): window of 4x4 raw values (halo 1)
   double w[4][4];
   int rp[4], cp[4];
-  r2l_static_window<G, 4, 1, BORDER, 1>(V, fy, fx, gy, gx, a, w, rp, cp);
+  r2l_static_window<G, 4, 4, 1, BORDER, 1>(V, fy, fx, gy, gx, a, w, rp, cp);
   R2L_PRAGMA_UNROLL
   for (int r = 0; r < 2; ++r)
     R2L_PRAGMA_UNROLL
@@ -333,25 +334,26 @@ R2L_HD void r2l_static_fill_yp(int tid, double* YP, int oy, int ox, int H, int W
 template <class G, bool BORDER, bool FULL>
 R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, const R2LStaticArgs& a,
                                    const R2LTile& t) {
+  constexpr int MR = R2L_STATIC_MR;
   const int tx = mt % G::TXN, ty = mt / G::TXN;
-  const int gy0 = t.oy + 4 * ty, gx0 = t.ox + 4 * tx;
-  const int fy0 = 4 * ty + 4, fx0 = 4 * tx + 4;
-  double d[4][4][3];
+  const int gy0 = t.oy + MR * ty, gx0 = t.ox + 4 * tx;
+  const int fy0 = MR * ty + 4, fx0 = 4 * tx + 4;
+  double d[MR][4][3];
   r2l_static_demosaic_4x4<G, BORDER>(V, fy0, fx0, gy0, gx0, a, d);
-  double ypp[4][4];
+  double ypp[MR][4];
   if (FULL) {
     R2L_PRAGMA_UNROLL
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < MR; ++r)
       R2L_PRAGMA_UNROLL
     for (int c = 0; c < 4; ++c) ypp[r][c] = 0.0;
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 8; ++i) {  // input row fy0-2+i contributes to output rows r = i-4 .. i
+    for (int i = 0; i < MR + 4; ++i) {  // input row fy0-2+i contributes to output rows r = i-4 .. i
       double row[8];
       const double* rp = YP + (fy0 - 2 + i) * G::FS + fx0 - 2;
       R2L_PRAGMA_UNROLL
       for (int j = 0; j < 8; ++j) row[j] = rp[j];
       R2L_PRAGMA_UNROLL
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < MR; ++r) {
         const int ki = i - r;
         if (ki < 0 || ki > 4) continue;
         R2L_PRAGMA_UNROLL
@@ -364,7 +366,7 @@ R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, con
   const size_t plane = (size_t)a.H * a.W;
   const bool vec_ok = ((a.W & 3) == 0) && (gx0 + 3 < a.W);
   R2L_PRAGMA_UNROLL
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < MR; ++r) {
     const int gy = gy0 + r;
     if (gy >= a.H) break;
     float x[3][4];
@@ -411,9 +413,9 @@ R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, con
 template <class G, bool FULL>
 R2L_HD void r2l_static_pixels(int tid, const float* V, const double* YP, const R2LStaticArgs& a,
                               const R2LTile& t) {
-  if (tid >= G::TXN * (G::TH / 4)) return;   // 4x4 micro-tiles: TW*TH/16 threads work in this phase
+  if (tid >= G::TXN * (G::TH / R2L_STATIC_MR)) return;
   const int tx = tid % G::TXN, ty = tid / G::TXN;
-  const int gy0 = t.oy + 4 * ty, gx0 = t.ox + 4 * tx;
+  const int gy0 = t.oy + R2L_STATIC_MR * ty, gx0 = t.ox + 4 * tx;
   if (gy0 >= a.H || gx0 >= a.W) return;
   const int halo = (a.debayer == R2L_DEBAYER_MALVAR2004) ? 2 : 1;
   if (r2l_static_touches_border(gy0, gx0, halo, a.H, a.W))
