@@ -5,11 +5,10 @@ torch.autograd.Function, so `stage.retain_grad()` / `stage.grad` (model.py:249-2
 as with the reference's ATen graph.  Slower than the fused path by construction (about twenty passes over the
 frames); used for visualisation / gradient tracking, not for training throughput."""
 import torch
-import torch.distributed as dist
 
 from . import _lib
 from ._lib import ptr
-from .functional import raw2rgb_bits, _f32c, _group_size, gather_ranks, bn_finalize, bn_bwd_means
+from .functional import raw2rgb_bits, _f32c, gather_ranks, bn_finalize, bn_bwd_means
 
 
 def _ws(lib, like):
