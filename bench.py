@@ -115,11 +115,12 @@ def cpu_baseline_static(debayer):
 def _init_distributed(torch, dist, world, local_rank):
     """one process per GPU over RCCL (backend "nccl").  R2L_BENCH_BACKEND=gloo lets the N > 1 code path be
     exercised with several processes on ONE GPU (a functional check, not a measurement)."""
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before anything initialises HIP
     index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(index)
     dev = torch.device('cuda', index)
     if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = os.environ.get('R2L_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
