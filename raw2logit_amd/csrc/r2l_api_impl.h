@@ -57,12 +57,12 @@ static bool r2l_timing_on = false;
 static std::vector<R2LTimedLaunch> r2l_timed;
 static void r2l_time_begin(const char* name, hipStream_t s, R2LTimedLaunch& t) {
   t.name = name;
-  hipEventCreate(&t.e0);
-  hipEventCreate(&t.e1);
-  hipEventRecord(t.e0, s);
+  (void)hipEventCreate(&t.e0);
+  (void)hipEventCreate(&t.e1);
+  (void)hipEventRecord(t.e0, s);
 }
 static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
-  hipEventRecord(t.e1, s);
+  (void)hipEventRecord(t.e1, s);
   std::lock_guard<std::mutex> g(r2l_timing_mutex);
   r2l_timed.push_back(t);
 }
@@ -293,11 +293,11 @@ int r2l_timing_report(char* buf, size_t n) {
   }
   std::map<std::string, std::pair<int, double>> acc;
   for (auto& t : v) {
-    hipEventSynchronize(t.e1);
+    (void)hipEventSynchronize(t.e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, t.e0, t.e1);
-    hipEventDestroy(t.e0);
-    hipEventDestroy(t.e1);
+    (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+    (void)hipEventDestroy(t.e0);
+    (void)hipEventDestroy(t.e1);
     auto& a = acc[t.name];
     a.first += 1;
     a.second += ms;
