@@ -1258,6 +1258,41 @@ R2L_HD void r2l_adjoint_blur(int tid, const float* G2, float* HP, R2LFoldedRef F
   }
 }
 
+// A frame whose image ends exactly 2 rows (columns) below (right of) its tile -- H % TH == 2 -- owns image
+// rows H-3 and H-2 as tile row TH-1 and sharpen halo, and their mirror images H+1, H sit in frame rows
+// FH-1, FH-2, which the pass above does not cover.  Those two rows (columns) are computed here, tap by tap;
+// frame positions beyond the frame are outside the image there, where dL/dY'' is zero.
+template <class G>
+R2L_HD bool r2l_tail_rows(int oy, int H) { return H - oy == G::TH + 2; }
+template <class G>
+R2L_HD bool r2l_tail_cols(int ox, int W) { return W - ox == G::TW + 2; }
+template <class G>
+R2L_HD float r2l_adjoint_blur_one(const float* G2, R2LFoldedRef F, int fy, int fx) {
+  float s = 0.f;
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) {
+      const int sy = fy - (i - 2), sx = fx - (j - 2);
+      if (sy >= 0 && sy < G::FH && sx >= 0 && sx < G::FW) s = fmaf(F.blur[i * 5 + j], G2[sy * G::FS + sx + 2], s);
+    }
+  return s;
+}
+template <class G>
+R2L_HD void r2l_adjoint_blur_tail(int tid, const float* G2, float* HP, R2LFoldedRef F, int oy, int ox, int H, int W) {
+  const bool rows = r2l_tail_rows<G>(oy, H), cols = r2l_tail_cols<G>(ox, W);
+  if (rows) {
+    const int xlim = cols ? G::FW : G::FW - 2;
+    for (int i = tid; i < 2 * (xlim - 2); i += R2L_NT) {
+      const int fy = G::FH - 2 + i / (xlim - 2), fx = 2 + i % (xlim - 2);
+      HP[fy * G::FS + fx] = r2l_adjoint_blur_one<G>(G2, F, fy, fx);
+    }
+  }
+  if (cols)
+    for (int i = tid; i < 2 * (G::FH - 4); i += R2L_NT) {
+      const int fx = G::FW - 2 + i / (G::FH - 4), fy = 2 + i % (G::FH - 4);
+      HP[fy * G::FS + fx] = r2l_adjoint_blur_one<G>(G2, F, fy, fx);
+    }
+}
+
 // phase (border tiles): fold the contributions that the mirror padding sent outside the image back
 // onto their sources, IN PLACE: an in-image position adds the values of its out-of-image mirror images
 // (which nobody writes in this phase).  Out-of-image entries keep their values; the pixel phase masks
@@ -1273,12 +1308,14 @@ R2L_HD void r2l_fold_one(float* HP, int fy, int fx, int oy, int ox, int H, int W
   ex[0] = fx;
   ex[1] = (gx >= 1 && gx <= 2) ? fx - 2 * gx : -1;
   ex[2] = (gx >= W - 3 && gx <= W - 2) ? fx + 2 * (W - 1 - gx) : -1;
+  // rows / columns of HP that hold adjoint-blur values: [2, F-2), plus the two tail rows / columns
+  const int ylim = r2l_tail_rows<G>(oy, H) ? G::FH : G::FH - 2, xlim = r2l_tail_cols<G>(ox, W) ? G::FW : G::FW - 2;
   float s = 0.f;
   R2L_PRAGMA_UNROLL
   for (int p = 0; p < 3; ++p)
     R2L_PRAGMA_UNROLL
   for (int q = 0; q < 3; ++q)
-    if ((p | q) != 0 && ey[p] >= 2 && ey[p] < G::FH - 2 && ex[q] >= 2 && ex[q] < G::FW - 2)
+    if ((p | q) != 0 && ey[p] >= 2 && ey[p] < ylim && ex[q] >= 2 && ex[q] < xlim)
       s += HP[ey[p] * G::FS + ex[q]];
   HP[fy * G::FS + fx] += s;
 }
@@ -1411,6 +1448,11 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     R2L_PHASE_BEGIN
     r2l_adjoint_blur<G>(tid, G2, HP, F);
     R2L_PHASE_END
+    if (r2l_tail_rows<G>(t.oy, a.H) || r2l_tail_cols<G>(t.ox, a.W)) {  // uniform over the workgroup
+      R2L_PHASE_BEGIN
+      r2l_adjoint_blur_tail<G>(tid, G2, HP, F, t.oy, t.ox, a.H, a.W);
+      R2L_PHASE_END
+    }
     R2L_STAMP(1)
     R2L_PHASE_BEGIN
     if (t.border) {

@@ -1,0 +1,102 @@
+"""Randomised parity sweep on the GPU (not part of the pytest suite): random frame shapes, perturbed parameters,
+BatchNorm modes and containers, fused output + all parameter gradients against the float64 oracle."""
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import isp_oracle as orc
+from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+import parity_checks as pc
+
+dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+if dev == 'cpu':       # the host emulation of the same kernels (slow: keep SECONDS small)
+    import conftest
+    from raw2logit_amd import _lib
+    _lib.enable_test_emulation(conftest.build_emulation())
+rng = np.random.default_rng(int(os.environ.get('SEED', '0')))
+budget = float(os.environ.get('SECONDS', '90'))
+t0 = time.time()
+n = 0
+worst = {'out': 0.0, 'grad': 0.0}
+while time.time() - t0 < budget:
+    B = int(rng.integers(1, 4))
+    H = 2 * int(rng.integers(2, 90))
+    W = 2 * int(rng.integers(2, 110))
+    cam = [orc.DRONE_CAMERA_PARAMS, orc.MICROSCOPY_CAMERA_PARAMS, orc.DEFAULT_CAMERA_PARAMS][int(rng.integers(0, 3))]
+    bn = ['none', 'train', 'eval'][int(rng.integers(0, 3))]
+    kind = ['scene', 'uniform', 'dark', 'midtone', 'midtone'][int(rng.integers(0, 5))]
+    u16 = bool(rng.integers(0, 2)) and W % 4 == 0
+    if kind == 'midtone':      # well conditioned (no clip events, Drone parameters, 1 % perturbation): tight limits
+        cam = orc.DRONE_CAMERA_PARAMS
+        raw_np = pc.midtone_frames(B, H, W, seed=int(rng.integers(0, 1 << 30)))
+    else:
+        raw_np = orc.synth_raw(B, H, W, seed=int(rng.integers(0, 1 << 30)), kind=kind)
+    P = orc.IspParams(cam, dtype=np.float32)
+    if rng.integers(0, 2):
+        P.perturb(int(rng.integers(0, 1 << 30)), 0.01 if kind == 'midtone' else 0.05)
+    m = ParametrizedProcessing(cam, batch_norm_output=(bn != 'none'))
+    with torch.no_grad():
+        for k, v in P.by_name().items():
+            if k != 'additive_layer':
+                pc.NAME2ATTR[k](m).copy_(torch.from_numpy(np.asarray(v)))
+    m = m.to(dev)
+    if bn == 'eval':
+        m.eval()
+        with torch.no_grad():
+            m.batch_norm.running_mean.copy_(torch.tensor([0.3, 0.35, 0.4]))
+            m.batch_norm.running_var.copy_(torch.tensor([0.02, 0.03, 0.025]))
+    else:
+        m.train()
+    cot = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    if u16:
+        codes = np.rint(raw_np.astype(np.float64) * 4095).astype(np.uint16)
+        raw_np = (codes.astype(np.float32) / np.float32(4095))
+        m.raw_bits = 12
+        x = torch.from_numpy(codes).to(dev)
+    else:
+        x = torch.from_numpy(raw_np).to(dev)
+    y = m(x)
+    (y * torch.from_numpy(cot).to(dev)).sum().backward()
+    obn = None
+    if bn == 'train':
+        obn = dict(training=True, running_mean=np.zeros(3), running_var=np.ones(3))
+    elif bn == 'eval':
+        obn = dict(training=False, running_mean=np.array([0.3, 0.35, 0.4]), running_var=np.array([0.02, 0.03, 0.025]))
+    Pm = P.astype(np.float64)
+    o, _, cache = orc.parametrized_forward(raw_np, Pm, bn=obn)
+    g, _, _ = orc.parametrized_backward(Pm, cache, cot)
+    glo, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=1e-5)
+    ghi, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=-1e-5)
+    # conditioning: the same oracle in float32 arithmetic (the reference's precision).  Near the lower clip
+    # threshold d/dx x**(1/gamma) ~ 1e5, so float32 round-off of the linear part moves some gradients by percents
+    _, _, c32 = orc.parametrized_forward(raw_np, P, bn=obn)
+    g32, _, _ = orc.parametrized_backward(P, c32, cot)
+    tol = pc.out_tolerance(cache, bn != 'none')
+    eo = np.abs(y.detach().cpu().numpy() - o)
+    assert np.all(eo <= 3 * tol), (B, H, W, bn, kind, u16, eo.max())
+    worst['out'] = max(worst['out'], float((eo / tol).max()))
+    for k in g:
+        got = pc.NAME2ATTR[k](m).grad.detach().cpu().numpy().reshape(np.asarray(g[k]).shape)
+        flip = max(np.abs(np.asarray(glo[k]) - g[k]).max(), np.abs(np.asarray(ghi[k]) - g[k]).max())
+        e = np.abs(got - g[k]).max()
+        cond = np.abs(np.asarray(g32[k], dtype=np.float64) - g[k]).max()
+        if kind == 'midtone':
+            lim = (3e-5 if bn == 'none' else 2e-4) * (np.abs(g[k]).max() + 1e-6) + 2 * flip + (1e-7 * cot.size if bn != 'none' else 0.0)
+            if bn == 'train' and H * W < 256:
+                continue
+        else:
+            lim = 5e-2 * (np.abs(g[k]).max() + 1e-6) + 2 * flip + 5 * cond   # ill-conditioned kinds: coarse net only
+        if e > lim:
+            for sh in (3e-6, 1e-5, 3e-5):
+                a1, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=sh)
+                a2, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=-sh)
+                print('  clip_shift', sh, 'moves this gradient by', max(np.abs(np.asarray(a1[k]) - g[k]).max(), np.abs(np.asarray(a2[k]) - g[k]).max()))
+            pre = cache['rgb']
+            print('  pixels within 1e-5 of a clip threshold:', int(((np.abs(pre - 1.0) < 1e-5) | (np.abs(pre - 1e-5) < 1e-5)).sum()), 'of', pre.size,
+                  ' camera', 'drone' if cam is orc.DRONE_CAMERA_PARAMS else ('micro' if cam is orc.MICROSCOPY_CAMERA_PARAMS else 'identity'))
+            print('FAIL', (B, H, W, bn, kind, u16, k, e, lim, float(np.abs(g[k]).max()), float(flip)))
+            np.set_printoptions(precision=4, suppress=True)
+            print('got', got.ravel()); print('ref', np.asarray(g[k]).ravel())
+            raise SystemExit(1)
+        worst['grad'] = max(worst['grad'], float(e / lim))
+    n += 1
+print(f'{n} random cases ok in {time.time() - t0:.0f} s; worst out error / tolerance {worst["out"]:.2f}, '
+      f'worst grad error / limit {worst["grad"]:.2f}')

@@ -242,6 +242,68 @@ def check_ragged_and_properties(device, B=2, H=70, W=134):
         assert torch.allclose(yt.double(), (y.double() - mu) * torch.rsqrt(var + 1e-5), rtol=0, atol=2e-5)
 
 
+FRAME_SHAPES = [(66, 130), (130, 66), (64, 66), (66, 64), (66, 66), (6, 78), (4, 4), (4, 6), (62, 126), (68, 70),
+                (2 * 64 + 2, 14), (70, 134)]
+
+
+def midtone_frames(B, H, W, seed):
+    """12-bit RGGB frames of a smooth grey scene whose pre-gamma RGB stays inside (0.05, 0.95) under the Drone
+    parameters (also when perturbed by 1 %, and on the image border, where the zero-padded sharpening
+    filter roughly triples the luma): no pixel near a clip threshold, modest power-law slope, so float32
+    round-off is the only difference between a correct kernel and the float64 oracle."""
+    rng = np.random.default_rng(seed)
+    bl, wb, _ = orc.DRONE_CAMERA_PARAMS
+    y, x = np.mgrid[0:H, 0:W]
+    grey = 0.2 + 0.03 * np.sin(x / 9.0 + seed) + 0.02 * np.cos(y / 7.0) + rng.uniform(-0.002, 0.002, (B, H, W))
+    gain = np.where(y % 2 == 0, np.where(x % 2 == 0, wb[0], wb[1]), np.where(x % 2 == 0, wb[1], wb[2]))
+    black = np.where(y % 2 == 0, np.where(x % 2 == 0, bl[0], bl[1]), np.where(x % 2 == 0, bl[2], bl[3]))
+    u16 = np.clip(np.round(4095 * (black + grey / gain)), 0, 4095)
+    return (u16.astype(np.float32) / np.float32(4095)).astype(np.float32)
+
+
+def check_frame_shapes(device, shapes=FRAME_SHAPES, B=2):
+    """Fused forward + every parameter gradient against the float64 oracle over frame shapes that put the image
+    edge at every distance (0, 2, 4, 6 pixels) from a tile boundary, below the halo width and in frames smaller
+    than the halo.  (A randomised sweep found the H % 64 == 2 case: the mirror images of rows H-3, H-2 then fall
+    in the last two frame rows of the tile above.)"""
+    worst = 0.0
+    for n, (H, W) in enumerate(shapes):
+        for bn in (False, True):
+            if bn and H * W < 256:     # batch statistics of a few dozen samples: the BatchNorm backward cancels
+                continue               # to round-off level (the golden case tiny_4x4 covers that path)
+            raw_np = midtone_frames(B, H, W, seed=20 + n)
+            P = orc.IspParams(orc.DRONE_CAMERA_PARAMS, dtype=np.float32)
+            P.perturb(31 + n, 0.01)
+            m = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=bn)
+            with torch.no_grad():
+                for k, v in P.by_name().items():
+                    if k != 'additive_layer':
+                        NAME2ATTR[k](m).copy_(torch.from_numpy(np.asarray(v)))
+            m = m.to(device).train()
+            cot = np.random.default_rng(40 + n).standard_normal((B, 3, H, W)).astype(np.float32)
+            y = m(torch.from_numpy(raw_np).to(device))
+            (y * torch.from_numpy(cot).to(device)).sum().backward()
+            obn = dict(training=True, running_mean=np.zeros(3), running_var=np.ones(3)) if bn else None
+            Pm = P.astype(np.float64)
+            o, _, cache = orc.parametrized_forward(raw_np, Pm, bn=obn)
+            g, _, _ = orc.parametrized_backward(Pm, cache, cot)
+            glo, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=1e-6)
+            ghi, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=-1e-6)
+            assert cache['rgb'].min() > 0.05 and cache['rgb'].max() < 0.95, (cache['rgb'].min(), cache['rgb'].max())
+            eo = np.abs(y.detach().cpu().numpy() - o)
+            assert np.all(eo <= out_tolerance(cache, bn)), (H, W, bn, eo.max())
+            for k in g:
+                ref = np.asarray(g[k])
+                got = NAME2ATTR[k](m).grad.detach().cpu().numpy().reshape(ref.shape)
+                flip = max(np.abs(np.asarray(glo[k]) - ref).max(), np.abs(np.asarray(ghi[k]) - ref).max())
+                lim = 3e-5 * (np.abs(ref).max() + 1e-6) + 2 * flip
+                if bn:      # BatchNorm's backward cancels: float32 round-off of a sum of B*3*H*W terms of size ~1
+                    lim += 1e-7 * cot.size
+                worst = max(worst, np.abs(got - ref).max() / lim)
+                assert np.abs(got - ref).max() <= lim, (H, W, bn, k, np.abs(got - ref).max(), lim)
+    return worst
+
+
 def check_grid_independence(device, B=40, H=64, W=64):
     """The in-kernel final reductions (statistics, BatchNorm backward sums, the 155 gradient sums + unfold) are
     finished by whichever workgroups arrive last; the result must not depend on the number of workgroups

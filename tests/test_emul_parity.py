@@ -28,6 +28,10 @@ def test_properties(emulation):
     pc.check_ragged_and_properties('cpu')
 
 
+def test_frame_shapes_around_tile_boundaries(emulation):
+    pc.check_frame_shapes('cpu')
+
+
 def test_harness_logits_and_adam_step(golden, emulation):
     pc.check_harness(golden, 'cpu')
 

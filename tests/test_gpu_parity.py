@@ -42,6 +42,10 @@ def test_properties(dev):
     pc.check_ragged_and_properties(dev)
 
 
+def test_frame_shapes_around_tile_boundaries(dev):
+    pc.check_frame_shapes(dev)
+
+
 def test_cpu_tensor_is_refused(dev):
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     from raw2logit_amd import _lib
