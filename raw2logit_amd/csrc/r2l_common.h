@@ -30,6 +30,13 @@ struct alignas(8) r2l_f2 {
 R2L_HD float r2l_log2(float x) { return log2f(x); }
 R2L_HD float r2l_exp2(float x) { return exp2f(x); }
 R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
+R2L_HD r2l_f4 r2l_stream_load_f4(const float* p) { return *(const r2l_f4*)p; }
+R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& v) { *(r2l_f4*)p = v; }
+// the emulation runs one lane at a time: kernels take their every-lane-loads form there
+#define R2L_HAVE_LANE_SHIFTS false
+#define R2L_LANE_ID 0
+R2L_HD float r2l_wave_shr1(float x) { return x; }
+R2L_HD float r2l_wave_shl1(float x) { return x; }
 #define R2L_PHASE_BEGIN for (int tid = 0; tid < R2L_NT; ++tid) {
 #define R2L_PHASE_BEGIN_N(NT) for (int tid = 0; tid < (NT); ++tid) {
 #define R2L_PHASE_END }
@@ -52,6 +59,47 @@ typedef float2 r2l_f2;
 R2L_HD float r2l_log2(float x) { return __builtin_amdgcn_logf(x); }
 R2L_HD float r2l_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 R2L_HD float r2l_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// value of the previous / next lane of the 64-lane wavefront (DPP wave shifts; lane 0 / 63 keep their own)
+#define R2L_HAVE_LANE_SHIFTS true
+#define R2L_LANE_ID ((int)(threadIdx.x & 63))
+R2L_HD float r2l_wave_shr1(float x) {
+  const int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x138, 0xf, 0xf, false));
+}
+R2L_HD float r2l_wave_shl1(float x) {
+  const int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x130, 0xf, 0xf, false));
+}
+// Touched-once streams (a frame read once, an output written once) can take the nontemporal policy.  A pure
+// 4 B : 12 B copy of the static chain's shape gains 5 % from it (tests/probes/stream_probe.hip: 5.2 -> 5.5-5.7
+// TB/s); the kernels themselves do not (profiles/r01_e_static_ab.txt), so both switches are OFF by default:
+// -DR2L_NT_LOADS / -DR2L_NT_STORES build the nontemporal forms for A/B runs.
+typedef float r2l_v4 __attribute__((ext_vector_type(4)));
+R2L_HD r2l_f4 r2l_stream_load_f4(const float* p) {
+#ifndef R2L_NT_LOADS
+  return *(const r2l_f4*)p;
+#else
+  const r2l_v4 v = __builtin_nontemporal_load((const r2l_v4*)p);
+  r2l_f4 o;
+  o.x = v.x;
+  o.y = v.y;
+  o.z = v.z;
+  o.w = v.w;
+  return o;
+#endif
+}
+R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& s) {
+#ifndef R2L_NT_STORES
+  *(r2l_f4*)p = s;
+#else
+  r2l_v4 v;
+  v.x = s.x;
+  v.y = s.y;
+  v.z = s.z;
+  v.w = s.w;
+  __builtin_nontemporal_store(v, (r2l_v4*)p);
+#endif
+}
 #define R2L_PHASE_BEGIN \
   {                     \
     const int tid = threadIdx.x;

@@ -30,7 +30,11 @@ struct R2LRowStage {
   float v[8];
   int ys;
 };
-template <bool U16>
+// LANES: the neighbour columns come from the neighbouring lanes of the wavefront (DPP wave shifts) when the row
+// enters the window; only lane 0 / lane 63 fetch theirs from the neighbouring strip (one load instruction for
+// both, staged in v[0..1] resp. v[0]).  Otherwise every lane loads its own neighbour pairs (hits in L1).  On the
+// bilinear chain (1 neighbour each side) the lane form is 3 % faster, on Malvar (2 each side) 9 % slower.
+template <bool U16, bool LANES>
 R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, size_t img0, int ys, int x0, bool le, bool re,
                                  R2LRowStage& st) {
   const size_t e = img0 + (size_t)ys * a.W + x0;
@@ -41,16 +45,32 @@ R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, size_t img0, int ys, in
     const r2l_f2 c = *(const r2l_f2*)r;
     v[1] = c.x;
     v[2] = c.y;
+    if (LANES) {
+      const int lane = (x0 >> 2) & 63;
+      v[0] = v[3] = 0.f;
+      if ((lane == 0 && !le) || (lane == 63 && !re)) v[0] = *(const float*)(lane == 0 ? r - 2 : r + 4);
+      return;
+    }
     v[0] = le ? 0.f : *(const float*)(r - 2);
     v[3] = re ? 0.f : *(const float*)(r + 4);
     return;
   }
   const float* r = a.raw.f32 + e;
-  const r2l_f4 c = *(const r2l_f4*)r;
+  const r2l_f4 c = r2l_stream_load_f4(r);
   v[2] = c.x;
   v[3] = c.y;
   v[4] = c.z;
   v[5] = c.w;
+  if (LANES) {
+    const int lane = (x0 >> 2) & 63;
+    v[0] = v[1] = v[6] = v[7] = 0.f;
+    if ((lane == 0 && !le) || (lane == 63 && !re)) {
+      const r2l_f2 q = *(const r2l_f2*)(lane == 0 ? r - 2 : r + 4);
+      v[0] = q.x;
+      v[1] = q.y;
+    }
+    return;
+  }
   if (le) {  // x = -1 -> 0, x = -2 -> 1
     v[0] = c.y;
     v[1] = c.x;
@@ -69,12 +89,20 @@ R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, size_t img0, int ys, in
   }
 }
 // staged row -> 8 black-level-corrected float64 values (the black level follows the SOURCE site)
-template <bool U16>
+template <bool U16, bool LANES>
 R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStage& st, bool le, bool re,
                                    double dst[8]) {
   float v[8];
   if (U16) {
-    const unsigned l = r2l_f2u(st.v[0]), c0 = r2l_f2u(st.v[1]), c1 = r2l_f2u(st.v[2]), q = r2l_f2u(st.v[3]);
+    const unsigned c0 = r2l_f2u(st.v[1]), c1 = r2l_f2u(st.v[2]);
+    unsigned l = r2l_f2u(st.v[0]), q = r2l_f2u(st.v[3]);
+    if (LANES) {
+      const int lane = R2L_LANE_ID;
+      l = r2l_f2u(r2l_wave_shr1(st.v[2]));
+      q = r2l_f2u(r2l_wave_shl1(st.v[1]));
+      if (lane == 0) l = r2l_f2u(st.v[0]);
+      if (lane == 63) q = r2l_f2u(st.v[0]);
+    }
     v[2] = r2l_raw_decode(c0 & 0xffffu, a.raw);
     v[3] = r2l_raw_decode(c0 >> 16, a.raw);
     v[4] = r2l_raw_decode(c1 & 0xffffu, a.raw);
@@ -86,6 +114,21 @@ R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStage& st
   } else {
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 8; ++i) v[i] = st.v[i];
+    if (LANES) {
+      const int lane = R2L_LANE_ID;
+      v[0] = r2l_wave_shr1(st.v[4]);  // columns x0-2, x0-1 = the left lane's x0+2, x0+3
+      v[1] = r2l_wave_shr1(st.v[5]);
+      v[6] = r2l_wave_shl1(st.v[2]);  // columns x0+4, x0+5 = the right lane's x0, x0+1
+      v[7] = r2l_wave_shl1(st.v[3]);
+      if (lane == 0) {
+        v[0] = le ? st.v[3] : st.v[0];
+        v[1] = le ? st.v[2] : st.v[1];
+      }
+      if (lane == 63 || re) {
+        v[6] = re ? st.v[5] : st.v[0];
+        v[7] = re ? st.v[4] : st.v[1];
+      }
+    }
   }
   const int ys = st.ys;
   const double be = (ys & 1) ? a.bl[2] : a.bl[0], bo = (ys & 1) ? a.bl[3] : a.bl[1];
@@ -100,6 +143,15 @@ R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStage& st
   dst[7] = (double)v[7] - (re ? be : bo);
 }
 
+// np.clip(img, 0, 1) (:138) and img ** (1 / gamma) (:243) of one float64 value.  Rounding to float32 is
+// monotonic and 0, 1 are float32 numbers, so clipping after the conversion gives the same float32 as clipping
+// before it (one v_cvt + a clamp instead of two float64 compares).  0 needs no special case: log2(0) = -inf,
+// -inf * (1 / gamma) = -inf, exp2(-inf) = 0 -- in libm and in v_log_f32 / v_exp_f32 alike.
+R2L_HD float r2l_clip_gamma(double rgb, float inv_gamma) {
+  const float xf = fminf(fmaxf((float)rgb, 0.f), 1.f);
+  return r2l_exp2(r2l_log2(xf) * inv_gamma);
+}
+
 // WB * CCM, clip, gamma and the three 16-byte stores of one output row (4 pixels of this lane)
 R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], float* outb, size_t plane,
                                   size_t off) {
@@ -109,8 +161,7 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
     R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
     const double rgb = a.wbccm[k * 3] * d[c][0] + a.wbccm[k * 3 + 1] * d[c][1] + a.wbccm[k * 3 + 2] * d[c][2];
-    const float xf = (float)fmin(fmax(rgb, 0.0), 1.0);                  // np.clip(img, 0, 1)   :138
-    x[k][c] = (xf > 0.f) ? r2l_exp2(r2l_log2(xf) * a.inv_gamma) : 0.f;  // img ** (1 / gamma)   :243
+    x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
   }
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
@@ -119,7 +170,7 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
     st.y = x[k][1];
     st.z = x[k][2];
     st.w = x[k][3];
-    *(r2l_f4*)(outb + (size_t)k * plane + off) = st;
+    r2l_stream_store_f4(outb + (size_t)k * plane + off, st);
   }
 }
 
@@ -146,8 +197,7 @@ R2L_HD void r2l_stream_luma_in_row(const R2LStaticArgs& a, const double d[4][3],
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < 3; ++k) {
       const double rgb = a.M2[k * 3] * yy + a.M2[k * 3 + 1] * u + a.M2[k * 3 + 2] * v;
-      const float xf = (float)fmin(fmax(rgb, 0.0), 1.0);
-      x[k][c] = (xf > 0.f) ? r2l_exp2(r2l_log2(xf) * a.inv_gamma) : 0.f;
+      x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
     }
   }
   R2L_PRAGMA_UNROLL
@@ -157,7 +207,7 @@ R2L_HD void r2l_stream_luma_in_row(const R2LStaticArgs& a, const double d[4][3],
     st.y = x[k][1];
     st.z = x[k][2];
     st.w = x[k][3];
-    *(r2l_f4*)(outb + (size_t)k * plane + off) = st;
+    r2l_stream_store_f4(outb + (size_t)k * plane + off, st);
   }
 }
 
@@ -181,6 +231,58 @@ R2L_HD void r2l_stream_bilinear_row(const double* w0, const double* w1, const do
   }
 }
 
+// The same convolution on rows / columns whose 3x3 neighbourhood lies inside the image, where the masks are
+// the plain checkerboard: per site the masked sums collapse to the pixel itself, the mean of its 2 row / column
+// neighbours, of its 4 edge neighbours or of its 4 corner neighbours.  u/m/l = window rows y-1, y, y+1;
+// vertical pair sums are shared by the 4 pixels.  (Summation order differs from the masked form by round-off
+// of float64 only.)  Pixel c = 0 (c = 3) is NOT valid on the lane that holds the left (right) image edge.
+template <int PY>
+R2L_HD void r2l_stream_bilinear_row_interior(const double* u, const double* m, const double* l, double d[4][3]) {
+  double vs[8], hs[4];
+  R2L_PRAGMA_UNROLL
+  for (int j = 1; j < 7; ++j) vs[j] = u[j] + l[j];
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) hs[c] = m[1 + c] + m[3 + c];
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) {
+    const int j = 2 + c;
+    const double corners = (vs[j - 1] + vs[j + 1]) * 0.25, edges = (vs[j] + hs[c]) * 0.25;
+    if (PY == 0 && (c & 1) == 0) {  // R site
+      d[c][0] = m[j];
+      d[c][1] = edges;
+      d[c][2] = corners;
+    } else if (PY == 0) {  // G site of an R row: R left/right, B above/below
+      d[c][0] = hs[c] * 0.5;
+      d[c][1] = m[j];
+      d[c][2] = vs[j] * 0.5;
+    } else if ((c & 1) == 0) {  // G site of a B row
+      d[c][0] = vs[j] * 0.5;
+      d[c][1] = m[j];
+      d[c][2] = hs[c] * 0.5;
+    } else {  // B site
+      d[c][0] = corners;
+      d[c][1] = edges;
+      d[c][2] = m[j];
+    }
+  }
+}
+// pixel c of the lane through the masked form (the lanes on the left / right image edge: c = 0 / c = 3)
+R2L_HD void r2l_stream_bilinear_edge_px(const double* w0, const double* w1, const double* w2, int py, int c, bool le,
+                                        bool re, double d[3]) {
+  double n[3][3];
+  R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    n[0][j] = w0[1 + c + j];
+    n[1][j] = w1[1 + c + j];
+    n[2][j] = w2[1 + c + j];
+  }
+  const int tpy[3] = {1 - py, py, 1 - py};
+  int tpx[3] = {1 - (c & 1), c & 1, 1 - (c & 1)};
+  if (c == 0 && le) tpx[0] = 0;
+  if (c == 3 && re) tpx[2] = 1;
+  r2l_bilinear_px(n, tpy, tpx, d);
+}
+
 template <int PY>
 R2L_HD void r2l_stream_malvar_row(const double* w0, const double* w1, const double* w2, const double* w3,
                                   const double* w4, double d[4][3]) {
@@ -199,11 +301,18 @@ R2L_HD void r2l_stream_malvar_row(const double* w0, const double* w1, const doub
   }
 }
 
+#ifndef R2L_STREAM_PF_BILINEAR
+#define R2L_STREAM_PF_BILINEAR 3
+#endif
+#ifndef R2L_STREAM_PF_MALVAR
+#define R2L_STREAM_PF_MALVAR 2
+#endif
 // one lane's work item: image b, column strip seg (256 columns), row band
 template <int DEB, bool U16, bool LUMA>
 R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int lane) {
   const R2LStaticArgs& a = sa.s;
   constexpr int HALO = DEB ? 2 : 1, NR = 2 * HALO + 1;
+  constexpr bool LANES = (DEB == 0) && R2L_HAVE_LANE_SHIFTS;
   const int seg = item % sa.nseg, r = item / sa.nseg;
   const int band = r % sa.nband, b = r / sa.nband;
   const int x0 = seg * 256 + 4 * lane;
@@ -221,35 +330,39 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < NR - 1; ++i) {
     const int ys = r2l_symmetric(y0 - HALO + i, a.H);
-    r2l_stream_fetch_row<U16>(a, img, ys, x0, le, re, st);
-    r2l_stream_convert_row<U16>(a, st, le, re, win[i]);
+    r2l_stream_fetch_row<U16, LANES>(a, img, ys, x0, le, re, st);
+    r2l_stream_convert_row<U16, LANES>(a, st, le, re, win[i]);
     par[i] = ys & 1;
   }
-  // software pipeline, two rows deep: the rows needed by the next TWO output rows are in flight while
-  // this one is computed (st = row y+HALO, st2 = row y+HALO+1)
-  R2LRowStage st2;
-  r2l_stream_fetch_row<U16>(a, img, r2l_symmetric(y0 + HALO, a.H), x0, le, re, st);
-  r2l_stream_fetch_row<U16>(a, img, r2l_symmetric(y0 + HALO + 1, a.H), x0, le, re, st2);
+  // software pipeline, PF rows deep: the rows needed by the next PF output rows are in flight while this one
+  // is computed (pf[i] = row y+HALO+i).  At 3-4 wavefronts per SIMD (the float64 window costs the registers)
+  // the bytes in flight come from the depth, not from the occupancy.
+  constexpr int PF = DEB ? R2L_STREAM_PF_MALVAR : R2L_STREAM_PF_BILINEAR;
+  R2LRowStage pf[PF];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i) r2l_stream_fetch_row<U16, LANES>(a, img, r2l_symmetric(y0 + HALO + i, a.H), x0, le, re, pf[i]);
   for (int yb = y0; yb < y1; yb += NR) {
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < NR; ++k) {  // unrolled by the window depth: slot indices are compile-time
       const int y = yb + k;
       if (y < y1) {
         // newest row y + HALO (fetched one iteration ago) goes to slot (k + NR - 1) % NR
-        r2l_stream_convert_row<U16>(a, st, le, re, win[(k + NR - 1) % NR]);
-        par[(k + NR - 1) % NR] = st.ys & 1;
-        st = st2;
-        if (y + 2 < y1) r2l_stream_fetch_row<U16>(a, img, r2l_symmetric(y + 2 + HALO, a.H), x0, le, re, st2);
+        r2l_stream_convert_row<U16, LANES>(a, pf[0], le, re, win[(k + NR - 1) % NR]);
+        par[(k + NR - 1) % NR] = pf[0].ys & 1;
+        R2L_PRAGMA_UNROLL
+        for (int i = 0; i + 1 < PF; ++i) pf[i] = pf[i + 1];
+        if (y + PF < y1) r2l_stream_fetch_row<U16, LANES>(a, img, r2l_symmetric(y + PF + HALO, a.H), x0, le, re, pf[PF - 1]);
         double d[4][3];
         if (DEB == 0) {
-          // interior rows: the tap rows have the checkerboard parities (compile-time after the uniform
-          // branch); the first / last image row sees a mirrored row and takes the runtime parities
-          if (y > 0 && y < a.H - 1 && (y & 1)) {
-            const int tpy[3] = {0, 1, 0};
-            r2l_stream_bilinear_row(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], tpy, le, re, d);
-          } else if (y > 0 && y < a.H - 1) {
-            const int tpy[3] = {1, 0, 1};
-            r2l_stream_bilinear_row(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], tpy, le, re, d);
+          // interior rows: closed-form sums (the two lanes on the image edge redo their edge pixel with the
+          // masks); the first / last image row sees a mirrored row and takes the masked form throughout
+          if (y > 0 && y < a.H - 1) {
+            if (y & 1)
+              r2l_stream_bilinear_row_interior<1>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], d);
+            else
+              r2l_stream_bilinear_row_interior<0>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], d);
+            if (le) r2l_stream_bilinear_edge_px(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], y & 1, 0, le, re, d[0]);
+            if (re) r2l_stream_bilinear_edge_px(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], y & 1, 3, le, re, d[3]);
           } else {
             const int tpy[3] = {par[k % NR], par[(k + 1) % NR], par[(k + 2) % NR]};
             r2l_stream_bilinear_row(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], tpy, le, re, d);
