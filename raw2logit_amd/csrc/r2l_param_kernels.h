@@ -733,7 +733,7 @@ R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, in
 #ifdef R2L_EXP_NOSTORE
         if (st.x == 123456.0f)
 #endif
-        *(r2l_f4*)(ob + off) = st;
+        *(r2l_f4*)(ob + off) = st;  // (a nontemporal store here costs the apply pass 4 %)
       } else {
         R2L_PRAGMA_UNROLL
         for (int c = 0; c < 4; ++c)
@@ -951,7 +951,8 @@ R2L_HD void r2l_bwd1_fetch_gout(int tid, const R2LBwd1Args& a, const R2LTile& t,
   const unsigned pix0 = (unsigned)(t.oy + row0) * (unsigned)a.W + (unsigned)(t.ox + 4 * tx);
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k)
-    gp.g[r][k] = *(const r2l_f4*)(gb + (unsigned)k * plane + pix0 + (unsigned)(2 * r) * (unsigned)a.W);
+    // read once here: nontemporal, so that it does not evict the raw frames / dL/dY'' (A/B: -1 % on the step)
+    gp.g[r][k] = r2l_load_f4_nt(gb + (unsigned)k * plane + pix0 + (unsigned)(2 * r) * (unsigned)a.W);
 }
 
 // one output row (4 pixels of this thread) of kernel B1; PY = row parity
