@@ -231,18 +231,30 @@ R2L_HD void r2l_stream_bilinear_row(const double* w0, const double* w1, const do
   }
 }
 
-// The same convolution on rows / columns whose 3x3 neighbourhood lies inside the image, where the masks are
-// the plain checkerboard: per site the masked sums collapse to the pixel itself, the mean of its 2 row / column
-// neighbours, of its 4 edge neighbours or of its 4 corner neighbours.  u/m/l = window rows y-1, y, y+1;
-// vertical pair sums are shared by the 4 pixels.  (Summation order differs from the masked form by round-off
-// of float64 only.)  Pixel c = 0 (c = 3) is NOT valid on the lane that holds the left (right) image edge.
+// The same convolution on rows y-1, y, y+1 inside the image, where the row masks are the plain checkerboard: per
+// site the masked sums collapse to the pixel itself, the mean of its 2 row / column neighbours, of its 4 edge or
+// of its 4 corner neighbours.  u/m/l = window rows y-1, y, y+1; vertical pair sums are shared by the 4 pixels.
+// (Summation order differs from the masked form by round-off of float64 only.)
+// Left / right image edge (le: pixel c = 0 is column 0; re: pixel c = 3 is column W-1): the column mirrored back
+// from outside is the edge column itself, so its taps carry the EDGE column's sites, not the checkerboard's.
+// In the closed form that is: the outer column contributes nothing to what the checkerboard expected there
+// (its values are zeroed), and the taps of that column (weights [1 2 1]/4 for R/B, [0 1 0]/4 for G) add to the
+// channels the edge column itself holds: the pixel's own channel gets +1/2 (R/B) or +1/4 (G) of the pixel, and
+// the channel of the rows above / below gets +1/4 of their sum when it is R or B.
 template <int PY>
-R2L_HD void r2l_stream_bilinear_row_interior(const double* u, const double* m, const double* l, double d[4][3]) {
+R2L_HD void r2l_stream_bilinear_row_interior(const double* u, const double* m, const double* l, bool le, bool re,
+                                             double d[4][3]) {
   double vs[8], hs[4];
   R2L_PRAGMA_UNROLL
   for (int j = 1; j < 7; ++j) vs[j] = u[j] + l[j];
-  R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) hs[c] = m[1 + c] + m[3 + c];
+  const double fl = le ? 1.0 : 0.0, fr = re ? 1.0 : 0.0;
+  const double m1 = le ? 0.0 : m[1], m6 = re ? 0.0 : m[6];
+  vs[1] = le ? 0.0 : vs[1];
+  vs[6] = re ? 0.0 : vs[6];
+  hs[0] = m1 + m[3];
+  hs[1] = m[2] + m[4];
+  hs[2] = m[3] + m[5];
+  hs[3] = m[4] + m6;
   R2L_PRAGMA_UNROLL
   for (int c = 0; c < 4; ++c) {
     const int j = 2 + c;
@@ -265,22 +277,15 @@ R2L_HD void r2l_stream_bilinear_row_interior(const double* u, const double* m, c
       d[c][2] = m[j];
     }
   }
-}
-// pixel c of the lane through the masked form (the lanes on the left / right image edge: c = 0 / c = 3)
-R2L_HD void r2l_stream_bilinear_edge_px(const double* w0, const double* w1, const double* w2, int py, int c, bool le,
-                                        bool re, double d[3]) {
-  double n[3][3];
-  R2L_PRAGMA_UNROLL
-  for (int j = 0; j < 3; ++j) {
-    n[0][j] = w0[1 + c + j];
-    n[1][j] = w1[1 + c + j];
-    n[2][j] = w2[1 + c + j];
+  if (PY == 0) {
+    d[0][0] += fl * (0.5 * m[2]);   // column 0 is R here, G2 above / below
+    d[3][1] += fr * (0.25 * m[5]);  // column W-1 is G1 here, B above / below
+    d[3][2] += fr * (0.25 * vs[5]);
+  } else {
+    d[0][1] += fl * (0.25 * m[2]);  // column 0 is G2 here, R above / below
+    d[0][0] += fl * (0.25 * vs[2]);
+    d[3][2] += fr * (0.5 * m[5]);   // column W-1 is B here, G1 above / below
   }
-  const int tpy[3] = {1 - py, py, 1 - py};
-  int tpx[3] = {1 - (c & 1), c & 1, 1 - (c & 1)};
-  if (c == 0 && le) tpx[0] = 0;
-  if (c == 3 && re) tpx[2] = 1;
-  r2l_bilinear_px(n, tpy, tpx, d);
 }
 
 template <int PY>
@@ -354,15 +359,13 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
         if (y + PF < y1) r2l_stream_fetch_row<U16, LANES>(a, img, r2l_symmetric(y + PF + HALO, a.H), x0, le, re, pf[PF - 1]);
         double d[4][3];
         if (DEB == 0) {
-          // interior rows: closed-form sums (the two lanes on the image edge redo their edge pixel with the
-          // masks); the first / last image row sees a mirrored row and takes the masked form throughout
+          // interior rows: closed-form sums (left / right image edge included); the first / last image row sees
+          // a mirrored row and takes the masked form
           if (y > 0 && y < a.H - 1) {
             if (y & 1)
-              r2l_stream_bilinear_row_interior<1>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], d);
+              r2l_stream_bilinear_row_interior<1>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], le, re, d);
             else
-              r2l_stream_bilinear_row_interior<0>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], d);
-            if (le) r2l_stream_bilinear_edge_px(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], y & 1, 0, le, re, d[0]);
-            if (re) r2l_stream_bilinear_edge_px(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], y & 1, 3, le, re, d[3]);
+              r2l_stream_bilinear_row_interior<0>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], le, re, d);
           } else {
             const int tpy[3] = {par[k % NR], par[(k + 1) % NR], par[(k + 2) % NR]};
             r2l_stream_bilinear_row(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], tpy, le, re, d);

@@ -7,7 +7,7 @@ for v in default "$@"; do
   for nb in ${BANDS:-0}; do
     if [ "$nb" = 0 ]; then unset R2L_STREAM_BANDS; else export R2L_STREAM_BANDS=$nb; fi
     for deb in bilinear malvar2004; do
-      python bench.py --workload static --steps 10 --warmup 2 --no-cpu-baseline --debayer $deb 2>/dev/null | python -c "
+      python bench.py --workload static --steps 30 --warmup 5 --no-cpu-baseline --debayer $deb 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']
