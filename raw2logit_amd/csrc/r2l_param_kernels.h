@@ -1023,8 +1023,8 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
       const r2l_p2 gxo = r2l_pmul(gx, og);
       ggam = r2l_pfma(gxo, lg, ggam);
       const r2l_p2 gc = r2l_pmul(r2l_pmul(gxo, r2l_splat2(F.inv_gamma)), r2l_mk2(r2l_rcp(xc[0]), r2l_rcp(xc[1])));
-      grgb[k][p] = r2l_mk2((rgb[0] >= 1e-5f && rgb[0] <= 1.0f) ? gc[0] : 0.f,       // torch.clip backward
-                           (rgb[1] >= 1e-5f && rgb[1] <= 1.0f) ? gc[1] : 0.f);
+      // torch.clip backward: the gradient passes where 1e-5 <= rgb <= 1, i.e. where clipping left rgb unchanged
+      grgb[k][p] = r2l_mk2((rgb[0] == xc[0]) ? gc[0] : 0.f, (rgb[1] == xc[1]) ? gc[1] : 0.f);
     }
   }
   r2l_p2 gy2[2], gu[2], gv[2];  // d loss / d (Y'', U, V)
