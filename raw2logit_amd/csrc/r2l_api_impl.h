@@ -176,7 +176,10 @@ R2L_KERNEL_NT(r2l_launch_static_luma_malvar, R2LStaticStreamArgs, r2l_stream_blo
 R2L_KERNEL_NT(r2l_launch_static_luma_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma_u16, R2L_STREAM_NT, 4)
 R2L_KERNEL_NT(r2l_launch_static_luma_malvar_u16, R2LStaticStreamArgs, r2l_stream_block_malvar_luma_u16, R2L_STREAM_NT, 3)
 R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
-R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear, R2L_STREAM_NT, 4)
+#ifndef R2L_STREAM_OCC_BILINEAR
+#define R2L_STREAM_OCC_BILINEAR 4
+#endif
+R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
 R2L_KERNEL_NT(r2l_launch_static_stream_malvar, R2LStaticStreamArgs, r2l_stream_block_malvar, R2L_STREAM_NT, 3)
 R2L_KERNEL_NT(r2l_launch_static_stream_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_u16, R2L_STREAM_NT, 4)
 R2L_KERNEL_NT(r2l_launch_static_stream_malvar_u16, R2LStaticStreamArgs, r2l_stream_block_malvar_u16, R2L_STREAM_NT, 3)

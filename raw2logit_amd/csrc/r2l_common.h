@@ -62,7 +62,11 @@ R2L_HD float r2l_log2(float x) { return __builtin_amdgcn_logf(x); }
 R2L_HD float r2l_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 R2L_HD float r2l_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // value of the previous / next lane of the 64-lane wavefront (DPP wave shifts; lane 0 / 63 keep their own)
+#ifdef R2L_HAVE_LANE_SHIFTS_OFF  // A/B builds: every lane loads its neighbour columns
+#define R2L_HAVE_LANE_SHIFTS false
+#else
 #define R2L_HAVE_LANE_SHIFTS true
+#endif
 #define R2L_LANE_ID ((int)(threadIdx.x & 63))
 R2L_HD float r2l_wave_shr1(float x) {
   const int i = __builtin_bit_cast(int, x);
