@@ -37,12 +37,12 @@ ALGO_BYTES_PER_PX = {
 }
 
 
-def pmc_traffic(kernel, B, S):
+def pmc_traffic(kernel, B, S, name='r01_pmc_traffic.json', shape=(64, 512)):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
-    their own runs, gfx950 correction applied; profiles/r01_pmc_traffic.json), valid for the 64x512x512
-    workload only; None otherwise."""
-    path = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
-    if (B, S) != (64, 512) or not os.path.exists(path):
+    their own runs, gfx950 correction applied; profiles/r01_pmc_traffic*.json), valid for the workload shape the
+    passes were collected on only (64x512x512 parametrized, 256x1024x1024 static); None otherwise."""
+    path = os.path.join(REPO, 'profiles', name)
+    if (B, S) != shape or not os.path.exists(path):
         return None
     with open(path) as f:
         t = json.load(f)
@@ -186,7 +186,9 @@ def main_static(args):
                           'global_batch': world * B, 'frame': [S, S],
                           'parallelism': f'batch shard x{world}, no collective' if world > 1 else 'single GPU'},
                'roofline': {'bound': 'hbm', 'kernel': name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                            'traffic': None if args.raw_u16 else
+                            pmc_traffic(name, B, S, 'r01_pmc_traffic_static.json', (256, 1024)),
                             'avg_us': round(avg_us, 1), 'algo_bytes_per_px': bpp}}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_static(args.debayer)
