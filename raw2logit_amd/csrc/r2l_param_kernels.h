@@ -308,17 +308,30 @@ R2L_HD void r2l_window_rows6(const float* Pl, int fy0, int fx, float w[RPI + 2][
     w[i][5] = h.x;
   }
 }
-// The stencil phases work on items of 4 columns x 4 rows: 18 x 18 (Y) or 18 x 17 (YP, adjoint blur) items
-// cover the frame in ONE pass of the 512 lanes (with 4 x 2 items the 630 items needed a second pass in which
-// two wavefronts worked and six waited at the barrier), and an even row count keeps the Bayer row parity of
-// every output row a compile-time constant.
-#define R2L_RPI 4
+// The stencil phases work on items of 4 columns x RPI rows, one item per lane, ONE pass (with 4 x 2 items the
+// 630 items needed a second pass in which two wavefronts worked and six waited at the barrier).  4-row items
+// (18 x 18 = 324 for Y, 18 x 17 = 306 for YP / the adjoint blur) fill 5 wavefronts, so SIMD 0 issues two streams
+// while two SIMDs idle; taller items make exactly 4 wavefronts, one per SIMD.  That pays for the adjoint blur
+// (5-row items, 252 of them: bwd2 -3 us); for Y and YP the taller register windows spill in the forward kernel
+// (128 VGPRs) and cost more than the balance gains (measured: forward 78 -> 85 us with 5-row YP items, 92 us with
+// 6-row Y items), so they stay at 4.  An even row count keeps the Bayer row parity of every output row of the Y
+// phase a compile-time constant.
+#ifndef R2L_RPI_Y
+#define R2L_RPI_Y 4
+#endif
+#ifndef R2L_RPI_YP
+#define R2L_RPI_YP 4
+#endif
+#ifndef R2L_RPI_ADJ
+#define R2L_RPI_ADJ 5
+#endif
+static_assert(R2L_RPI_Y % 2 == 0, "row parity of the Y phase");
 
 // ---- phase B: Y on frame rows/cols [1, F-1) ------------------------------------------------------
 template <class G, bool BORDER>
 R2L_HD void r2l_compute_y(int tid, const float* V, float* Y, R2LFoldedRef F, int oy, int ox, int H,
                           int W) {
-  constexpr int CPR = G::FW / 4, RPI = R2L_RPI, NRG = (G::FH - 2 + RPI - 1) / RPI;
+  constexpr int CPR = G::FW / 4, RPI = R2L_RPI_Y, NRG = (G::FH - 2 + RPI - 1) / RPI;
   static_assert(CPR * NRG <= R2L_NT, "one pass");
   const int rg = tid / CPR, col = tid - rg * CPR;
   if (rg >= NRG) return;
@@ -358,8 +371,8 @@ R2L_HD void r2l_compute_y(int tid, const float* V, float* Y, R2LFoldedRef F, int
 // ---- phase C: YP = sharpen(Y) on frame rows/cols [2, F-2), stored shifted by +2 columns ----------
 template <class G>
 R2L_HD void r2l_compute_yp(int tid, const float* Y, float* YP, R2LFoldedRef F) {
-  constexpr int CPR = G::FW / 4, RPI = R2L_RPI, NRG = (G::FH - 4) / RPI;
-  static_assert((G::FH - 4) % RPI == 0 && CPR * NRG <= R2L_NT, "one pass, no ragged row group");
+  constexpr int CPR = G::FW / 4, RPI = R2L_RPI_YP, NRG = (G::FH - 4 + RPI - 1) / RPI;
+  static_assert(CPR * NRG <= R2L_NT, "one pass");
   const int rg = tid / CPR, col = tid - rg * CPR;
   if (rg >= NRG) return;
   const int fy0 = 2 + RPI * rg, fx = 4 * col;
@@ -383,8 +396,10 @@ R2L_HD void r2l_compute_yp(int tid, const float* Y, float* YP, R2LFoldedRef F) {
     lo.y = o[0][1];
     hi.x = o[1][0];
     hi.y = o[1][1];
-    *(r2l_f2*)d = lo;
-    *(r2l_f2*)(d + 2) = hi;
+    if ((G::FH - 4) % RPI == 0 || fy0 + r < G::FH - 2) {  // ragged last row group
+      *(r2l_f2*)d = lo;
+      *(r2l_f2*)(d + 2) = hi;
+    }
   }
 }
 
@@ -1217,15 +1232,17 @@ R2L_HD float r2l_b2_slot(const R2LBwd2Regs& r, int i) {
 // phase: HP(q') = sum_t blur[t] * G2_ext0(q' - t) on frame rows/cols [2, F-2); G2 is stored shifted
 template <class G>
 R2L_HD void r2l_adjoint_blur(int tid, const float* G2, float* HP, R2LFoldedRef F) {
-  constexpr int CPR = G::FW / 4, RPI = R2L_RPI, NRG = (G::FH - 4) / RPI;
-  static_assert((G::FH - 4) % RPI == 0 && CPR * NRG <= R2L_NT, "one pass, no ragged row group");
+  constexpr int CPR = G::FW / 4, RPI = R2L_RPI_ADJ, NRG = (G::FH - 4 + RPI - 1) / RPI;
+  static_assert(CPR * NRG <= R2L_NT, "one pass");
   const int rg = tid / CPR, cx = tid - rg * CPR;
   if (rg >= NRG) return;
   const int fy0 = 2 + RPI * rg, fx = 4 * cx;
   float w[RPI + 4][8];  // rows fy0-2..fy0+RPI+1, cols fx-2..fx+5
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < RPI + 4; ++i) {
-    const float* r = G2 + (fy0 - 2 + i) * G::FS + fx;  // (+2 shift) - 2
+    // rows past the end of the plane (ragged last row group) are clamped: they only feed rows that are not stored
+    const int fy = (fy0 - 2 + i < G::FH - 1) ? fy0 - 2 + i : G::FH - 1;
+    const float* r = G2 + fy * G::FS + fx;  // (+2 shift) - 2
     const r2l_f4 a = r2l_lds_f4(r);
     const r2l_f4 b = r2l_lds_f4(r + 4);
     w[i][0] = a.x;
@@ -1255,7 +1272,7 @@ R2L_HD void r2l_adjoint_blur(int tid, const float* G2, float* HP, R2LFoldedRef F
     st.y = o[0][1];
     st.z = o[1][0];
     st.w = o[1][1];
-    *(r2l_f4*)(HP + (fy0 + r) * G::FS + fx) = st;
+    if ((G::FH - 4) % RPI == 0 || fy0 + r < G::FH - 2) *(r2l_f4*)(HP + (fy0 + r) * G::FS + fx) = st;  // ragged group
   }
 }
 
