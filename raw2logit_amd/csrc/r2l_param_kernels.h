@@ -1102,6 +1102,119 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
   regs.acc[R2L_L1_SV] = r2l_padd(regs.acc[R2L_L1_SV], r2l_padd(gv[0], gv[1]));
 }
 
+// Both rows of a thread (frame rows frow0 and frow0 + 2, the same Bayer row parity), STAGE by stage instead of row
+// by row: the ~85 weights of a row body do not fit the scalar registers, so the row-by-row form re-loads them
+// for every row (8 scalar-load waits per row, each a full `s_waitcnt lgkmcnt(0)` with one other wave per SIMD to
+// hide behind); stage-major, every group of weights is fetched once per two rows.  Hot instantiation only (tiles
+// inside the image, prefetched grad_out).
+template <class G, int PY, bool ADD>
+R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a, int tx, int frow0, unsigned off00,
+                           unsigned plane, const R2LGoutPre& gpre, float* gyb, const R2LBnConsts& bc,
+                           R2LBwd1Regs& regs) {
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
+  r2l_p2 ypp[2][2], u[2][2], v[2][2];
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 2; ++r) {
+    float yw[5][8];
+    r2l_rows_yp<G>(YP, tx, frow0 + 2 * r, yw);
+    r2l_blur_row2(yw, F, ypp[r]);
+  }
+  R2L_SCHED_FENCE();
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 2; ++r) {
+    float vw[3][6];
+    r2l_rows_3x6<G>(V, tx, frow0 + 2 * r, vw);
+    r2l_chroma_row2<PY>(vw, F, u[r], v[r]);
+  }
+  R2L_SCHED_FENCE();
+  r2l_p2 gy2[2][2], gu[2][2], gv[2][2];  // d loss / d (Y'', U, V)
+  r2l_p2 ggam = r2l_splat2(0.f);
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 2; ++r) {
+    const unsigned off0 = off00 + (unsigned)(2 * r) * (unsigned)a.W;
+    r2l_p2 grgb[3][2];
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      const unsigned off = (unsigned)k * plane + off0;
+      const float g[4] = {gpre.g[r][k].x, gpre.g[r][k].y, gpre.g[r][k].z, gpre.g[r][k].w};
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) {
+        r2l_p2 rgb = r2l_pmul(r2l_splat2(F.M2[k * 3]), ypp[r][p]);
+        rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 1]), u[r][p], rgb);
+        rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 2]), v[r][p], rgb);
+        const r2l_p2 xc = r2l_mk2(fminf(fmaxf(rgb[0], 1e-5f), 1.0f), fminf(fmaxf(rgb[1], 1e-5f), 1.0f));
+        const r2l_p2 lg = r2l_mk2(r2l_log2(xc[0]), r2l_log2(xc[1]));
+        const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));
+        const r2l_p2 og = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
+        r2l_p2 x = og;
+        if (ADD) x = r2l_padd(x, r2l_mk2(a.additive[off + 2 * p], a.additive[off + 2 * p + 1]));
+        const r2l_p2 xhat = r2l_pmul(r2l_padd(x, r2l_splat2(-bc.mean[k])), r2l_splat2(bc.istd[k]));
+        r2l_p2 gx = r2l_padd(r2l_mk2(g[2 * p], g[2 * p + 1]), r2l_splat2(-bc.mg[k]));  // BatchNorm2d backward
+        gx = r2l_pmul(r2l_splat2(bc.istd[k]), r2l_pfma(xhat, r2l_splat2(-bc.mgx[k]), gx));
+        const r2l_p2 gxo = r2l_pmul(gx, og);
+        ggam = r2l_pfma(gxo, lg, ggam);
+        const r2l_p2 gc = r2l_pmul(r2l_pmul(gxo, r2l_splat2(F.inv_gamma)), r2l_mk2(r2l_rcp(xc[0]), r2l_rcp(xc[1])));
+        grgb[k][p] = r2l_mk2((rgb[0] == xc[0]) ? gc[0] : 0.f, (rgb[1] == xc[1]) ? gc[1] : 0.f);  // clip backward
+      }
+    }
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) {
+      gy2[r][p] = r2l_pfma(r2l_splat2(F.M2[6]), grgb[2][p],
+                           r2l_pfma(r2l_splat2(F.M2[3]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[0]), grgb[0][p])));
+      gu[r][p] = r2l_pfma(r2l_splat2(F.M2[7]), grgb[2][p],
+                          r2l_pfma(r2l_splat2(F.M2[4]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[1]), grgb[0][p])));
+      gv[r][p] = r2l_pfma(r2l_splat2(F.M2[8]), grgb[2][p],
+                          r2l_pfma(r2l_splat2(F.M2[5]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[2]), grgb[0][p])));
+    }
+    r2l_f4 st;
+    st.x = gy2[r][0][0];
+    st.y = gy2[r][0][1];
+    st.z = gy2[r][1][0];
+    st.w = gy2[r][1][1];
+    *(r2l_f4*)(gyb + off0) = st;
+  }
+  R2L_SCHED_FENCE();
+  regs.acc[R2L_L1_GGAM] = r2l_padd(regs.acc[R2L_L1_GGAM], ggam);
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 2; ++r) {  // d/d gaussian_blur.weight (windows read from LDS a second time, see r2l_bwd1_row)
+    float yw[5][8];
+    r2l_rows_yp<G>(YP, tx, frow0 + 2 * r, yw);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 5; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      r2l_p2 sacc = regs.acc[R2L_L1_GBLUR + i * 5 + j];
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) sacc = r2l_pfma(gy2[r][p], r2l_mk2(yw[i][2 * p + j], yw[i][2 * p + j + 1]), sacc);
+      regs.acc[R2L_L1_GBLUR + i * 5 + j] = sacc;
+    }
+    R2L_SCHED_FENCE();
+  }
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 2; ++r) {  // folded chroma stencils
+    float vw[3][6];
+    r2l_rows_3x6<G>(V, tx, frow0 + 2 * r, vw);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      r2l_p2 su = regs.acc[R2L_L1_GAU + i * 3 + j];
+      r2l_p2 sv = regs.acc[R2L_L1_GAV + i * 3 + j];
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) {
+        const r2l_p2 x = r2l_mk2(vw[i][2 * p + j], vw[i][2 * p + j + 1]);
+        su = r2l_pfma(gu[r][p], x, su);
+        sv = r2l_pfma(gv[r][p], x, sv);
+      }
+      regs.acc[R2L_L1_GAU + i * 3 + j] = su;
+      regs.acc[R2L_L1_GAV + i * 3 + j] = sv;
+    }
+    regs.acc[R2L_L1_SU] = r2l_padd(regs.acc[R2L_L1_SU], r2l_padd(gu[r][0], gu[r][1]));
+    regs.acc[R2L_L1_SV] = r2l_padd(regs.acc[R2L_L1_SV], r2l_padd(gv[r][0], gv[r][1]));
+    R2L_SCHED_FENCE();
+  }
+}
+
 template <class G, bool RAGGED, bool ADD, bool PRE>
 R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LBwd1Args& a,
                             const R2LTile& t, const R2LGoutPre& gp, R2LBwd1Regs& regs) {
@@ -1121,6 +1234,15 @@ R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LB
     bc.mg[k] = a.bn_bwd ? a.bn_bwd[k] : 0.f;
     bc.mgx[k] = a.bn_bwd ? a.bn_bwd[3 + k] : 0.f;
   }
+#ifndef R2L_B1_ROW_MAJOR
+  if (!RAGGED && PRE) {
+    if (py)
+      r2l_bwd1_rows2<G, 1, ADD>(V, YP, a, tx, row0 + 4, pix0, plane, gp, gyb, bc, regs);
+    else
+      r2l_bwd1_rows2<G, 0, ADD>(V, YP, a, tx, row0 + 4, pix0, plane, gp, gyb, bc, regs);
+    return;
+  }
+#endif
   R2L_PRAGMA_NOUNROLL
   for (int rr = 0; rr < 4; rr += 2) {
     if (RAGGED && gy0 + rr >= a.H) break;
