@@ -152,7 +152,10 @@ R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& s) {
 // SQ_LDS_BANK_CONFLICT = 68 % of SQ_LDS_IDX_ACTIVE).
 #ifdef R2L_EMUL
 R2L_HD r2l_f4 r2l_lds_f4(const float* p) { return *(const r2l_f4*)p; }
+R2L_HD float r2l_lds_f1(const float* p) { return *p; }
 #else
+// one float, as its own ds_read_b32 (never merged with a neighbour)
+R2L_HD float r2l_lds_f1(const float* p) { return *(const volatile __attribute__((address_space(3))) float*)p; }
 typedef float r2l_v4 __attribute__((ext_vector_type(4)));
 R2L_HD r2l_f4 r2l_lds_f4(const float* p) {
   // volatile: the access may neither be split nor merged with neighbours, but several of them can

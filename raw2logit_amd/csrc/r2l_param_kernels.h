@@ -64,8 +64,29 @@ struct R2LTile {
 // XCD-aware tile walk: workgroup ids are dealt round-robin over the 8 XCDs (each with a private L2),
 // so ids with equal (bid % 8) share an L2.  Each such group walks its own contiguous 1/8 of the tile
 // list, which keeps halo rows/columns shared by neighbouring tiles inside one L2.
+// Division of a tile index by a launch constant (tiles per row, rows per image, tiles per walk block): a runtime
+// u32 division costs ~35 scalar instructions and the walk needs five per tile, on the critical path between two
+// barriers (measured: 750 cycles per tile, 4 % of the backward kernels).  Round-up multiplier (Granlund &
+// Montgomery): l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1, n / d = (mulhi(m, n) + n) >> l for n < 2^31.
+// m comes from one float64 division: 2^32 (2^l - d) / d is an integer only for d a power of two (where it is 0,
+// exactly), otherwise its fractional part is at least 1/d > 2^-31, far above the float64 rounding error.
+struct R2LDiv {
+  unsigned m, l, d;
+};
+R2L_HD R2LDiv r2l_div_init(int d_) {
+  R2LDiv r;
+  r.d = (unsigned)d_;
+  r.l = 0;
+  while ((1u << r.l) < r.d) ++r.l;
+  r.m = (unsigned)(4294967296.0 * ((double)((1u << r.l) - r.d) / (double)r.d)) + 1u;
+  return r;
+}
+R2L_HD unsigned r2l_mulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+R2L_HD int r2l_div(int n, const R2LDiv& dv) { return (int)((r2l_mulhi(dv.m, (unsigned)n) + (unsigned)n) >> dv.l); }
+
 struct R2LTileWalk {
   int ntx, nty, ntiles, nper, group, w, k, jstep;
+  R2LDiv dx, dy, dj;
 };
 R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, int nblk) {
   R2LTileWalk w;
@@ -78,6 +99,9 @@ R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, i
   w.w = bid / ngroups;
   w.k = 0;
   w.jstep = nblk / ngroups;
+  w.dx = r2l_div_init(w.ntx);
+  w.dy = r2l_div_init(w.nty);
+  w.dj = r2l_div_init(w.jstep);
   return w;
 }
 // k-th tile of a workgroup: block k of `jstep` consecutive tiles, rotated by k tile rows + k tile columns
@@ -87,14 +111,15 @@ R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, i
 // 28 % above the mean).
 R2L_HD bool r2l_walk_next(R2LTileWalk& w, int H, int W, int TW, int TH, R2LTile& t) {
   while (w.k * w.jstep < w.nper) {
-    const int j = w.k * w.jstep + (w.w + w.k * (w.ntx + 1)) % w.jstep;
+    const int rot = w.w + w.k * (w.ntx + 1);
+    const int j = w.k * w.jstep + (rot - r2l_div(rot, w.dj) * w.jstep);
     w.k += 1;
     if (j >= w.nper) continue;
     const int tile = w.group * w.nper + j;
     if (tile >= w.ntiles) continue;
-    const int tx = tile % w.ntx, r = tile / w.ntx;
-    t.b = r / w.nty;
-    t.oy = (r % w.nty) * TH;
+    const int r = r2l_div(tile, w.dx), tx = tile - r * w.ntx;
+    t.b = r2l_div(r, w.dy);
+    t.oy = (r - t.b * w.nty) * TH;
     t.ox = tx * TW;
     t.border = (t.oy < 4) || (t.ox < 4) || (t.oy + TH + 4 > H) || (t.ox + TW + 4 > W) || ((W & 3) != 0);
     t.ragged = (t.oy + TH > H) || (t.ox + TW > W) || ((W & 3) != 0);
@@ -293,19 +318,21 @@ R2L_HD void r2l_store_plane_s2(int tid, float* Pl, const R2LPrefetch<G>& pf) {
 // are clamped: their values only feed output rows that are not stored.
 template <class G, int RPI>
 R2L_HD void r2l_window_rows6(const float* Pl, int fy0, int fx, float w[RPI + 2][6]) {
+  // The two outer columns are read as single floats.  As 128-bit reads (cols fx-4..fx-1 and fx+4..fx+7) three of
+  // their four registers are dead, hipcc overlaps those dead registers with the destination of the NEXT read,
+  // and the write-after-write hazard on a register with a load in flight makes it wait for every row's reads
+  // before issuing the next row's: one LDS round trip per row instead of one per window.
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < RPI + 2; ++i) {
     const int fy = (fy0 - 1 + i < G::FH - 1) ? fy0 - 1 + i : G::FH - 1;
-    const float* r = Pl + fy * G::FS + fx;  // three aligned 128-bit reads: cols fx-4..fx+7
-    const r2l_f4 l = r2l_lds_f4(r - 4);
+    const float* r = Pl + fy * G::FS + fx;
     const r2l_f4 m = r2l_lds_f4(r);
-    const r2l_f4 h = r2l_lds_f4(r + 4);
-    w[i][0] = l.w;
+    w[i][0] = r2l_lds_f1(r - 1);
     w[i][1] = m.x;
     w[i][2] = m.y;
     w[i][3] = m.z;
     w[i][4] = m.w;
-    w[i][5] = h.x;
+    w[i][5] = r2l_lds_f1(r + 4);
   }
 }
 // The stencil phases work on items of 4 columns x RPI rows, one item per lane, ONE pass (with 4 x 2 items the
@@ -456,21 +483,19 @@ R2L_HD void r2l_rows_yp(const float* YP, int tx, int frow, float yw[5][8]) {
   }
 }
 // 3 rows x 6 columns of an unshifted plane around output row `frow`: rows frow-1..frow+1, columns
-// fx0-1..fx0+4, fetched as three aligned 128-bit reads per row (cols fx0-4..fx0+7)
+// fx0-1..fx0+4, fetched as one aligned 128-bit read and two single floats per row
 template <class G>
 R2L_HD void r2l_rows_3x6(const float* Pl, int tx, int frow, float w[3][6]) {
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 3; ++i) {  // outer columns as single floats: see r2l_window_rows6
     const float* r = Pl + (frow - 1 + i) * G::FS + 4 * tx + 4;
-    const r2l_f4 l = r2l_lds_f4(r - 4);
     const r2l_f4 m = r2l_lds_f4(r);
-    const r2l_f4 h = r2l_lds_f4(r + 4);
-    w[i][0] = l.w;
+    w[i][0] = r2l_lds_f1(r - 1);
     w[i][1] = m.x;
     w[i][2] = m.y;
     w[i][3] = m.z;
     w[i][4] = m.w;
-    w[i][5] = h.x;
+    w[i][5] = r2l_lds_f1(r + 4);
   }
 }
 
@@ -776,6 +801,7 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
       istd[k] = a.bn[3 + k];
     }
   }
+  // (the stage-major form of r2l_bwd1_rows2 does not pay here: at 128 VGPRs it spills, 78 -> 173 us)
   R2L_PRAGMA_NOUNROLL
   for (int rr = 0; rr < 4; rr += 2) {  // rows row0 and row0 + 2
     if (RAGGED && gy0 + rr >= a.H) break;
