@@ -801,7 +801,8 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
       istd[k] = a.bn[3 + k];
     }
   }
-  // (the stage-major form of r2l_bwd1_rows2 does not pay here: at 128 VGPRs it spills, 78 -> 173 us)
+  // (the stage-major form of r2l_bwd1_rows2 does not pay here: at 128 VGPRs it spills, 78 -> 173 us; the 5x5 blur
+  // of both rows first, the rest row by row: 77 -> 79.5 us -- four waves per SIMD already hide the scalar loads)
   R2L_PRAGMA_NOUNROLL
   for (int rr = 0; rr < 4; rr += 2) {  // rows row0 and row0 + 2
     if (RAGGED && gy0 + rr >= a.H) break;
