@@ -153,7 +153,23 @@ R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& s) {
 #ifdef R2L_EMUL
 R2L_HD r2l_f4 r2l_lds_f4(const float* p) { return *(const r2l_f4*)p; }
 R2L_HD float r2l_lds_f1(const float* p) { return *p; }
+struct alignas(16) r2l_d2 {
+  double x, y;
+};
+R2L_HD r2l_d2 r2l_lds_d2(const double* p) { return *(const r2l_d2*)p; }
 #else
+// two float64 as one ds_read_b128
+struct alignas(16) r2l_d2 {
+  double x, y;
+};
+typedef double r2l_vd2 __attribute__((ext_vector_type(2)));
+R2L_HD r2l_d2 r2l_lds_d2(const double* p) {
+  const r2l_vd2 v = *(const volatile __attribute__((address_space(3))) r2l_vd2*)p;
+  r2l_d2 o;
+  o.x = v.x;
+  o.y = v.y;
+  return o;
+}
 // one float, as its own ds_read_b32 (never merged with a neighbour)
 R2L_HD float r2l_lds_f1(const float* p) { return *(const volatile __attribute__((address_space(3))) float*)p; }
 typedef float r2l_v4 __attribute__((ext_vector_type(4)));

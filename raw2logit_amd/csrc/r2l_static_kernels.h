@@ -20,6 +20,15 @@
 #pragma once
 #include "r2l_param_kernels.h"
 
+// The float64 arithmetic of the static chains is written out with explicit fma() where a fused operation is
+// wanted and compiled WITHOUT automatic contraction (until the end of r2l_static_planes.h): left to the compiler,
+// the float32 and the 16-bit instantiations of one kernel can fuse differently, and a value that differs in its
+// last float64 bit can round to a different float32 next to the clip at 0 (found by tests/fuzz_more.py: one pixel
+// in 10^8).  With this, frames fed as 16-bit containers give bit-identical results to host-normalised ones.
+#ifndef R2L_EMUL
+#pragma clang fp contract(off)
+#endif
+
 typedef R2LGeom<64, 64> GStatic;
 #define R2L_STATIC_LDS_FLOATS (2 * GStatic::PAD + 5 * GStatic::PLANE)
 #define R2L_STATIC_SHORT_LDS_FLOATS (2 * GStatic::PAD + GStatic::PLANE)
@@ -119,6 +128,70 @@ R2L_HD void r2l_load_raw_sym(int tid, float* V, const R2LRaw& raw, size_t img0, 
   }
 }
 
+// the same in two halves for the software pipeline of the full chain: the next tile's frame is fetched into
+// registers at the start of the pixel phase and written to LDS after it (16-bit containers travel undecoded in
+// .x/.y when the chunk was fetched as a vector)
+template <class G>
+struct R2LStaticPre {
+  static constexpr int NIT = ((G::FW / 4) * G::FH + R2L_NT - 1) / R2L_NT;
+  r2l_f4 v[NIT];
+};
+template <class G>
+R2L_HD void r2l_fetch_raw_sym(int tid, const R2LRaw& raw, size_t img0, int oy, int ox, int H, int W,
+                              R2LStaticPre<G>& pf) {
+  constexpr int CPR = G::FW / 4;
+  const bool vec_ok = (W & 3) == 0;
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < R2LStaticPre<G>::NIT; ++it) {
+    const int ci = tid + it * R2L_NT;
+    r2l_f4 v;
+    v.x = v.y = v.z = v.w = 0.f;
+    if (ci < CPR * G::FH) {
+      const int fy = ci / CPR, cx = ci - fy * CPR;
+      const int gy = r2l_symmetric(oy - 4 + fy, H);
+      const int gx0 = ox - 4 + 4 * cx;
+      const size_t row = img0 + (size_t)gy * W;
+      if (vec_ok && gx0 >= 0 && gx0 + 3 < W) {
+        if (raw.u16) {
+          const r2l_f2 b = *(const r2l_f2*)(raw.u16 + row + gx0);
+          v.x = b.x;
+          v.y = b.y;
+        } else {
+          v = *(const r2l_f4*)(raw.f32 + row + gx0);
+        }
+      } else {
+        v.x = r2l_raw_elem(raw, row + r2l_symmetric(gx0, W));
+        v.y = r2l_raw_elem(raw, row + r2l_symmetric(gx0 + 1, W));
+        v.z = r2l_raw_elem(raw, row + r2l_symmetric(gx0 + 2, W));
+        v.w = r2l_raw_elem(raw, row + r2l_symmetric(gx0 + 3, W));
+      }
+    }
+    pf.v[it] = v;
+  }
+}
+template <class G>
+R2L_HD void r2l_store_raw_sym(int tid, float* V, const R2LRaw& raw, int ox, int W, const R2LStaticPre<G>& pf) {
+  constexpr int CPR = G::FW / 4;
+  const bool vec_ok = (W & 3) == 0;
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < R2LStaticPre<G>::NIT; ++it) {
+    const int ci = tid + it * R2L_NT;
+    if (ci < CPR * G::FH) {
+      const int fy = ci / CPR, cx = ci - fy * CPR;
+      const int gx0 = ox - 4 + 4 * cx;
+      r2l_f4 v = pf.v[it];
+      if (raw.u16 && vec_ok && gx0 >= 0 && gx0 + 3 < W) {
+        const unsigned lo = r2l_f2u(v.x), hi = r2l_f2u(v.y);
+        v.x = r2l_raw_decode(lo & 0xffffu, raw);
+        v.y = r2l_raw_decode(lo >> 16, raw);
+        v.z = r2l_raw_decode(hi & 0xffffu, raw);
+        v.w = r2l_raw_decode(hi >> 16, raw);
+      }
+      *(r2l_f4*)(V + fy * G::FS + 4 * cx) = v;
+    }
+  }
+}
+
 // ---- demosaicing of one pixel -----------------------------------------------------------------------
 // Bilinear: three MASKED planes convolved with H_RB / H_G / H_RB.  n = black-level-corrected 3x3
 // neighbourhood, tpy/tpx = row / column parities of the taps' (symmetric-clamped) coordinates: for taps
@@ -143,6 +216,23 @@ R2L_HD void r2l_bilinear_px(const double n[3][3], const int tpy[3], const int tp
   d[0] = dr;
   d[1] = dg;
   d[2] = db;
+}
+
+// the same convolution where the 3x3 neighbourhood lies inside the image (plain checkerboard masks): the pixel
+// itself, the mean of its 2 row / column neighbours, of its 4 edge or of its 4 corner neighbours; (py, px) =
+// site parities of the pixel.  Differs from the masked form by float64 round-off of the summation order only.
+R2L_HD void r2l_bilinear_interior_px(const double n[3][3], int py, int px, double d[3]) {
+  const double vs = n[0][1] + n[2][1], hs = n[1][0] + n[1][2];
+  if (py == px) {
+    const double corners = ((n[0][0] + n[2][0]) + (n[0][2] + n[2][2])) * 0.25, edges = (vs + hs) * 0.25;
+    d[0] = py ? corners : n[1][1];
+    d[1] = edges;
+    d[2] = py ? n[1][1] : corners;
+  } else {  // G sites: (0,1) has R left/right and B above/below, (1,0) the other way round
+    d[0] = (py == 0) ? hs * 0.5 : vs * 0.5;
+    d[1] = n[1][1];
+    d[2] = (py == 0) ? vs * 0.5 : hs * 0.5;
+  }
 }
 
 // Malvar-He-Cutler 2004 (colour-demosaicing 0.1.6 coefficients), w = black-level-corrected 5x5
@@ -214,20 +304,26 @@ R2L_HD void r2l_static_window(const float* V, int fy0, int fx0, int gy0, int gx0
   }
 }
 
-// demosaiced RGB (float64) of the 4-wide x MR-tall micro-tile at frame (fy0, fx0) / global (gy0, gx0)
-#define R2L_STATIC_MR 2  // rows per micro-tile: 16 x 32 micro-tiles = all 512 lanes of the workgroup
-template <class G, bool BORDER>
-R2L_HD void r2l_static_demosaic_4x4(const float* V, int fy0, int fx0, int gy0, int gx0,
-                                    const R2LStaticArgs& a, double d[R2L_STATIC_MR][4][3]) {
-  constexpr int MR = R2L_STATIC_MR;
+// Micro-tile of the pixel stage: NC columns x MR rows per lane.  The short tile chain keeps 4 x 2 (float4 stores);
+// the full chain takes 2 x 4: its float64 luma window is then read with a lane stride of 16 bytes, i.e. free of
+// LDS bank conflicts (4-column micro-tiles read 8-byte values 32 bytes apart: 8 of the 32 banks, measured as
+// more than half of the pixel phase).
+template <bool FULL>
+struct R2LStaticMT {
+  static constexpr int NC = FULL ? 2 : 4, MR = FULL ? 4 : 2;
+};
+// demosaiced RGB (float64) of the NC-wide x MR-tall micro-tile at frame (fy0, fx0) / global (gy0, gx0)
+template <class G, bool BORDER, int NC, int MR>
+R2L_HD void r2l_static_demosaic(const float* V, int fy0, int fx0, int gy0, int gx0, const R2LStaticArgs& a,
+                                double d[MR][NC][3]) {
   if (a.debayer == R2L_DEBAYER_MALVAR2004) {
-    double w[MR + 4][8];
-    int rp[MR + 4], cp[8];
-    r2l_static_window<G, MR + 4, 8, 2, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
+    double w[MR + 4][NC + 4];
+    int rp[MR + 4], cp[NC + 4];
+    r2l_static_window<G, MR + 4, NC + 4, 2, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
     R2L_PRAGMA_UNROLL
     for (int r = 0; r < MR; ++r)
       R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
       double n[5][5];
       R2L_PRAGMA_UNROLL
       for (int i = 0; i < 5; ++i)
@@ -236,13 +332,13 @@ R2L_HD void r2l_static_demosaic_4x4(const float* V, int fy0, int fx0, int gy0, i
       r2l_malvar_px(n, r & 1, c & 1, d[r][c]);
     }
   } else {
-    double w[MR + 2][6];
-    int rp[MR + 2], cp[6];
-    r2l_static_window<G, MR + 2, 6, 1, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
+    double w[MR + 2][NC + 2];
+    int rp[MR + 2], cp[NC + 2];
+    r2l_static_window<G, MR + 2, NC + 2, 1, BORDER, 0>(V, fy0, fx0, gy0, gx0, a, w, rp, cp);
     R2L_PRAGMA_UNROLL
     for (int r = 0; r < MR; ++r)
       R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
       double n[3][3];
       int tpy[3], tpx[3];
       R2L_PRAGMA_UNROLL
@@ -252,13 +348,16 @@ R2L_HD void r2l_static_demosaic_4x4(const float* V, int fy0, int fx0, int gy0, i
         R2L_PRAGMA_UNROLL
         for (int j = 0; j < 3; ++j) n[i][j] = w[r + i][c + j];
       }
-      r2l_bilinear_px(n, tpy, tpx, d[r][c]);
+      if (BORDER)
+        r2l_bilinear_px(n, tpy, tpx, d[r][c]);
+      else
+        r2l_bilinear_interior_px(n, r & 1, c & 1, d[r][c]);  // micro-tiles start on even pixels
     }
   }
 }
 
-R2L_HD bool r2l_static_touches_border(int gy0, int gx0, int halo, int H, int W) {
-  return gy0 - halo < 0 || gx0 - halo < 0 || gy0 + R2L_STATIC_MR - 1 + halo >= H || gx0 + 3 + halo >= W;
+R2L_HD bool r2l_static_touches_border(int gy0, int gx0, int halo, int H, int W, int nc, int mr) {
+  return gy0 - halo < 0 || gx0 - halo < 0 || gy0 + mr - 1 + halo >= H || gx0 + nc - 1 + halo >= W;
 }
 
 // ---- full chain, phase B: luma on frame [1, F-1) quads -> Y (float64, zero outside the image) -------
@@ -282,8 +381,11 @@ R2L_HD void r2l_static_y_quad(const float* V, double* Y, int fy, int fx, int gy,
       R2L_PRAGMA_UNROLL
       for (int j = 0; j < 3; ++j) n[i][j] = w[r + i][c + j];
     }
-    r2l_bilinear_px(n, tpy, tpx, d);
-    const double y = a.T[0] * d[0] + a.T[1] * d[1] + a.T[2] * d[2];
+    if (BORDER)
+      r2l_bilinear_px(n, tpy, tpx, d);
+    else
+      r2l_bilinear_interior_px(n, (1 + r) & 1, (1 + c) & 1, d);  // quads start on odd pixels
+    const double y = fma(a.T[0], d[0], fma(a.T[1], d[1], a.T[2] * d[2]));
     const bool in = (unsigned)(gy + r) < (unsigned)a.H && (unsigned)(gx + c) < (unsigned)a.W;
     Y[(fy + r) * G::FS + fx + c] = in ? y : 0.0;
   }
@@ -305,16 +407,39 @@ R2L_HD void r2l_static_compute_y(int tid, const float* V, double* Y, const R2LSt
 // phase C: YP = convolve2d(Y, K, 'same', fill 0) on frame [2, F-2)
 template <class G>
 R2L_HD void r2l_static_compute_yp(int tid, const double* Y, double* YP, const R2LStaticArgs& a) {
-  constexpr int NW = G::FW - 4, NH = G::FH - 4;
-  for (int i = tid; i < NW * NH; i += R2L_NT) {
-    const int fy = 2 + i / NW, fx = 2 + i % NW;
-    double s = 0.0;
+  // items of 2 columns x 4 rows with a 6 x 6 register window read two float64 at a time (frame column fx - 2 is
+  // even, i.e. 16-byte aligned; lane stride 16 bytes: no bank conflicts): 18 LDS reads per 8 pixels instead of 72
+  constexpr int NW = G::FW - 4, NH = G::FH - 4, CW = NW / 2, RH = NH / 4;
+  static_assert(NW % 2 == 0 && NH % 4 == 0, "whole items");
+  for (int it = tid; it < CW * RH; it += R2L_NT) {
+    const int fy = 2 + 4 * (it / CW), fx = 2 + 2 * (it % CW);
+    double w[6][6];  // rows fy-1..fy+4, columns fx-2..fx+3
     R2L_PRAGMA_UNROLL
-    for (int p = 0; p < 3; ++p)
+    for (int i = 0; i < 6; ++i)
       R2L_PRAGMA_UNROLL
-    for (int q = 0; q < 3; ++q)  // true convolution: flipped kernel (K is symmetric anyway)
-      s += a.ksharp[(2 - p) * 3 + (2 - q)] * Y[(fy - 1 + p) * G::FS + fx - 1 + q];
-    YP[fy * G::FS + fx] = s;
+    for (int j = 0; j < 6; j += 2) {
+      const r2l_d2 q = r2l_lds_d2(Y + (fy - 1 + i) * G::FS + fx - 2 + j);
+      w[i][j] = q.x;
+      w[i][j + 1] = q.y;
+    }
+    R2L_PRAGMA_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      double o[2];
+      R2L_PRAGMA_UNROLL
+      for (int c = 0; c < 2; ++c) {
+        double sacc = 0.0;
+        R2L_PRAGMA_UNROLL
+        for (int p = 0; p < 3; ++p)
+          R2L_PRAGMA_UNROLL
+        for (int q = 0; q < 3; ++q)  // true convolution: flipped kernel (K is symmetric anyway)
+          sacc = fma(a.ksharp[(2 - p) * 3 + (2 - q)], w[r + p][c + q + 1], sacc);
+        o[c] = sacc;
+      }
+      r2l_d2 st;
+      st.x = o[0];
+      st.y = o[1];
+      *(r2l_d2*)(YP + (fy + r) * G::FS + fx) = st;
+    }
   }
 }
 // phase C2 (border tiles): symmetric extension of YP outside the image
@@ -330,80 +455,105 @@ R2L_HD void r2l_static_fill_yp(int tid, double* YP, int oy, int ox, int H, int W
   }
 }
 
+// np.clip(img, 0, 1) (:138) and img ** (1 / gamma) (:243) of one float64 value.  Rounding to float32 is
+// monotonic and 0, 1 are float32 numbers, so clipping after the conversion gives the same float32 as clipping
+// before it (one v_cvt + a clamp instead of two float64 compares).  0 needs no special case: log2(0) = -inf,
+// -inf * (1 / gamma) = -inf, exp2(-inf) = 0 -- in libm and in v_log_f32 / v_exp_f32 alike.
+R2L_HD float r2l_clip_gamma(double rgb, float inv_gamma) {
+  const float xf = fminf(fmaxf((float)rgb, 0.f), 1.f);
+  return r2l_exp2(r2l_log2(xf) * inv_gamma);
+}
+
 // ---- pixel stage ---------------------------------------------------------------------------------
 template <class G, bool BORDER, bool FULL>
 R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, const R2LStaticArgs& a,
                                    const R2LTile& t) {
-  constexpr int MR = R2L_STATIC_MR;
-  const int tx = mt % G::TXN, ty = mt / G::TXN;
-  const int gy0 = t.oy + MR * ty, gx0 = t.ox + 4 * tx;
-  const int fy0 = MR * ty + 4, fx0 = 4 * tx + 4;
-  double d[MR][4][3];
-  r2l_static_demosaic_4x4<G, BORDER>(V, fy0, fx0, gy0, gx0, a, d);
-  double ypp[MR][4];
+  constexpr int NC = R2LStaticMT<FULL>::NC, MR = R2LStaticMT<FULL>::MR, TXN = G::TW / NC;
+  const int tx = mt % TXN, ty = mt / TXN;
+  const int gy0 = t.oy + MR * ty, gx0 = t.ox + NC * tx;
+  const int fy0 = MR * ty + 4, fx0 = NC * tx + 4;
+  double d[MR][NC][3];
+  r2l_static_demosaic<G, BORDER, NC, MR>(V, fy0, fx0, gy0, gx0, a, d);
+  double ypp[MR][NC];
   if (FULL) {
+    // ndimage.gaussian_filter is two 1-D passes, along axis 0 (rows) first, then along axis 1: 5 + 5 taps per
+    // pixel instead of 25 (and the same order of operations as scipy)
+    static_assert(!FULL || NC % 2 == 0, "the luma window is read two float64 at a time");
+    double vert[MR][NC + 4];
     R2L_PRAGMA_UNROLL
     for (int r = 0; r < MR; ++r)
       R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) ypp[r][c] = 0.0;
+    for (int j = 0; j < NC + 4; ++j) vert[r][j] = 0.0;
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < MR + 4; ++i) {  // input row fy0-2+i contributes to output rows r = i-4 .. i
-      double row[8];
-      const double* rp = YP + (fy0 - 2 + i) * G::FS + fx0 - 2;
+      double row[NC + 4];
+      const double* rp = YP + (fy0 - 2 + i) * G::FS + fx0 - 2;  // fx0 is even: 16-byte aligned
       R2L_PRAGMA_UNROLL
-      for (int j = 0; j < 8; ++j) row[j] = rp[j];
+      for (int j = 0; j < NC + 4; j += 2) {
+        const r2l_d2 q = r2l_lds_d2(rp + j);
+        row[j] = q.x;
+        row[j + 1] = q.y;
+      }
       R2L_PRAGMA_UNROLL
       for (int r = 0; r < MR; ++r) {
         const int ki = i - r;
         if (ki < 0 || ki > 4) continue;
         R2L_PRAGMA_UNROLL
-        for (int c = 0; c < 4; ++c)
-          R2L_PRAGMA_UNROLL
-        for (int kj = 0; kj < 5; ++kj) ypp[r][c] += (a.gk[ki] * a.gk[kj]) * row[c + kj];
+        for (int j = 0; j < NC + 4; ++j) vert[r][j] = fma(a.gk[ki], row[j], vert[r][j]);
       }
+    }
+    R2L_PRAGMA_UNROLL
+    for (int r = 0; r < MR; ++r)
+      R2L_PRAGMA_UNROLL
+    for (int c = 0; c < NC; ++c) {
+      double sacc = 0.0;
+      R2L_PRAGMA_UNROLL
+      for (int kj = 0; kj < 5; ++kj) sacc = fma(a.gk[kj], vert[r][c + kj], sacc);
+      ypp[r][c] = sacc;
     }
   }
   const size_t plane = (size_t)a.H * a.W;
-  const bool vec_ok = ((a.W & 3) == 0) && (gx0 + 3 < a.W);
+  const bool vec_ok = ((a.W & (NC - 1)) == 0) && (gx0 + NC - 1 < a.W);
   R2L_PRAGMA_UNROLL
   for (int r = 0; r < MR; ++r) {
     const int gy = gy0 + r;
     if (gy >= a.H) break;
-    float x[3][4];
+    float x[3][NC];
     R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
       double rgb[3];
       if (FULL) {
-        const double u = a.T[3] * d[r][c][0] + a.T[4] * d[r][c][1] + a.T[5] * d[r][c][2];
-        const double v = a.T[6] * d[r][c][0] + a.T[7] * d[r][c][1] + a.T[8] * d[r][c][2];
+        const double u = fma(a.T[3], d[r][c][0], fma(a.T[4], d[r][c][1], a.T[5] * d[r][c][2]));
+        const double v = fma(a.T[6], d[r][c][0], fma(a.T[7], d[r][c][1], a.T[8] * d[r][c][2]));
         R2L_PRAGMA_UNROLL
         for (int k = 0; k < 3; ++k)
-          rgb[k] = a.M2[k * 3] * ypp[r][c] + a.M2[k * 3 + 1] * u + a.M2[k * 3 + 2] * v;
+          rgb[k] = fma(a.M2[k * 3], ypp[r][c], fma(a.M2[k * 3 + 1], u, a.M2[k * 3 + 2] * v));
       } else {
         R2L_PRAGMA_UNROLL
         for (int k = 0; k < 3; ++k)
-          rgb[k] = a.wbccm[k * 3] * d[r][c][0] + a.wbccm[k * 3 + 1] * d[r][c][1] +
-                   a.wbccm[k * 3 + 2] * d[r][c][2];
+          rgb[k] = fma(a.wbccm[k * 3], d[r][c][0], fma(a.wbccm[k * 3 + 1], d[r][c][1], a.wbccm[k * 3 + 2] * d[r][c][2]));
       }
       R2L_PRAGMA_UNROLL
-      for (int k = 0; k < 3; ++k) {
-        const float xf = (float)fmin(fmax(rgb[k], 0.0), 1.0);           // np.clip(img, 0, 1)  :138
-        x[k][c] = (xf > 0.f) ? r2l_exp2(r2l_log2(xf) * a.inv_gamma) : 0.f;  // img ** (1/gamma) :243
-      }
+      for (int k = 0; k < 3; ++k) x[k][c] = r2l_clip_gamma(rgb[k], a.inv_gamma);
     }
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < 3; ++k) {
       float* o = a.out + ((size_t)t.b * 3 + k) * plane + (size_t)gy * a.W + gx0;
-      if (vec_ok) {
+      if (vec_ok && NC == 4) {
         r2l_f4 st;
         st.x = x[k][0];
         st.y = x[k][1];
         st.z = x[k][2];
-        st.w = x[k][3];
+        st.w = x[k][NC - 1];
         *(r2l_f4*)o = st;
+      } else if (vec_ok && NC == 2) {
+        r2l_f2 st;
+        st.x = x[k][0];
+        st.y = x[k][1];
+        *(r2l_f2*)o = st;
       } else {
         R2L_PRAGMA_UNROLL
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < NC; ++c)
           if (gx0 + c < a.W) o[c] = x[k][c];
       }
     }
@@ -413,16 +563,37 @@ R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, con
 template <class G, bool FULL>
 R2L_HD void r2l_static_pixels(int tid, const float* V, const double* YP, const R2LStaticArgs& a,
                               const R2LTile& t) {
-  if (tid >= G::TXN * (G::TH / R2L_STATIC_MR)) return;
-  const int tx = tid % G::TXN, ty = tid / G::TXN;
-  const int gy0 = t.oy + R2L_STATIC_MR * ty, gx0 = t.ox + 4 * tx;
+  constexpr int NC = R2LStaticMT<FULL>::NC, MR = R2LStaticMT<FULL>::MR, TXN = G::TW / NC;
+  static_assert(TXN * (G::TH / MR) == R2L_NT, "one micro-tile per lane");
+  const int tx = tid % TXN, ty = tid / TXN;
+  const int gy0 = t.oy + MR * ty, gx0 = t.ox + NC * tx;
   if (gy0 >= a.H || gx0 >= a.W) return;
   const int halo = (a.debayer == R2L_DEBAYER_MALVAR2004) ? 2 : 1;
-  if (r2l_static_touches_border(gy0, gx0, halo, a.H, a.W))
+  if (r2l_static_touches_border(gy0, gx0, halo, a.H, a.W, NC, MR))
     r2l_static_pixels_impl<G, true, FULL>(tid, V, YP, a, t);
   else
     r2l_static_pixels_impl<G, false, FULL>(tid, V, YP, a, t);
 }
+
+// The chain's constants (45 float64 + the frame geometry) are kernel arguments; kept live across the tile loop they
+// overflow the scalar registers and hipcc parks them in VGPR lanes (1,400 v_readlane in the kernel, two per use of
+// a constant).  Every phase therefore re-reads the argument block through a laundered pointer to the kernarg
+// segment: only what the phase uses is loaded, into scalar registers, for the length of the phase.
+#ifdef R2L_EMUL
+#define R2L_STATIC_ARGS(a) (a)
+#else
+R2L_HD R2LStaticArgs r2l_static_args_reload() {
+  R2LStaticArgs r;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc parses this too and has no address spaces)
+  const __attribute__((address_space(4))) R2LStaticArgs* p =
+      (const __attribute__((address_space(4))) R2LStaticArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  __builtin_memcpy(&r, (const void*)p, sizeof(r));
+#endif
+  return r;
+}
+#define R2L_STATIC_ARGS(a) r2l_static_args_reload()
+#endif
 
 template <class G>
 R2L_BLOCKFN void r2l_static_block(const R2LStaticArgs& a, int bid, int nblk, float* lds) {
@@ -430,17 +601,22 @@ R2L_BLOCKFN void r2l_static_block(const R2LStaticArgs& a, int bid, int nblk, flo
   double* Y = (double*)(V + G::PLANE);
   double* YP = Y + G::PLANE;
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
-  R2LTile t;
-  while (r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t)) {
-    const size_t img0 = (size_t)t.b * a.H * a.W;
+  R2LTile t, tn;
+  R2L_TREG_DECL(R2LStaticPre<G>, pre);
+  bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
+  R2L_PHASE_BEGIN
+  if (have) r2l_fetch_raw_sym<G>(tid, a.raw, (size_t)t.b * a.H * a.W, t.oy, t.ox, a.H, a.W, R2L_TREG(pre));
+  R2L_PHASE_END
+  while (have) {
     R2L_PHASE_BEGIN
-    r2l_load_raw_sym<G>(tid, V, a.raw, img0, t.oy, t.ox, a.H, a.W);
+    r2l_store_raw_sym<G>(tid, V, a.raw, t.ox, a.W, R2L_TREG(pre));
+    R2L_PHASE_END
+    const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
+    R2L_PHASE_BEGIN
+    r2l_static_compute_y<G>(tid, V, Y, R2L_STATIC_ARGS(a), t.oy, t.ox);
     R2L_PHASE_END
     R2L_PHASE_BEGIN
-    r2l_static_compute_y<G>(tid, V, Y, a, t.oy, t.ox);
-    R2L_PHASE_END
-    R2L_PHASE_BEGIN
-    r2l_static_compute_yp<G>(tid, Y, YP, a);
+    r2l_static_compute_yp<G>(tid, Y, YP, R2L_STATIC_ARGS(a));
     R2L_PHASE_END
     if (t.border) {
       R2L_PHASE_BEGIN
@@ -448,8 +624,12 @@ R2L_BLOCKFN void r2l_static_block(const R2LStaticArgs& a, int bid, int nblk, flo
       R2L_PHASE_END
     }
     R2L_PHASE_BEGIN
-    r2l_static_pixels<G, true>(tid, V, YP, a, t);
+    // next tile's frame: in flight during the pixel phase
+    if (haven) r2l_fetch_raw_sym<G>(tid, a.raw, (size_t)tn.b * a.H * a.W, tn.oy, tn.ox, a.H, a.W, R2L_TREG(pre));
+    r2l_static_pixels<G, true>(tid, V, YP, R2L_STATIC_ARGS(a), t);
     R2L_PHASE_END
+    t = tn;
+    have = haven;
   }
 }
 

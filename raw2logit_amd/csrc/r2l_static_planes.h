@@ -78,9 +78,6 @@ R2L_HD double r2l_plane_px(const R2LPlaneArgs& a, const double* img, int y, int 
 // Interior fast path: the two adjacent pixels (x, x+1) of a lane share their window, which is fetched with
 // aligned 16-byte loads (x is even) and no border arithmetic; lanes whose window leaves the image take the
 // per-pixel path above.  `r` = window radius of the op.
-struct r2l_d2 {
-  double x, y;
-};
 R2L_HD r2l_d2 r2l_ld2(const double* p) {
 #ifdef R2L_EMUL
   r2l_d2 v;
@@ -163,3 +160,7 @@ R2L_BLOCKFN void r2l_plane_filter_block(const R2LPlaneArgs& a, int bid, int nblk
   }
   R2L_PHASE_END
 }
+
+#ifndef R2L_EMUL
+#pragma clang fp contract(fast)  // end of the static chains (see r2l_static_kernels.h)
+#endif

@@ -143,15 +143,6 @@ R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStage& st
   dst[7] = (double)v[7] - (re ? be : bo);
 }
 
-// np.clip(img, 0, 1) (:138) and img ** (1 / gamma) (:243) of one float64 value.  Rounding to float32 is
-// monotonic and 0, 1 are float32 numbers, so clipping after the conversion gives the same float32 as clipping
-// before it (one v_cvt + a clamp instead of two float64 compares).  0 needs no special case: log2(0) = -inf,
-// -inf * (1 / gamma) = -inf, exp2(-inf) = 0 -- in libm and in v_log_f32 / v_exp_f32 alike.
-R2L_HD float r2l_clip_gamma(double rgb, float inv_gamma) {
-  const float xf = fminf(fmaxf((float)rgb, 0.f), 1.f);
-  return r2l_exp2(r2l_log2(xf) * inv_gamma);
-}
-
 // WB * CCM, clip, gamma and the three 16-byte stores of one output row (4 pixels of this lane)
 R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], float* outb, size_t plane,
                                   size_t off) {
@@ -160,7 +151,7 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
   for (int c = 0; c < 4; ++c)
     R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
-    const double rgb = a.wbccm[k * 3] * d[c][0] + a.wbccm[k * 3 + 1] * d[c][1] + a.wbccm[k * 3 + 2] * d[c][2];
+    const double rgb = fma(a.wbccm[k * 3], d[c][0], fma(a.wbccm[k * 3 + 1], d[c][1], a.wbccm[k * 3 + 2] * d[c][2]));
     x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
   }
   R2L_PRAGMA_UNROLL
@@ -178,7 +169,7 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
 R2L_HD void r2l_stream_luma_out_row(const R2LStaticArgs& a, const double d[4][3], double* yplane, size_t off) {
   double y[4];
   R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) y[c] = a.T[0] * d[c][0] + a.T[1] * d[c][1] + a.T[2] * d[c][2];
+  for (int c = 0; c < 4; ++c) y[c] = fma(a.T[0], d[c][0], fma(a.T[1], d[c][1], a.T[2] * d[c][2]));
   double* o = yplane + off;
   o[0] = y[0];
   o[1] = y[1];
@@ -192,11 +183,11 @@ R2L_HD void r2l_stream_luma_in_row(const R2LStaticArgs& a, const double d[4][3],
   R2L_PRAGMA_UNROLL
   for (int c = 0; c < 4; ++c) {
     const double yy = yplane[off + c];
-    const double u = a.T[3] * d[c][0] + a.T[4] * d[c][1] + a.T[5] * d[c][2];
-    const double v = a.T[6] * d[c][0] + a.T[7] * d[c][1] + a.T[8] * d[c][2];
+    const double u = fma(a.T[3], d[c][0], fma(a.T[4], d[c][1], a.T[5] * d[c][2]));
+    const double v = fma(a.T[6], d[c][0], fma(a.T[7], d[c][1], a.T[8] * d[c][2]));
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < 3; ++k) {
-      const double rgb = a.M2[k * 3] * yy + a.M2[k * 3 + 1] * u + a.M2[k * 3 + 2] * v;
+      const double rgb = fma(a.M2[k * 3], yy, fma(a.M2[k * 3 + 1], u, a.M2[k * 3 + 2] * v));
       x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
     }
   }
@@ -278,13 +269,13 @@ R2L_HD void r2l_stream_bilinear_row_interior(const double* u, const double* m, c
     }
   }
   if (PY == 0) {
-    d[0][0] += fl * (0.5 * m[2]);   // column 0 is R here, G2 above / below
-    d[3][1] += fr * (0.25 * m[5]);  // column W-1 is G1 here, B above / below
-    d[3][2] += fr * (0.25 * vs[5]);
+    d[0][0] = fma(fl, 0.5 * m[2], d[0][0]);   // column 0 is R here, G2 above / below
+    d[3][1] = fma(fr, 0.25 * m[5], d[3][1]);  // column W-1 is G1 here, B above / below
+    d[3][2] = fma(fr, 0.25 * vs[5], d[3][2]);
   } else {
-    d[0][1] += fl * (0.25 * m[2]);  // column 0 is G2 here, R above / below
-    d[0][0] += fl * (0.25 * vs[2]);
-    d[3][2] += fr * (0.5 * m[5]);   // column W-1 is B here, G1 above / below
+    d[0][1] = fma(fl, 0.25 * m[2], d[0][1]);  // column 0 is G2 here, R above / below
+    d[0][0] = fma(fl, 0.25 * vs[2], d[0][0]);
+    d[3][2] = fma(fr, 0.5 * m[5], d[3][2]);   // column W-1 is B here, G1 above / below
   }
 }
 

@@ -54,7 +54,9 @@ def fuzz_static():
     assert e <= 1e-5, ('static', (B, H, W), deb, sh, dn, e)
     if W % 4 == 0:
         out16 = F_.static_pipeline(torch.from_numpy(u).to(dev), cam, deb, sh, dn, bits=12).cpu().numpy()
-        assert np.array_equal(out16, out), ('static u16', (B, H, W), deb, sh, dn)
+        dd = np.abs(out16.astype(np.float64) - out)
+        assert np.array_equal(out16, out), ('static u16', (B, H, W), deb, sh, dn, 'max diff', float(dd.max()), 'pixels', int((dd > 0).sum()),
+                                            'camera', 'drone' if cam is orc.DRONE_CAMERA_PARAMS else 'microscopy', np.argwhere(dd > 0)[:4].tolist())
     return e / 1e-5
 
 
