@@ -33,7 +33,6 @@ R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
 R2L_HD r2l_f4 r2l_stream_load_f4(const float* p) { return *(const r2l_f4*)p; }
 R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& v) { *(r2l_f4*)p = v; }
 R2L_HD r2l_f4 r2l_load_f4_nt(const float* p) { return *(const r2l_f4*)p; }
-R2L_HD void r2l_store_f4_nt(float* p, const r2l_f4& v) { *(r2l_f4*)p = v; }
 // the emulation runs one lane at a time: kernels take their every-lane-loads form there
 #define R2L_HAVE_LANE_SHIFTS false
 #define R2L_LANE_ID 0
@@ -103,14 +102,6 @@ R2L_HD r2l_f4 r2l_load_f4_nt(const float* p) {
   o.z = v.z;
   o.w = v.w;
   return o;
-}
-R2L_HD void r2l_store_f4_nt(float* p, const r2l_f4& s) {
-  r2l_v4 v;
-  v.x = s.x;
-  v.y = s.y;
-  v.z = s.z;
-  v.w = s.w;
-  __builtin_nontemporal_store(v, (r2l_v4*)p);
 }
 R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& s) {
 #ifndef R2L_NT_STORES
