@@ -24,6 +24,9 @@ while time.time() - t0 < budget:
     cam = [orc.DRONE_CAMERA_PARAMS, orc.MICROSCOPY_CAMERA_PARAMS, orc.DEFAULT_CAMERA_PARAMS][int(rng.integers(0, 3))]
     bn = ['none', 'train', 'eval'][int(rng.integers(0, 3))]
     kind = ['scene', 'uniform', 'dark', 'midtone', 'midtone'][int(rng.integers(0, 5))]
+    additive = rng.integers(0, 12) == 0          # the additive layer is (1,3,256,256): frames of that size only
+    if additive:
+        B, H, W = int(rng.integers(1, 3)), 256, 256
     u16 = bool(rng.integers(0, 2)) and W % 4 == 0
     if kind == 'midtone':      # well conditioned (no clip events, Drone parameters, 1 % perturbation): tight limits
         cam = orc.DRONE_CAMERA_PARAMS
@@ -34,10 +37,13 @@ while time.time() - t0 < budget:
     if rng.integers(0, 2):
         P.perturb(int(rng.integers(0, 1 << 30)), 0.01 if kind == 'midtone' else 0.05)
     m = ParametrizedProcessing(cam, batch_norm_output=(bn != 'none'))
+    if additive:
+        from raw2logit_amd.processing.pipeline_torch import append_additive_layer
+        append_additive_layer(m)
+        P.additive_layer = (0.02 * rng.standard_normal((1, 3, 256, 256))).astype(np.float32)
     with torch.no_grad():
         for k, v in P.by_name().items():
-            if k != 'additive_layer':
-                pc.NAME2ATTR[k](m).copy_(torch.from_numpy(np.asarray(v)))
+            pc.NAME2ATTR[k](m).copy_(torch.from_numpy(np.asarray(v)))
     m = m.to(dev)
     if bn == 'eval':
         m.eval()
