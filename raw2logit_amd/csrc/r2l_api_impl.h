@@ -159,6 +159,10 @@ R2L_KERNEL(r2l_launch_add_bwd, R2LAddBwdArgs, r2l_add_bwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_fwd, R2LRaw2RgbArgs, r2l_raw2rgb_fwd_block, 4)
 R2L_KERNEL(r2l_launch_raw2rgb_bwd, R2LRaw2RgbArgs, r2l_raw2rgb_bwd_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L_STATIC_LDS_FLOATS)
+// 3 wavefronts per SIMD with 5 rows in flight each beat 4 with 3 by 1 % (same-buffer A/B): the depth is what counts
+#ifndef R2L_STREAM_OCC_BILINEAR
+#define R2L_STREAM_OCC_BILINEAR 3
+#endif
 #define R2L_STREAM_BLOCK(name, DEB, U16, LUMA)                                                           \
   R2L_BLOCKFN void name(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {                  \
     r2l_static_stream_block<DEB, U16, LUMA>(sa, bid, nblk, lds);                                         \
@@ -171,17 +175,14 @@ R2L_STREAM_BLOCK(r2l_stream_block_bilinear_luma, 0, false, true)
 R2L_STREAM_BLOCK(r2l_stream_block_malvar_luma, 1, false, true)
 R2L_STREAM_BLOCK(r2l_stream_block_bilinear_luma_u16, 0, true, true)
 R2L_STREAM_BLOCK(r2l_stream_block_malvar_luma_u16, 1, true, true)
-R2L_KERNEL_NT(r2l_launch_static_luma_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma, R2L_STREAM_NT, 4)
+R2L_KERNEL_NT(r2l_launch_static_luma_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
 R2L_KERNEL_NT(r2l_launch_static_luma_malvar, R2LStaticStreamArgs, r2l_stream_block_malvar_luma, R2L_STREAM_NT, 3)
-R2L_KERNEL_NT(r2l_launch_static_luma_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma_u16, R2L_STREAM_NT, 4)
+R2L_KERNEL_NT(r2l_launch_static_luma_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma_u16, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
 R2L_KERNEL_NT(r2l_launch_static_luma_malvar_u16, R2LStaticStreamArgs, r2l_stream_block_malvar_luma_u16, R2L_STREAM_NT, 3)
 R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
-#ifndef R2L_STREAM_OCC_BILINEAR
-#define R2L_STREAM_OCC_BILINEAR 4
-#endif
 R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
 R2L_KERNEL_NT(r2l_launch_static_stream_malvar, R2LStaticStreamArgs, r2l_stream_block_malvar, R2L_STREAM_NT, 3)
-R2L_KERNEL_NT(r2l_launch_static_stream_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_u16, R2L_STREAM_NT, 4)
+R2L_KERNEL_NT(r2l_launch_static_stream_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_u16, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
 R2L_KERNEL_NT(r2l_launch_static_stream_malvar_u16, R2LStaticStreamArgs, r2l_stream_block_malvar_u16, R2L_STREAM_NT, 3)
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
@@ -551,10 +552,11 @@ static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoisin
   return debayer == R2L_DEBAYER_BILINEAR && sharpening == R2L_SHARPEN_FILTER && denoising == R2L_DENOISE_GAUSSIAN;
 }
 static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W) {
-  // one wavefront per (image, 256-column strip, row band); enough bands for ~16 wavefronts per CU, at least
-  // 16 rows each so the 2-4 halo rows re-read per band stay cheap
+  // one wavefront per (image, 256-column strip, row band); enough bands for ~128 wavefronts per CU (ten rounds
+  // of the 12 resident ones: a smooth tail), at least 16 rows each so the 2-4 halo rows re-read per band stay
+  // cheap (same-buffer A/B on 256x1024x1024: 32 bands of 32 rows -1.4 % against 8 bands of 128)
   sa.nseg = (W + 255) / 256;
-  const long want = 256L * 16 * 2;
+  const long want = 256L * 128;
   long nband = (want + (long)B * sa.nseg - 1) / ((long)B * sa.nseg);
   nband = r2l_env_int("R2L_STREAM_BANDS", (int)nband);
   if (nband > H / 16) nband = H / 16;

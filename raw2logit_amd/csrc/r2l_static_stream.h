@@ -298,7 +298,7 @@ R2L_HD void r2l_stream_malvar_row(const double* w0, const double* w1, const doub
 }
 
 #ifndef R2L_STREAM_PF_BILINEAR
-#define R2L_STREAM_PF_BILINEAR 3
+#define R2L_STREAM_PF_BILINEAR 5
 #endif
 #ifndef R2L_STREAM_PF_MALVAR
 #define R2L_STREAM_PF_MALVAR 2

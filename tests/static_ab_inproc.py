@@ -37,9 +37,15 @@ def run(f, reps=10):
         if r >= 2: ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
     return ts[len(ts) // 2]
-res = {k: [] for k in fns}
+bands = [b for b in os.environ.get('BANDS', '0').split()]       # R2L_STREAM_BANDS settings to sweep (0 = default)
+res = {(k, b): [] for k in fns for b in bands}
 for rnd in range(3):
-    for k, f in fns.items():
-        res[k].append(run(f))
-for k, v in res.items():
-    print('%-10s median us per round: %s   %6.1f GB/s' % (k, ' '.join('%7.1f' % x for x in v), 16.0 * n / min(v) / 1e3))
+    for b in bands:
+        if b == '0':
+            os.environ.pop('R2L_STREAM_BANDS', None)
+        else:
+            os.environ['R2L_STREAM_BANDS'] = b
+        for k, f in fns.items():
+            res[(k, b)].append(run(f))
+for (k, b), v in res.items():
+    print('%-10s bands %-3s median us per round: %s   %6.1f GB/s' % (k, b, ' '.join('%7.1f' % x for x in v), 16.0 * n / min(v) / 1e3))
