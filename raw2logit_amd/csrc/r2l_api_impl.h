@@ -551,18 +551,22 @@ static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoisin
   (void)W;
   return debayer == R2L_DEBAYER_BILINEAR && sharpening == R2L_SHARPEN_FILTER && denoising == R2L_DENOISE_GAUSSIAN;
 }
-static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W) {
-  // one wavefront per (image, 256-column strip, row band); enough bands for ~128 wavefronts per CU (ten rounds
-  // of the 12 resident ones: a smooth tail), at least 16 rows each so the 2-4 halo rows re-read per band stay
-  // cheap (same-buffer A/B on 256x1024x1024: 32 bands of 32 rows -1.4 % against 8 bands of 128)
+static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W, int debayer) {
+  // One wavefront per (image, 256-column strip, row band), dealt in that order, so the ~3,000 wavefronts resident
+  // at any moment work on ADJACENT bands.  Short bands keep that active region of the frames and of the output
+  // compact in HBM (a few tens of MiB instead of a slice of every image of the batch), which is worth far more
+  // than the halo rows every band re-reads (they come from L2): same-buffer A/B on 256x1024x1024, bilinear,
+  // 128 rows per band 862 us, 32 rows 830, 16 rows 800, 8 rows 735-756, 5 rows 754, 4 rows 778, 2 rows 1012.
+  // Malvar (4 halo rows, 5-row window) is flat between 24 and 48 rows per band.
   sa.nseg = (W + 255) / 256;
-  const long want = 256L * 128;
-  long nband = (want + (long)B * sa.nseg - 1) / ((long)B * sa.nseg);
+  const int rows = (debayer == R2L_DEBAYER_MALVAR2004) ? 32 : 8;
+  long nband = (H + rows - 1) / rows;
   nband = r2l_env_int("R2L_STREAM_BANDS", (int)nband);
-  if (nband > H / 16) nband = H / 16;
+  if (nband > H / 2) nband = H / 2;
   if (nband < 1) nband = 1;
   sa.band_h = (int)((H + nband - 1) / nband);
   sa.nband = (H + sa.band_h - 1) / sa.band_h;
+  (void)B;
 }
 
 static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int W, const double* camera_host,
@@ -591,7 +595,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     double* p1 = p0 + (size_t)B * H * W;
     R2LStaticStreamArgs sa;
     sa.s = a;
-    r2l_stream_shape(sa, B, H, W);
+    r2l_stream_shape(sa, B, H, W, debayer);
     const long nitems = (long)B * sa.nseg * sa.nband;
     if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_static_fwd: batch too large");
     sa.nitems = (int)nitems;
@@ -647,7 +651,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     sa.s = a;
     sa.luma_out = nullptr;
     sa.luma_in = nullptr;
-    r2l_stream_shape(sa, B, H, W);
+    r2l_stream_shape(sa, B, H, W, debayer);
     const long nitems = (long)B * sa.nseg * sa.nband;
     if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_static_fwd: batch too large");
     sa.nitems = (int)nitems;
