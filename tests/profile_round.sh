@@ -47,8 +47,8 @@ PY
 rm -rf $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/tcc1 $OUT/tcc2
 # the other measured paths: 16-bit ingest, static chains (BASELINE config 3), auxiliary losses, phase stamps
 python3 bench.py --steps 30 --warmup 5 --raw-u16 --no-cpu-baseline > $OUT/bench_u16.json 2>> $OUT/bench.err
-python3 bench.py --workload static --steps 10 --warmup 2 > $OUT/bench_static.json 2>> $OUT/bench.err
-python3 bench.py --workload static --steps 10 --warmup 2 --debayer malvar2004 --no-cpu-baseline > $OUT/bench_static_malvar.json 2>> $OUT/bench.err
+python3 bench.py --workload static --steps 30 --warmup 10 > $OUT/bench_static.json 2>> $OUT/bench.err
+python3 bench.py --workload static --steps 30 --warmup 10 --debayer malvar2004 --no-cpu-baseline > $OUT/bench_static_malvar.json 2>> $OUT/bench.err
 python3 tests/bench_static.py > $OUT/static.txt 2>&1
 python3 tests/bench_aux.py > $OUT/aux.txt 2>&1
 if [ -f tests/_build/lib_stamps.so ]; then python3 tests/stamps.py > $OUT/stamps.txt 2>&1; fi
