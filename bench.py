@@ -54,8 +54,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='frames per GPU')
-    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=None, help='frames per GPU (default: 64 parametrized, 256 static)')
+    ap.add_argument('--size', type=int, default=None, help='frame height = width (default: 512 parametrized, 1024 static)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--workload', choices=('parametrized', 'static'), default='parametrized',
@@ -140,7 +140,7 @@ def main_static(args):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dev = _init_distributed(torch, dist, world, local_rank)
     lib = _lib.device_library()
-    B, S = (args.batch if args.batch != 64 else 256), (args.size if args.size != 512 else 1024)
+    B, S = (args.batch or 256), (args.size or 1024)
     gen = torch.Generator(dev).manual_seed(rank)
     u = torch.randint(0, 4096, (B, S, S), device=dev, generator=gen, dtype=torch.int32)
     raw = u.to(torch.uint16) if args.raw_u16 else u.to(torch.float32) / 4095.0
@@ -214,7 +214,7 @@ def main():
     dev = _init_distributed(torch, dist, world, local_rank)
     lib = _lib.device_library()                     # raises if the HIP extension is missing
 
-    B, S = args.batch, args.size
+    B, S = (args.batch or 64), (args.size or 512)
     # SURVEY.md section 8d "perf" distribution: uniform 12-bit codes, raw = u16 / 4095 (float32)
     u16 = np.random.default_rng(rank).integers(0, 4096, (B, S, S)).astype(np.uint16)
     raw = torch.from_numpy(u16 if args.raw_u16 else u16.astype(np.float32) / np.float32(4095)).to(dev)
