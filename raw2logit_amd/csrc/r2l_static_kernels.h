@@ -30,7 +30,7 @@
 #endif
 
 typedef R2LGeom<64, 64> GStatic;
-#define R2L_STATIC_LDS_FLOATS (2 * GStatic::PAD + 5 * GStatic::PLANE)
+#define R2L_STATIC_LDS_FLOATS (2 * GStatic::PAD + 5 * GStatic::PLANE + 128)
 #define R2L_STATIC_SHORT_LDS_FLOATS (2 * GStatic::PAD + GStatic::PLANE)
 
 struct R2LStaticArgs {
@@ -577,22 +577,32 @@ R2L_HD void r2l_static_pixels(int tid, const float* V, const double* YP, const R
 
 // The chain's constants (45 float64 + the frame geometry) are kernel arguments; kept live across the tile loop they
 // overflow the scalar registers and hipcc parks them in VGPR lanes (1,400 v_readlane in the kernel, two per use of
-// a constant).  Every phase therefore re-reads the argument block through a laundered pointer to the kernarg
-// segment: only what the phase uses is loaded, into scalar registers, for the length of the phase.
+// a constant).  The argument block is therefore copied to LDS once per workgroup, and every phase re-reads from
+// there what it uses (broadcast ds_reads into registers for the length of the phase; reading it from the kernarg
+// segment again per phase costs a global-memory round trip at the head of every phase).
+#define R2L_STATIC_ARGS_FLOATS 128
+static_assert(sizeof(R2LStaticArgs) <= 4 * R2L_STATIC_ARGS_FLOATS, "argument block copy in LDS");
 #ifdef R2L_EMUL
-#define R2L_STATIC_ARGS(a) (a)
+#define R2L_STATIC_ARGS(a, lds_args) (a)
+R2L_HD void r2l_static_args_to_lds(int, const R2LStaticArgs&, float*) {}
 #else
-R2L_HD R2LStaticArgs r2l_static_args_reload() {
-  R2LStaticArgs r;
+R2L_HD void r2l_static_args_to_lds(int tid, const R2LStaticArgs& a, float* lds_args) {
+  (void)a;
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc parses this too and has no address spaces)
-  const __attribute__((address_space(4))) R2LStaticArgs* p =
-      (const __attribute__((address_space(4))) R2LStaticArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
-  __builtin_memcpy(&r, (const void*)p, sizeof(r));
+  const __attribute__((address_space(4))) float* p =
+      (const __attribute__((address_space(4))) float*)__builtin_amdgcn_kernarg_segment_ptr();
+  if (tid < (int)((sizeof(R2LStaticArgs) + 3) / 4)) lds_args[tid] = p[tid];
+#else
+  (void)tid;
+  (void)lds_args;
 #endif
+}
+R2L_HD R2LStaticArgs r2l_static_args_from_lds(const float* lds_args) {
+  R2LStaticArgs r;
+  __builtin_memcpy(&r, lds_args, sizeof(r));
   return r;
 }
-#define R2L_STATIC_ARGS(a) r2l_static_args_reload()
+#define R2L_STATIC_ARGS(a, lds_args) r2l_static_args_from_lds(lds_args)
 #endif
 
 template <class G>
@@ -600,6 +610,10 @@ R2L_BLOCKFN void r2l_static_block(const R2LStaticArgs& a, int bid, int nblk, flo
   float* V = lds + G::PAD;
   double* Y = (double*)(V + G::PLANE);
   double* YP = Y + G::PLANE;
+  float* lds_args = (float*)(YP + G::PLANE);
+  R2L_PHASE_BEGIN
+  r2l_static_args_to_lds(tid, a, lds_args);
+  R2L_PHASE_END
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t, tn;
   R2L_TREG_DECL(R2LStaticPre<G>, pre);
@@ -613,10 +627,10 @@ R2L_BLOCKFN void r2l_static_block(const R2LStaticArgs& a, int bid, int nblk, flo
     R2L_PHASE_END
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
     R2L_PHASE_BEGIN
-    r2l_static_compute_y<G>(tid, V, Y, R2L_STATIC_ARGS(a), t.oy, t.ox);
+    r2l_static_compute_y<G>(tid, V, Y, R2L_STATIC_ARGS(a, lds_args), t.oy, t.ox);
     R2L_PHASE_END
     R2L_PHASE_BEGIN
-    r2l_static_compute_yp<G>(tid, Y, YP, R2L_STATIC_ARGS(a));
+    r2l_static_compute_yp<G>(tid, Y, YP, R2L_STATIC_ARGS(a, lds_args));
     R2L_PHASE_END
     if (t.border) {
       R2L_PHASE_BEGIN
@@ -626,7 +640,7 @@ R2L_BLOCKFN void r2l_static_block(const R2LStaticArgs& a, int bid, int nblk, flo
     R2L_PHASE_BEGIN
     // next tile's frame: in flight during the pixel phase
     if (haven) r2l_fetch_raw_sym<G>(tid, a.raw, (size_t)tn.b * a.H * a.W, tn.oy, tn.ox, a.H, a.W, R2L_TREG(pre));
-    r2l_static_pixels<G, true>(tid, V, YP, R2L_STATIC_ARGS(a), t);
+    r2l_static_pixels<G, true>(tid, V, YP, R2L_STATIC_ARGS(a, lds_args), t);
     R2L_PHASE_END
     t = tn;
     have = haven;
