@@ -161,7 +161,7 @@ int r2l_additive_bwd(const float *grad_out, const float *out, const float *bn_me
 /* ---- static pipeline, numpy semantics (processing(), processing/pipeline_numpy.py:70-141, batched):
  * remove_blacklv (:152-158) -> demosaicing_CFA_Bayer_{bilinear,Malvar2004} (:92-95) -> wb (:161-162) ->
  * CCM (:165-167) -> [sharpening_filter (:180-191) | unsharp_masking (:170-177)] -> [gaussian_denoising (:203-209) | median_denoising
- * (:194-200)] -> clip[0,1] (:138) -> x**(1/gamma) (:241-244).  Linear part in float64 like the reference,
+ * (:194-200)] -> clip[0,1] (:138) -> x**(1/gamma) (:241-244).  Linear part in float64 like the reference (black level: see below),
  * output (B,3,H,W) float32 (RawProcessingPipeline.__call__, :55-67).  camera_host: double[16] =
  * black_level[4], white_balance[3], colour_matrix[9] (host memory).
  * The short chain (no sharpening, no denoising: BASELINE config 3) and bilinear + sharpening_filter +
@@ -172,6 +172,18 @@ size_t r2l_static_workspace_bytes(int B, int H, int W, int debayer, int sharpeni
 int r2l_static_fwd(const float *raw, float *out, int B, int H, int W, const double *camera_host,
                    int debayer, int sharpening, int denoising, double gamma, void *workspace,
                    size_t workspace_bytes, void *stream);
+/* remove_blacklv (:152-158) subtracts IN PLACE, i.e. in the dtype of the frame it is handed.  The reference's
+ * datasets hand processing() float32 frames for every tif / png tile (utils/dataset_utils.py:18-26,
+ * dataset.py:86-87; docstring :57): r2l_static_fwd (and the 16-bit entry point below, whose division is the
+ * datasets' float32 division) therefore rounds the black level to float32 and subtracts in float32 before
+ * widening -- near-black pixels differ by up to 1e-4 after the gamma from a float64 subtraction.  A float64
+ * ndarray (a DNG: uint16 raw_image_visible / (2**bits - 1) is float64) keeps float64 arithmetic throughout:
+ * r2l_static_fwd_f64 reads float64 frames (8 B/px; W % 4 == 0; every chain but the short one runs as
+ * luma-plane passes and needs r2l_static_workspace_bytes_f64()).                                         */
+size_t r2l_static_workspace_bytes_f64(int B, int H, int W, int debayer, int sharpening, int denoising);
+int r2l_static_fwd_f64(const double *raw, float *out, int B, int H, int W, const double *camera_host,
+                       int debayer, int sharpening, int denoising, double gamma, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* ---- 16-bit ingest.  The reference's datasets deliver the sensor's 16-bit
  * containers and normalise them on the host: img = load_image(path) / (2**bits - 1), float32

@@ -25,7 +25,7 @@ import torch  # noqa: E402
 
 from oracle import isp_oracle as orc  # noqa: E402
 from oracle.golden_cases import (PARAM_CASES, RAW2RGB_CASES, STATIC_CASES, SAMPLE_STRIDE,  # noqa: E402
-                                 AUX_CASES, aux_inputs)
+                                 AUX_CASES, aux_inputs, static_case_frames)
 from oracle import harness  # noqa: E402
 
 
@@ -205,25 +205,34 @@ def gen_static(ppn, out):
     for case in STATIC_CASES:
         name = case['name']
         B, H, W = case['shape']
-        raw_np = orc.synth_raw(B, H, W, seed=case['seed'], kind=case['kind'])
+        # frames in the dtype the case names: float32 is what the reference's datasets hand to processing()
+        # (utils/dataset_utils.py:18-26 -> dataset.py:86-87), float64 what a DNG's uint16 / (2**bits-1) gives
+        raw_np, u16 = static_case_frames(case)
         cam = orc.CAMERAS[case['camera']]
         res = []
         for img in raw_np:
-            # the reference is handed float64 frames: uint16 / (2**bits - 1)  (dataset.py:86-87)
-            o = ppn.processing(img.astype(np.float64).copy(), *cam, debayer=case['debayer'],
+            frame = img.copy()
+            o = ppn.processing(frame, *cam, debayer=case['debayer'],
                                sharpening=case['sharpening'], denoising=case['denoising'])
+            assert frame.dtype == raw_np.dtype        # remove_blacklv worked in place, in the frame's dtype
             res.append(o)
         res = np.stack(res)                                  # (B,H,W,3) float64
         out[f'{name}/raw'] = raw_np
+        if u16 is not None:
+            out[f'{name}/u16'] = u16
         out[f'{name}/out_hwc_f64'] = res
         # RawProcessingPipeline wrapper (pipeline_numpy.py:36-67): (3,H,W) float32 tensor
         pipe = ppn.RawProcessingPipeline(cam, debayer=case['debayer'], sharpening=case['sharpening'],
                                          denoising=case['denoising'])
-        t = pipe(raw_np[0].astype(np.float64).copy())
+        t = pipe(raw_np[0].copy())
         assert t.dtype == torch.float32 and tuple(t.shape) == (3, H, W)
         out[f'{name}/pipeline_chw_f32'] = t.numpy()
         mine = orc.static_batch(raw_np, cam, case['debayer'], case['sharpening'], case['denoising'])
-        print(f'  {name:32s} oracle-vs-reference: {np.abs(mine - res.transpose(0, 3, 1, 2)).max():.2e}')
+        other = np.float64 if raw_np.dtype == np.float32 else np.float32
+        cross = orc.static_batch(raw_np.astype(other), cam, case['debayer'], case['sharpening'], case['denoising'])
+        print(f'  {name:32s} {str(raw_np.dtype):8s} oracle-vs-reference: '
+              f'{np.abs(mine - res.transpose(0, 3, 1, 2)).max():.2e}   (frames cast to {other.__name__}: '
+              f'{np.abs(cross - res.transpose(0, 3, 1, 2)).max():.2e})')
 
 
 def gen_harness(ppt, out):
@@ -278,6 +287,8 @@ def main():
     for fname, fn, mod in [('param_cases.npz', gen_param_cases, ppt), ('raw2rgb.npz', gen_raw2rgb, ppt),
                            ('static_cases.npz', gen_static, ppn), ('harness.npz', gen_harness, ppt),
                            ('aux_losses.npz', gen_aux, None)]:
+        if len(sys.argv) > 1 and fname.split('.')[0] not in sys.argv[1:]:
+            continue          # `python oracle/gen_golden.py static_cases` regenerates one file
         out = {}
         print(fname)
         fn(mod, out)

@@ -55,6 +55,12 @@ SAMPLE_STRIDE = 8          # 'full=False' cases store [..., ::8, ::8] samples (+
 RAW2RGB_CASES = [(True, 3), (True, 4), (False, 3), (False, 4)]
 
 # numpy ("static") semantics -- processing() (pipeline_numpy.py:70-141)
+#   dtype      dtype of the frame handed to processing(): remove_blacklv (:152-158) works in place, i.e. in THAT
+#              arithmetic.  'float32' is what the reference's datasets deliver for tif / png tiles
+#              (utils/dataset_utils.py:18-26 -> dataset.py:86-87), 'float64' what a DNG's uint16 / (2**bits-1)
+#              gives; default 'float64' (the round-1 cases).
+#   bits       if given, the case starts from 16-bit containers u16 = round(raw * (2**bits - 1)) and forms the frame
+#              exactly like the dataset does: np.array(u16, dtype=np.float32) / (2**bits - 1)
 STATIC_CASES = [
     dict(name='drone_default_chain', seed=0, shape=(2, 32, 32), kind='scene', camera='drone',
          debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
@@ -82,7 +88,60 @@ STATIC_CASES = [
          debayer='bilinear', sharpening='unsharp_masking', denoising='gaussian'),
     dict(name='drone_malvar_unsharp_median', seed=11, shape=(1, 24, 32), kind='scene', camera='drone',
          debayer='malvar2004', sharpening='unsharp_masking', denoising='median_denoising'),
+    # float32 frames: the reference's real call path; 'dark' frames sit next to the black level
+    dict(name='f32_drone_short_dark', seed=12, shape=(2, 32, 32), kind='dark', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='none', denoising='none'),
+    dict(name='f32_drone_short_scene', seed=13, shape=(1, 32, 48), kind='scene', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='none', denoising='none'),
+    dict(name='f32_drone_default_dark', seed=14, shape=(1, 32, 32), kind='dark', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='f32_drone_default_uniform', seed=15, shape=(2, 24, 40), kind='uniform', camera='drone',
+         dtype='float32', debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='f32_micro_default_scene', seed=16, shape=(1, 32, 32), kind='scene', camera='microscopy',
+         dtype='float32', debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='f32_drone_malvar_short_dark', seed=17, shape=(1, 24, 40), kind='dark', camera='drone',
+         dtype='float32', debayer='malvar2004', sharpening='none', denoising='none'),
+    dict(name='f32_drone_malvar_median_dark', seed=18, shape=(1, 32, 32), kind='dark', camera='drone',
+         dtype='float32', debayer='malvar2004', sharpening='sharpening_filter', denoising='median_denoising'),
+    dict(name='f32_drone_class_default_dark', seed=19, shape=(1, 32, 40), kind='dark', camera='drone',
+         dtype='float32', debayer='bilinear', sharpening='unsharp_masking', denoising='gaussian'),
+    dict(name='f32_drone_ragged_width', seed=20, shape=(1, 20, 38), kind='dark', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='f32_drone_ragged_width_short', seed=21, shape=(1, 20, 38), kind='dark', camera='drone',
+         dtype='float32', debayer='bilinear', sharpening='none', denoising='none'),
+    # frames sitting on the black level: float32 vs float64 remove_blacklv differ by ~2e-4 after the gamma
+    dict(name='f32_drone_short_at_black', seed=24, shape=(1, 32, 32), kind='at_black', camera='drone',
+         dtype='float32', debayer='bilinear', sharpening='none', denoising='none'),
+    dict(name='f32_drone_default_at_black', seed=25, shape=(1, 32, 40), kind='at_black', camera='drone',
+         dtype='float32', debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='f32_drone_malvar_at_black', seed=26, shape=(1, 24, 32), kind='at_black', camera='drone',
+         dtype='float32', debayer='malvar2004', sharpening='none', denoising='none'),
+    dict(name='f64_drone_short_at_black', seed=24, shape=(1, 32, 32), kind='at_black', camera='drone',
+         dtype='float64', debayer='bilinear', sharpening='none', denoising='none'),
+    # 16-bit containers normalised like dataset.py:86-87 (float32 division)
+    dict(name='u16_drone_short_dark', seed=22, shape=(2, 32, 32), kind='dark', camera='drone', dtype='float32',
+         bits=16, debayer='bilinear', sharpening='none', denoising='none'),
+    dict(name='u16_drone_default_scene_12bit', seed=23, shape=(1, 32, 48), kind='scene', camera='drone',
+         dtype='float32', bits=12, debayer='bilinear', sharpening='sharpening_filter',
+         denoising='gaussian_denoising'),
 ]
+
+
+def static_case_frames(case):
+    """(frames handed to processing(), 16-bit containers | None) of a static case."""
+    import numpy as np
+    from oracle import isp_oracle as orc
+    B, H, W = case['shape']
+    raw = orc.synth_raw(B, H, W, seed=case['seed'], kind=case['kind'])
+    dtype = np.dtype(case.get('dtype', 'float64'))
+    if case.get('bits'):
+        d = 2 ** case['bits'] - 1
+        u16 = np.clip(np.rint(raw.astype(np.float64) * d), 0, d).astype(np.uint16)
+        img = np.array(u16, dtype=np.float32)          # utils/dataset_utils.py:20-24
+        img = img / d                                  # dataset.py:87
+        assert img.dtype == np.float32
+        return img, u16
+    return raw.astype(dtype), None
 
 
 # adversarial auxiliary losses (utils/ssim.py, utils/base.py:342-358): img1 = reference-processor output,

@@ -107,8 +107,20 @@ def synth_raw(B, H, W, seed=0, kind='uniform'):
         u16 = rng.integers(0, 4096, (B, H, W))
         u16[:, : H // 2] = rng.integers(250, 262, (B, H // 2, W))   # ~ black level of Drone
         u16[:, :2, :] = 4095
-    else:
-        raise ValueError(kind)
+    elif kind == 'at_black':
+        # float32 frames sitting ON the black level: every value is float32(black_level[site]) + k float32 ulps,
+        # k in -3..3 (top quarter: the uniform distribution).  remove_blacklv in float32 (float32 frames, the
+        # reference's datasets) gives exact multiples of the ulp, in float64 it also keeps black_level -
+        # float32(black_level) ~ 3e-9 -- after x ** (1/2.2) that is 0 against ~2e-4 on the flat-zero pixels.
+        bl = np.asarray(DRONE_CAMERA_PARAMS[0], dtype=np.float32)
+        site = np.empty((H, W), dtype=np.float32)
+        site[0::2, 0::2], site[0::2, 1::2], site[1::2, 0::2], site[1::2, 1::2] = bl
+        k = rng.integers(-3, 4, (B, H, W)).astype(np.float32)
+        k[:, H // 2:, : W // 2] = 0                      # a flat patch exactly at the black level
+        raw = (site[None] + k * np.spacing(site)[None]).astype(np.float32)
+        top = rng.integers(0, 4096, (B, H // 4, W)).astype(np.float32) / np.float32(4095)
+        raw[:, : H // 4] = top
+        return raw
     return (u16.astype(np.float32) / np.float32(4095)).astype(np.float32)
 
 
@@ -648,11 +660,16 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
 def static_batch(raw, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
                  denoising='gaussian_denoising', gamma=2.2):
     """RawProcessingPipeline.__call__ (pipeline_numpy.py:55-67) over a batch: (B,H,W) -> (B,3,H,W)
-    float32.  The reference receives float64 frames (uint16 / (2**bits-1), dataset.py:87)."""
+    float32.  Frames are processed in the dtype they come in, like the reference: remove_blacklv works in
+    place, so float32 frames (load_image's np.float32 array / (2**bits-1), utils/dataset_utils.py:18-26,
+    dataset.py:86-87) get a float32 subtraction of the float32-rounded black level, float64 frames (a DNG's
+    uint16 / (2**bits-1)) a float64 one; everything from the demosaic on is float64."""
     bl, wb, ccm = camera_parameters
     out = []
-    for img in np.asarray(raw):
-        o = processing(img.astype(np.float64).copy(), bl, wb, ccm, debayer=debayer,
+    raw = np.asarray(raw)
+    assert raw.dtype in (np.float32, np.float64), raw.dtype
+    for img in raw:
+        o = processing(img.copy(), bl, wb, ccm, debayer=debayer,
                        sharpening=sharpening, denoising=denoising, gamma=gamma)
         out.append(o.transpose(2, 0, 1).astype(np.float32))
     return np.stack(out)

@@ -99,6 +99,11 @@ _SIGNATURES = {
     'r2l_stage_point': (ctypes.c_int, [ctypes.c_int] + [_c_float_p] * 7 + [ctypes.c_void_p, ctypes.c_size_t] +
                         [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'r2l_static_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 6),
+    'r2l_static_workspace_bytes_f64': (ctypes.c_size_t, [ctypes.c_int] * 6),
+    'r2l_static_fwd_f64': (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.c_void_p]),
     'r2l_static_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,

@@ -163,27 +163,25 @@ R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L
 #ifndef R2L_STREAM_OCC_BILINEAR
 #define R2L_STREAM_OCC_BILINEAR 3
 #endif
-#define R2L_STREAM_BLOCK(name, DEB, U16, LUMA)                                                           \
-  R2L_BLOCKFN void name(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {                  \
-    r2l_static_stream_block<DEB, U16, LUMA>(sa, bid, nblk, lds);                                         \
-  }
-R2L_STREAM_BLOCK(r2l_stream_block_bilinear, 0, false, false)
-R2L_STREAM_BLOCK(r2l_stream_block_malvar, 1, false, false)
-R2L_STREAM_BLOCK(r2l_stream_block_bilinear_u16, 0, true, false)
-R2L_STREAM_BLOCK(r2l_stream_block_malvar_u16, 1, true, false)
-R2L_STREAM_BLOCK(r2l_stream_block_bilinear_luma, 0, false, true)
-R2L_STREAM_BLOCK(r2l_stream_block_malvar_luma, 1, false, true)
-R2L_STREAM_BLOCK(r2l_stream_block_bilinear_luma_u16, 0, true, true)
-R2L_STREAM_BLOCK(r2l_stream_block_malvar_luma_u16, 1, true, true)
-R2L_KERNEL_NT(r2l_launch_static_luma_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
-R2L_KERNEL_NT(r2l_launch_static_luma_malvar, R2LStaticStreamArgs, r2l_stream_block_malvar_luma, R2L_STREAM_NT, 3)
-R2L_KERNEL_NT(r2l_launch_static_luma_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_luma_u16, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
-R2L_KERNEL_NT(r2l_launch_static_luma_malvar_u16, R2LStaticStreamArgs, r2l_stream_block_malvar_luma_u16, R2L_STREAM_NT, 3)
+#define R2L_STREAM_KERNEL(name, DEB, RAWK, LUMA, OCC)                                                    \
+  R2L_BLOCKFN void name##_block(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {          \
+    r2l_static_stream_block<DEB, RAWK, LUMA>(sa, bid, nblk, lds);                                        \
+  }                                                                                                      \
+  R2L_KERNEL_NT(name, R2LStaticStreamArgs, name##_block, R2L_STREAM_NT, OCC)
+// demosaic x frame container (float32 | 16-bit | float64) x {whole short chain, luma-plane passes}
+R2L_STREAM_KERNEL(r2l_launch_static_stream_bilinear, 0, R2L_RAW_F32, false, R2L_STREAM_OCC_BILINEAR)
+R2L_STREAM_KERNEL(r2l_launch_static_stream_malvar, 1, R2L_RAW_F32, false, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_stream_bilinear_u16, 0, R2L_RAW_U16, false, R2L_STREAM_OCC_BILINEAR)
+R2L_STREAM_KERNEL(r2l_launch_static_stream_malvar_u16, 1, R2L_RAW_U16, false, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_stream_bilinear_f64, 0, R2L_RAW_F64, false, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_stream_malvar_f64, 1, R2L_RAW_F64, false, 2)
+R2L_STREAM_KERNEL(r2l_launch_static_luma_bilinear, 0, R2L_RAW_F32, true, R2L_STREAM_OCC_BILINEAR)
+R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar, 1, R2L_RAW_F32, true, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_luma_bilinear_u16, 0, R2L_RAW_U16, true, R2L_STREAM_OCC_BILINEAR)
+R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_u16, 1, R2L_RAW_U16, true, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_luma_bilinear_f64, 0, R2L_RAW_F64, true, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_f64, 1, R2L_RAW_F64, true, 2)
 R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
-R2L_KERNEL_NT(r2l_launch_static_stream_bilinear, R2LStaticStreamArgs, r2l_stream_block_bilinear, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
-R2L_KERNEL_NT(r2l_launch_static_stream_malvar, R2LStaticStreamArgs, r2l_stream_block_malvar, R2L_STREAM_NT, 3)
-R2L_KERNEL_NT(r2l_launch_static_stream_bilinear_u16, R2LStaticStreamArgs, r2l_stream_block_bilinear_u16, R2L_STREAM_NT, R2L_STREAM_OCC_BILINEAR)
-R2L_KERNEL_NT(r2l_launch_static_stream_malvar_u16, R2LStaticStreamArgs, r2l_stream_block_malvar_u16, R2L_STREAM_NT, 3)
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
 
@@ -322,7 +320,8 @@ size_t r2l_isp_workspace_bytes(int B, int H, int W) {
 }
 
 static int r2l_check_raw(const R2LRaw& raw, int W, const char* who) {
-  if (!raw.f32 && !raw.u16) return r2l_fail(-1, std::string(who) + ": null pointer");
+  if (!raw.f32 && !raw.u16 && !raw.f64) return r2l_fail(-1, std::string(who) + ": null pointer");
+  if (raw.f64 && (W & 3)) return r2l_fail(-4, std::string(who) + ": float64 frames need W % 4 == 0");
   if (raw.u16 && !(raw.denom >= 1.f)) return r2l_fail(-1, std::string(who) + ": denom must be >= 1 (2**bits - 1)");
   if (raw.u16 && (W & 3)) return r2l_fail(-1, std::string(who) + ": 16-bit frames need W % 4 == 0");
   return 0;
@@ -546,9 +545,10 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
 
 // chains the single-launch kernels cover: the short chain (any demosaic) and bilinear + sharpening_filter +
 // gaussian_denoising; everything else runs as luma-plane passes and needs two float64 planes of workspace
-static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoising) {
+static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoising, bool f64_frames = false) {
   if (sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE) return true;
   (void)W;
+  if (f64_frames) return false;  // the tile kernel of the default chain stages float32 frames in LDS
   return debayer == R2L_DEBAYER_BILINEAR && sharpening == R2L_SHARPEN_FILTER && denoising == R2L_DENOISE_GAUSSIAN;
 }
 static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W, int debayer) {
@@ -585,7 +585,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
   R2LStaticArgs a;
   r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma);
   const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
-  if (!r2l_static_is_fused(W, debayer, sharpening, denoising)) {
+  if (!r2l_static_is_fused(W, debayer, sharpening, denoising, raw.f64 != nullptr)) {
     // luma-plane passes: raw -> Y | sharpen | denoise | raw + Y'' -> RGB
     if (W & 3) return r2l_fail(-4, "r2l_static_fwd: this chain runs as plane passes, which need W % 4 == 0");
     const size_t plane_bytes = sizeof(double) * (size_t)B * H * W;
@@ -605,6 +605,9 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
       if (raw.u16)
         return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_luma_malvar_u16(x, sgrid, stream)
                                                  : r2l_launch_static_luma_bilinear_u16(x, sgrid, stream);
+      if (raw.f64)
+        return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_luma_malvar_f64(x, sgrid, stream)
+                                                 : r2l_launch_static_luma_bilinear_f64(x, sgrid, stream);
       return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_luma_malvar(x, sgrid, stream)
                                                : r2l_launch_static_luma_bilinear(x, sgrid, stream);
     };
@@ -646,7 +649,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC_FULL", 256));
     return r2l_launch_static_full(a, grid, stream);
   }
-  if ((W & 3) == 0 && !r2l_env_int("R2L_STATIC_TILED", 0)) {
+  if ((W & 3) == 0 && (raw.f64 || !r2l_env_int("R2L_STATIC_TILED", 0))) {
     R2LStaticStreamArgs sa;
     sa.s = a;
     sa.luma_out = nullptr;
@@ -660,6 +663,9 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     if (raw.u16)
       return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_stream_malvar_u16(sa, grid, stream)
                                                : r2l_launch_static_stream_bilinear_u16(sa, grid, stream);
+    if (raw.f64)
+      return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_stream_malvar_f64(sa, grid, stream)
+                                               : r2l_launch_static_stream_bilinear_f64(sa, grid, stream);
     return debayer == R2L_DEBAYER_MALVAR2004 ? r2l_launch_static_stream_malvar(sa, grid, stream)
                                              : r2l_launch_static_stream_bilinear(sa, grid, stream);
   }
@@ -733,6 +739,16 @@ int r2l_raw2rgb_fwd_u16(const unsigned short* raw, float denom, const float* bla
 size_t r2l_static_workspace_bytes(int B, int H, int W, int debayer, int sharpening, int denoising) {
   if (B < 1 || H < 1 || W < 1 || r2l_static_is_fused(W, debayer, sharpening, denoising)) return 0;
   return 2 * sizeof(double) * (size_t)B * H * W;
+}
+size_t r2l_static_workspace_bytes_f64(int B, int H, int W, int debayer, int sharpening, int denoising) {
+  if (B < 1 || H < 1 || W < 1 || r2l_static_is_fused(W, debayer, sharpening, denoising, true)) return 0;
+  return 2 * sizeof(double) * (size_t)B * H * W;
+}
+int r2l_static_fwd_f64(const double* raw, float* out, int B, int H, int W, const double* camera_host,
+                       int debayer, int sharpening, int denoising, double gamma, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  return r2l_static_fwd_impl(r2l_raw_f64(raw), out, B, H, W, camera_host, debayer, sharpening, denoising, gamma,
+                             workspace, workspace_bytes, stream);
 }
 int r2l_static_fwd(const float* raw, float* out, int B, int H, int W, const double* camera_host,
                    int debayer, int sharpening, int denoising, double gamma, void* workspace,

@@ -218,21 +218,35 @@ R2L_HD double r2l_load_coherent(const double* p) {
 // of 4) and apply that division when a value enters LDS / the register window: q0 = u * (1/d), one residual
 // step e = fma(-q0, d, u), q = fma(e, 1/d, q0) -- equal to the correctly rounded float32 quotient u / d for
 // every 16-bit u and d = 65535, 4095, 1023, 255 (checked exhaustively by the tests).
+// A third container, float64 frames, exists for the static chains only (a float64 ndarray handed to
+// processing(), e.g. a DNG's uint16 / (2**bits - 1), stays float64 through remove_blacklv).
+enum { R2L_RAW_F32 = 0, R2L_RAW_U16 = 1, R2L_RAW_F64 = 2 };
 struct R2LRaw {
   const float* f32;
   const unsigned short* u16;
+  const double* f64;
   float denom, rdenom;
 };
 R2L_HOSTDEV R2LRaw r2l_raw_f32(const float* p) {
   R2LRaw r;
   r.f32 = p;
   r.u16 = nullptr;
+  r.f64 = nullptr;
+  r.denom = r.rdenom = 1.f;
+  return r;
+}
+R2L_HOSTDEV R2LRaw r2l_raw_f64(const double* p) {
+  R2LRaw r;
+  r.f32 = nullptr;
+  r.u16 = nullptr;
+  r.f64 = p;
   r.denom = r.rdenom = 1.f;
   return r;
 }
 R2L_HOSTDEV R2LRaw r2l_raw_u16(const unsigned short* p, float denom) {
   R2LRaw r;
   r.f32 = nullptr;
+  r.f64 = nullptr;
   r.u16 = p;
   r.denom = denom;
   r.rdenom = 1.0f / denom;

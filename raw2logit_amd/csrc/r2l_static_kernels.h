@@ -7,9 +7,12 @@
 //   matrix (:165-167) -> [sharpening_filter (:180-191): rgb2yuv, convolve2d(Y, K, 'same', fill 0),
 //   yuv2rgb] -> [gaussian_denoising (:203-209): rgb2yuv, ndimage.gaussian_filter(Y, 0.5) (5 taps,
 //   symmetric), yuv2rgb] -> clip[0,1] (:138) -> x ** (1/gamma) (:241-244).
-// The reference computes all of this in float64 (dataset.py:87 hands it float64 frames); x**(1/gamma)
-// has an unbounded derivative at 0, so float32 round-off in the linear part would break the 1e-5
-// parity bar near black.  The linear part therefore runs in float64 here as well (MI355X: half the
+// remove_blacklv works in place in the dtype of the frame it is handed -- float32 for every tif / png tile
+// (utils/dataset_utils.py:18-26, dataset.py:86-87), float64 for a DNG's uint16 / (2**bits - 1) -- and from
+// the demosaic on everything is float64.  x**(1/gamma) has an unbounded derivative at 0, so float32 round-off
+// in the linear part would break the 1e-5 parity bar near black.  The kernels therefore subtract the black
+// level in the frames' own arithmetic (float32 frames and 16-bit containers: float32-rounded black level,
+// float32 subtraction; float64 frames: float64) and run the rest of the linear part in float64 as well (MI355X: half the
 // f32 vector rate, still far below the HBM time); only log2/exp2 run in float32, whose RELATIVE error
 // is what matters for the power law.
 //
@@ -38,7 +41,8 @@ struct R2LStaticArgs {
   float* out;
   int B, H, W;
   int debayer, full, sharpen, denoise;
-  double bl[4];
+  double bl[4];   // black level of float64 frames
+  float blf[4];   // ... of float32 frames / 16-bit containers: rounded to float32, subtracted in float32
   double wbccm[9];  // colour_matrix * diag(white_balance): RGB_cc = wbccm * RGB_demosaic
   double T[9];      // yuv_from_rgb * wbccm
   double M2[9];     // rgb_from_yuv = inv(yuv_from_rgb)
@@ -79,6 +83,7 @@ static inline void r2l_static_setup(R2LStaticArgs& a, const R2LRaw& raw, float* 
   a.denoise = denoising;
   a.full = (sharpening != R2L_SHARPEN_NONE) || (denoising != R2L_DENOISE_NONE);
   for (int s = 0; s < 4; ++s) a.bl[s] = cam[s];
+  for (int s = 0; s < 4; ++s) a.blf[s] = (float)cam[s];
   for (int k = 0; k < 3; ++k)
     for (int c = 0; c < 3; ++c) a.wbccm[k * 3 + c] = cam[7 + k * 3 + c] * cam[4 + c];
   for (int k = 0; k < 3; ++k)
@@ -292,14 +297,14 @@ R2L_HD void r2l_static_window(const float* V, int fy0, int fx0, int gy0, int gx0
     const float* r = V + (fy0 - HALO + i) * G::FS + fx0 - HALO;
     R2L_PRAGMA_UNROLL
     for (int j = 0; j < NC; ++j) {
-      double bl;
+      float bl;  // the tile kernels serve float32 frames / 16-bit containers: float32 black level arithmetic
       if (BORDER) {
-        const double b0 = rp[i] ? a.bl[2] : a.bl[0], b1 = rp[i] ? a.bl[3] : a.bl[1];
+        const float b0 = rp[i] ? a.blf[2] : a.blf[0], b1 = rp[i] ? a.blf[3] : a.blf[1];
         bl = cp[j] ? b1 : b0;
       } else {
-        bl = a.bl[(((PAR0 + i + HALO) & 1) << 1) | ((PAR0 + j + HALO) & 1)];
+        bl = a.blf[(((PAR0 + i + HALO) & 1) << 1) | ((PAR0 + j + HALO) & 1)];
       }
-      w[i][j] = (double)r[j] - bl;
+      w[i][j] = (double)(r[j] - bl);
     }
   }
 }

@@ -25,21 +25,54 @@ struct R2LStaticStreamArgs {
 
 // raw values of columns x0-2 .. x0+5 of source row `ys` (symmetric extension at the image edges); with 16-bit
 // containers the undecoded bits (v[0] = left pair, v[1..2] = the 4 centre values, v[3] = right pair), decoded
-// when the row enters the window so that the fetch stays a fire-and-forget load
-struct R2LRowStage {
+// when the row enters the window so that the fetch stays a fire-and-forget load.  RAWK = container of the
+// frames: R2L_RAW_F32 | R2L_RAW_U16 | R2L_RAW_F64 (float64 frames keep their float64 values in the stage)
+template <int RAWK>
+struct R2LRowStageT {
   float v[8];
+  int ys;
+};
+template <>
+struct R2LRowStageT<R2L_RAW_F64> {
+  double v[8];
   int ys;
 };
 // LANES: the neighbour columns come from the neighbouring lanes of the wavefront (DPP wave shifts) when the row
 // enters the window; only lane 0 / lane 63 fetch theirs from the neighbouring strip (one load instruction for
 // both, staged in v[0..1] resp. v[0]).  Otherwise every lane loads its own neighbour pairs (hits in L1).  On the
 // bilinear chain (1 neighbour each side) the lane form is 3 % faster, on Malvar (2 each side) 9 % slower.
-template <bool U16, bool LANES>
+template <int RAWK, bool LANES>
 R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, size_t img0, int ys, int x0, bool le, bool re,
-                                 R2LRowStage& st) {
+                                 R2LRowStageT<RAWK>& st) {
   const size_t e = img0 + (size_t)ys * a.W + x0;
-  float* v = st.v;
   st.ys = ys;
+  if constexpr (RAWK == R2L_RAW_F64) {
+    const double* r = a.raw.f64 + e;
+    double* v = st.v;
+    const r2l_d2 c0 = *(const r2l_d2*)r, c1 = *(const r2l_d2*)(r + 2);
+    v[2] = c0.x;
+    v[3] = c0.y;
+    v[4] = c1.x;
+    v[5] = c1.y;
+    if (le) {  // x = -1 -> 0, x = -2 -> 1
+      v[0] = c0.y;
+      v[1] = c0.x;
+    } else {
+      const r2l_d2 l = *(const r2l_d2*)(r - 2);
+      v[0] = l.x;
+      v[1] = l.y;
+    }
+    if (re) {  // x = W -> W-1, x = W+1 -> W-2
+      v[6] = c1.y;
+      v[7] = c1.x;
+    } else {
+      const r2l_d2 q = *(const r2l_d2*)(r + 4);
+      v[6] = q.x;
+      v[7] = q.y;
+    }
+  } else {
+  constexpr bool U16 = RAWK == R2L_RAW_U16;
+  float* v = st.v;
   if (U16) {
     const unsigned short* r = a.raw.u16 + e;
     const r2l_f2 c = *(const r2l_f2*)r;
@@ -87,11 +120,29 @@ R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, size_t img0, int ys, in
     v[6] = q.x;
     v[7] = q.y;
   }
+  }
 }
-// staged row -> 8 black-level-corrected float64 values (the black level follows the SOURCE site)
-template <bool U16, bool LANES>
-R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStage& st, bool le, bool re,
+// staged row -> 8 black-level-corrected float64 values (the black level follows the SOURCE site).  The
+// subtraction happens in the arithmetic of the frames' dtype, like the reference's in-place remove_blacklv
+// (pipeline_numpy.py:152-158): float32 frames (and 16-bit containers, which the datasets normalise in float32,
+// dataset.py:86-87) subtract the float32-rounded black level in float32; float64 frames subtract in float64.
+template <int RAWK, bool LANES>
+R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStageT<RAWK>& st, bool le, bool re,
                                    double dst[8]) {
+  const int ys = st.ys;
+  if constexpr (RAWK == R2L_RAW_F64) {
+    const double be = (ys & 1) ? a.bl[2] : a.bl[0], bo = (ys & 1) ? a.bl[3] : a.bl[1];
+    // source column parities: x0-2 even, x0-1 odd, ..., except the mirrored ones (1, 0 | W-1, W-2)
+    dst[0] = st.v[0] - (le ? bo : be);
+    dst[1] = st.v[1] - (le ? be : bo);
+    dst[2] = st.v[2] - be;
+    dst[3] = st.v[3] - bo;
+    dst[4] = st.v[4] - be;
+    dst[5] = st.v[5] - bo;
+    dst[6] = st.v[6] - (re ? bo : be);
+    dst[7] = st.v[7] - (re ? be : bo);
+  } else {
+  constexpr bool U16 = RAWK == R2L_RAW_U16;
   float v[8];
   if (U16) {
     const unsigned c0 = r2l_f2u(st.v[1]), c1 = r2l_f2u(st.v[2]);
@@ -130,17 +181,16 @@ R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStage& st
       }
     }
   }
-  const int ys = st.ys;
-  const double be = (ys & 1) ? a.bl[2] : a.bl[0], bo = (ys & 1) ? a.bl[3] : a.bl[1];
-  // source column parities: x0-2 even, x0-1 odd, ..., except the mirrored ones (1, 0 | W-1, W-2)
-  dst[0] = (double)v[0] - (le ? bo : be);
-  dst[1] = (double)v[1] - (le ? be : bo);
-  dst[2] = (double)v[2] - be;
-  dst[3] = (double)v[3] - bo;
-  dst[4] = (double)v[4] - be;
-  dst[5] = (double)v[5] - bo;
-  dst[6] = (double)v[6] - (re ? bo : be);
-  dst[7] = (double)v[7] - (re ? be : bo);
+  const float be = (ys & 1) ? a.blf[2] : a.blf[0], bo = (ys & 1) ? a.blf[3] : a.blf[1];
+  dst[0] = (double)(v[0] - (le ? bo : be));
+  dst[1] = (double)(v[1] - (le ? be : bo));
+  dst[2] = (double)(v[2] - be);
+  dst[3] = (double)(v[3] - bo);
+  dst[4] = (double)(v[4] - be);
+  dst[5] = (double)(v[5] - bo);
+  dst[6] = (double)(v[6] - (re ? bo : be));
+  dst[7] = (double)(v[7] - (re ? be : bo));
+  }
 }
 
 // WB * CCM, clip, gamma and the three 16-byte stores of one output row (4 pixels of this lane)
@@ -304,11 +354,11 @@ R2L_HD void r2l_stream_malvar_row(const double* w0, const double* w1, const doub
 #define R2L_STREAM_PF_MALVAR 2
 #endif
 // one lane's work item: image b, column strip seg (256 columns), row band
-template <int DEB, bool U16, bool LUMA>
+template <int DEB, int RAWK, bool LUMA>
 R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int lane) {
   const R2LStaticArgs& a = sa.s;
   constexpr int HALO = DEB ? 2 : 1, NR = 2 * HALO + 1;
-  constexpr bool LANES = (DEB == 0) && R2L_HAVE_LANE_SHIFTS;
+  constexpr bool LANES = (DEB == 0) && R2L_HAVE_LANE_SHIFTS && RAWK != R2L_RAW_F64;
   const int seg = item % sa.nseg, r = item / sa.nseg;
   const int band = r % sa.nband, b = r / sa.nband;
   const int x0 = seg * 256 + 4 * lane;
@@ -322,32 +372,32 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   double win[NR][8];
   int par[NR];  // source row parity of each window slot
   // warm-up: slots 0..NR-2 hold rows y0-HALO .. y0+HALO-1
-  R2LRowStage st;
+  R2LRowStageT<RAWK> st;
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < NR - 1; ++i) {
     const int ys = r2l_symmetric(y0 - HALO + i, a.H);
-    r2l_stream_fetch_row<U16, LANES>(a, img, ys, x0, le, re, st);
-    r2l_stream_convert_row<U16, LANES>(a, st, le, re, win[i]);
+    r2l_stream_fetch_row<RAWK, LANES>(a, img, ys, x0, le, re, st);
+    r2l_stream_convert_row<RAWK, LANES>(a, st, le, re, win[i]);
     par[i] = ys & 1;
   }
   // software pipeline, PF rows deep: the rows needed by the next PF output rows are in flight while this one
   // is computed (pf[i] = row y+HALO+i).  At 3-4 wavefronts per SIMD (the float64 window costs the registers)
   // the bytes in flight come from the depth, not from the occupancy.
-  constexpr int PF = DEB ? R2L_STREAM_PF_MALVAR : R2L_STREAM_PF_BILINEAR;
-  R2LRowStage pf[PF];
+  constexpr int PF = (DEB || RAWK == R2L_RAW_F64) ? R2L_STREAM_PF_MALVAR : R2L_STREAM_PF_BILINEAR;
+  R2LRowStageT<RAWK> pf[PF];
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < PF; ++i) r2l_stream_fetch_row<U16, LANES>(a, img, r2l_symmetric(y0 + HALO + i, a.H), x0, le, re, pf[i]);
+  for (int i = 0; i < PF; ++i) r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(y0 + HALO + i, a.H), x0, le, re, pf[i]);
   for (int yb = y0; yb < y1; yb += NR) {
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < NR; ++k) {  // unrolled by the window depth: slot indices are compile-time
       const int y = yb + k;
       if (y < y1) {
         // newest row y + HALO (fetched one iteration ago) goes to slot (k + NR - 1) % NR
-        r2l_stream_convert_row<U16, LANES>(a, pf[0], le, re, win[(k + NR - 1) % NR]);
+        r2l_stream_convert_row<RAWK, LANES>(a, pf[0], le, re, win[(k + NR - 1) % NR]);
         par[(k + NR - 1) % NR] = pf[0].ys & 1;
         R2L_PRAGMA_UNROLL
         for (int i = 0; i + 1 < PF; ++i) pf[i] = pf[i + 1];
-        if (y + PF < y1) r2l_stream_fetch_row<U16, LANES>(a, img, r2l_symmetric(y + PF + HALO, a.H), x0, le, re, pf[PF - 1]);
+        if (y + PF < y1) r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(y + PF + HALO, a.H), x0, le, re, pf[PF - 1]);
         double d[4][3];
         if (DEB == 0) {
           // interior rows: closed-form sums (left / right image edge included); the first / last image row sees
@@ -381,12 +431,12 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
 }
 
 #define R2L_STREAM_NT 256  // 4 independent wavefronts per workgroup
-template <int DEB, bool U16, bool LUMA>
+template <int DEB, int RAWK, bool LUMA>
 R2L_BLOCKFN void r2l_static_stream_block(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {
   (void)lds;
   (void)nblk;
   R2L_PHASE_BEGIN_N(R2L_STREAM_NT)
   const int item = bid * (R2L_STREAM_NT / 64) + (tid >> 6);  // one work item per wavefront
-  if (item < sa.nitems) r2l_static_stream_item<DEB, U16, LUMA>(sa, item, tid & 63);
+  if (item < sa.nitems) r2l_static_stream_item<DEB, RAWK, LUMA>(sa, item, tid & 63);
   R2L_PHASE_END
 }

@@ -292,13 +292,25 @@ _DENOISE = {'gaussian_denoising': 1, 'median_denoising': 2}
 
 def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
                     denoising='gaussian_denoising', gamma=2.2, bits=16):
-    """(B,H,W) float32 raw on the GPU -> (B,3,H,W) float32, numpy semantics of the reference.
+    """(B,H,W) raw on the GPU -> (B,3,H,W) float32, numpy semantics of the reference.
+
+    The black level is removed in the arithmetic of the frames' dtype, as the reference's in-place
+    remove_blacklv does (pipeline_numpy.py:152-158): float32 frames -- what its datasets deliver
+    (utils/dataset_utils.py:18-26, dataset.py:86-87) -- and 16-bit containers (divided by 2**bits - 1 in
+    float32 like dataset.py:87) subtract the float32-rounded black level in float32; float64 frames (a DNG's
+    uint16 / (2**bits - 1)) stay float64.  Everything after the demosaic is float64 in both cases.
 
     Like the reference's if-chains (pipeline_numpy.py:110-122) a sharpening / denoising string that
     names no algorithm means "skip that stage"; algorithms the reference has but this library does not
     build (menon2007, unsharp_masking, median/fft/... denoising) raise instead of silently differing."""
-    raw, denom = _raw_arg(raw, bits)
     assert raw.ndim == 3, f"needs dims (B, H, W), got {raw.shape}"
+    f64 = raw.dtype == torch.float64
+    if f64:
+        if raw.shape[-1] % 4:
+            raise ValueError('float64 frames need W % 4 == 0')
+        raw, denom = (raw if raw.is_contiguous() else raw.contiguous()), None
+    else:
+        raw, denom = _raw_arg(raw, bits)
     known_sharp = {'sharpening_filter', 'unsharp_masking'}
     known_den = {'median_denoising', 'gaussian_denoising', 'fft_denoising', 'tv_chambolle', 'tv_bregman',
                  'bilateral'}
@@ -314,10 +326,12 @@ def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='shar
     lib, stream = _lib.library_for(raw)
     out = torch.empty((B, 3, H, W), dtype=torch.float32, device=raw.device)
     codes = (_DEBAYER[debayer], _SHARPEN.get(sharpening, 0), _DENOISE.get(denoising, 0))
-    nws = lib.r2l_static_workspace_bytes(B, H, W, *codes)      # 0 for the single-launch chains
-    ws = torch.empty(nws, dtype=torch.uint8, device=raw.device) if nws else None
+    nws = (lib.r2l_static_workspace_bytes_f64 if f64 else lib.r2l_static_workspace_bytes)(B, H, W, *codes)
+    ws = torch.empty(nws, dtype=torch.uint8, device=raw.device) if nws else None      # 0: single-launch chains
     tail = (ptr(out), B, H, W, cam, *codes, float(gamma), ptr(ws), nws, stream)
-    if denom is None:
+    if f64:
+        lib.check(lib.r2l_static_fwd_f64(ptr(raw), *tail), 'r2l_static_fwd_f64')
+    elif denom is None:
         lib.check(lib.r2l_static_fwd(ptr(raw), *tail), 'r2l_static_fwd')
     else:
         lib.check(lib.r2l_static_fwd_u16(ptr(raw), denom, *tail), 'r2l_static_fwd_u16')

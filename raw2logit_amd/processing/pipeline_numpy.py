@@ -28,15 +28,20 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
                weight_chambolle=0.01, weight_bregman=100, sigma_bilateral=0.6, gamma=2.2, bits=16):
     """reference :70-141.  img (H,W) float ndarray -> (H,W,3) float64 ndarray.
 
-    As in the reference, `img` has its black level removed IN PLACE (:152-158) and option strings that
-    name no algorithm skip their stage (the signature default denoising="median_filter" is one)."""
+    As in the reference, `img` has its black level removed IN PLACE (:152-158), in the array's own dtype:
+    a float32 frame (what the reference's datasets hand over, dataset.py:86-87; docstring :57) gets the
+    float32 subtraction, a float64 frame the float64 one -- on the device exactly as in the caller's array.
+    Option strings that name no algorithm skip their stage (the signature default denoising="median_filter"
+    is one)."""
     if gaussian_sigma != 0.5 and denoising == 'gaussian_denoising':
         raise NotImplementedError('only gaussian_sigma=0.5 (the reference default) is built')
     if median_kernel_size != 3 and denoising == 'median_denoising':
         raise NotImplementedError('only median_kernel_size=3 (the reference default) is built')
     if (sharp_radius != 1.0 or sharp_amount != 1.0) and sharpening == 'unsharp_masking':
         raise NotImplementedError('only sharp_radius=1.0, sharp_amount=1.0 (the reference defaults) are built')
-    raw = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None].to(_device())
+    if not (isinstance(img, np.ndarray) and img.dtype in (np.float32, np.float64)):
+        raise TypeError('processing() takes a float32 or float64 ndarray (dataset.py:86-87 delivers float32)')
+    raw = torch.from_numpy(np.ascontiguousarray(img))[None].to(_device())
     out = F_.static_pipeline(raw, (black_level, white_balance, colour_matrix), debayer=debayer,
                              sharpening=sharpening, denoising=denoising, gamma=gamma)
     img[0::2, 0::2] -= black_level[0]      # side effect of remove_blacklv on the caller's array

@@ -45,3 +45,25 @@ def golden():
     d = os.path.join(REPO, 'tests', 'golden')
     return {n: np.load(os.path.join(d, n + '.npz'), allow_pickle=False)
             for n in ('param_cases', 'raw2rgb', 'static_cases', 'harness', 'aux_losses')}
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """achieved error of every parity check next to its limit (tests/parity_checks.py: report())"""
+    pc = sys.modules.get('parity_checks')
+    if pc is None:
+        return
+    log = {}
+    for what, err, tol in pc.ERROR_LOG:
+        if what not in log or err / max(tol, 1e-300) > log[what][0] / max(log[what][1], 1e-300):
+            log[what] = (err, tol)
+    if not log:
+        return
+    tr = terminalreporter
+    tr.section('parity: achieved max|err| vs limit')
+    for what, (err, tol) in sorted(log.items(), key=lambda kv: -kv[1][0] / max(kv[1][1], 1e-300)):
+        tr.write_line(f'{what:72s} {err:10.3e} / {tol:9.3e}  {100.0 * err / tol if tol > 0 else 0.0:6.1f} %')
+    out = os.environ.get('R2L_PARITY_LOG')
+    if out:
+        with open(out, 'w') as f:
+            for what, (err, tol) in sorted(log.items()):
+                f.write(f'{what}\t{err:.6e}\t{tol:.6e}\n')

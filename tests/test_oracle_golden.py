@@ -103,14 +103,23 @@ def test_raw2rgb_oracle_matches_reference(golden):
 
 @pytest.mark.parametrize('case', STATIC_CASES, ids=[c['name'] for c in STATIC_CASES])
 def test_static_oracle_matches_reference(case, golden):
+    from oracle.golden_cases import static_case_frames
     g = golden['static_cases']
-    B, H, W = case['shape']
-    raw = orc.synth_raw(B, H, W, seed=case['seed'], kind=case['kind'])
+    raw, u16 = static_case_frames(case)          # in the dtype the reference was handed (float32 | float64)
+    assert raw.dtype == g[case['name'] + '/raw'].dtype == np.dtype(case.get('dtype', 'float64'))
     assert np.array_equal(raw, g[case['name'] + '/raw'])
-    out = np.stack([orc.processing(img.astype(np.float64).copy(), *orc.CAMERAS[case['camera']],
+    if u16 is not None:
+        assert np.array_equal(u16, g[case['name'] + '/u16'])
+    out = np.stack([orc.processing(img.copy(), *orc.CAMERAS[case['camera']],
                                    debayer=case['debayer'], sharpening=case['sharpening'],
                                    denoising=case['denoising']) for img in raw])
     np.testing.assert_allclose(out, g[case['name'] + '/out_hwc_f64'], rtol=0, atol=1e-12)
+    if case['kind'] == 'at_black':
+        # the fixture can tell the two black-level arithmetics apart (frames sitting on the black level)
+        other = np.float64 if raw.dtype == np.float32 else np.float32
+        wrong = np.stack([orc.processing(img.astype(other), *orc.CAMERAS[case['camera']], debayer=case['debayer'],
+                                         sharpening=case['sharpening'], denoising=case['denoising']) for img in raw])
+        assert np.abs(wrong - g[case['name'] + '/out_hwc_f64']).max() > 1e-4
     chw = orc.static_batch(raw[:1], orc.CAMERAS[case['camera']], case['debayer'], case['sharpening'],
                            case['denoising'])[0]
     np.testing.assert_allclose(chw, g[case['name'] + '/pipeline_chw_f32'], rtol=0, atol=1e-7)
