@@ -2,7 +2,9 @@
 """bench.py -- ISP Mpix/s (fwd+bwd) of the fused parametrized pipeline on 512x512 raw batches.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    (N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks are already there (WORLD_SIZE
+    set); started plainly, `python bench.py --gpus N` launches the N ranks itself -- as child processes of a
+    parent that never touches the GPU -- and relays rank 0's JSON line.)
 
 Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): ParametrizedProcessing, Drone camera
 parameters, batch_norm_output=True in train mode, 64 x 512 x 512 synthetic 12-bit RGGB frames PER GPU
@@ -14,13 +16,20 @@ The JSON line also carries
   roofline      the dominant kernel's algorithmic HBM bytes / its average duration (HIP events on the
                 launch stream, collected by the library's timing hooks in a second, instrumented pass of
                 the same K steps) against the 8 TB/s HBM3E peak;
-  cpu_baseline  the numpy oracle (a port of the reference's pipeline_torch.py forward + backward) timed on
-                the host on a bounded sample of the same workload (rank 0, N == 1 only).
+  static_c3     BASELINE config 3 (the north star's >= 70 % target): the fused static chain demosaic -> WB -> CCM
+                -> clip -> gamma on 256x1024x1024 and 1024x512x512 frames, per-launch HIP-event time and fraction
+                of the HBM peak at 16 algorithmic B/px; plus the train.py default static chain (N == 1 only);
+  cpu_baseline  SURVEY.md section 8d: the numpy restatement of the reference's pipeline_numpy.processing() (default
+                chain of train.py:96-101) on BASELINE config 1 (16 x 256 x 256 frames) with 1 process and with a
+                16-process pool (train.py:318 num_workers=16), and the numpy port of the parametrized fwd+bwd on
+                one core; timed on the host BEFORE the process touches the GPU (rank 0, N == 1 only).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,16 +46,26 @@ ALGO_BYTES_PER_PX = {
 }
 
 
-def pmc_traffic(kernel, B, S, name='r01_pmc_traffic.json', shape=(64, 512)):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
-    their own runs, gfx950 correction applied; profiles/r01_pmc_traffic*.json), valid for the workload shape the
-    passes were collected on only (64x512x512 parametrized, 256x1024x1024 static); None otherwise."""
+PMC_PARAM = 'r02_pmc_traffic.json'
+PMC_STATIC = 'r02_pmc_traffic_static.json'
+
+
+def pmc_traffic(kernel, B, S, name=PMC_PARAM, shape=(64, 512)):
+    """(HBM bytes per launch of `kernel`, where the number comes from).  PMC counters cannot be read inside a
+    timed run, so this is NOT measured here: it is taken from the committed rocprofv3 --pmc passes (FETCH_SIZE /
+    WRITE_SIZE in their own runs, gfx950 correction applied; profiles/<name>) and only for the workload shape
+    those passes were collected on (64x512x512 parametrized, 256x1024x1024 static); (None, reason) otherwise."""
     path = os.path.join(REPO, 'profiles', name)
-    if (B, S) != shape or not os.path.exists(path):
-        return None
+    if (B, S) != shape:
+        return None, f'no PMC profile for this shape (profiles/{name} covers {shape[0]}x{shape[1]}x{shape[1]})'
+    if not os.path.exists(path):
+        return None, f'profiles/{name} not found'
     with open(path) as f:
         t = json.load(f)
-    return t.get(kernel, {}).get('total_bytes')
+    v = t.get(kernel, {}).get('total_bytes')
+    if v is None:
+        return None, f'profiles/{name} has no entry for {kernel}'
+    return v, f'committed rocprofv3 --pmc profile profiles/{name} (same build, same shape; not measured in this run)'
 
 
 def parse():
@@ -62,15 +81,19 @@ def parse():
                     help='parametrized = the headline metric (BASELINE config 2); static = the fused static chain '
                          'demosaic->WB->CCM->clip->gamma on 256x1024x1024 frames per GPU (BASELINE config 3)')
     ap.add_argument('--debayer', choices=('bilinear', 'malvar2004'), default='bilinear')
+    ap.add_argument('--sharpening', default='none', help="static workload: 'none' | 'sharpening_filter' | 'unsharp_masking'")
+    ap.add_argument('--denoising', default='none', help="static workload: 'none' | 'gaussian_denoising' | 'median_denoising'")
+    ap.add_argument('--no-static-c3', action='store_true',
+                    help='skip the static_c3 sub-records (BASELINE config 3) appended to the headline line')
     ap.add_argument('--raw-u16', action='store_true',
                     help='feed the 12-bit frames as uint16 containers (2 B/px ingest, normalised in-kernel; '
                          'SURVEY.md section 8f) instead of float32: a separate variant, not the headline config')
     return ap.parse_args()
 
 
-def cpu_baseline(size):
+def cpu_baseline_parametrized(size, seconds=8.0):
     """numpy oracle (port of pipeline_torch.py fwd + hand-written bwd), float32, one host thread,
-    BatchNorm train mode, on 2 frames of the workload's size; repeated until ~10 s have passed."""
+    BatchNorm train mode, on 2 frames of the workload's size; repeated for ~8 s."""
     import numpy as np
     from oracle import isp_oracle as orc
     B = 2
@@ -85,7 +108,7 @@ def cpu_baseline(size):
         orc.parametrized_backward(P, c, cot)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 12.0:
+        if dt > seconds:
             break
     return {'value': round(n * B * size * size / dt / 1e6, 3), 'unit': 'Mpix/s', 'cores': 1,
             'kind': 'port',
@@ -93,28 +116,112 @@ def cpu_baseline(size):
                       f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
 
 
-def cpu_baseline_static(debayer):
-    """numpy oracle of processing() (pipeline_numpy.py:70-141, float64 like the reference) on BASELINE config 1
-    frames (256x256), short chain, one host thread, repeated for ~10 s."""
-    import numpy as np
+C1_SHAPE = (16, 256, 256)      # BASELINE config 1
+
+
+def _pool_worker_init():
+    """one compute thread per worker process (BLAS pools of 16 workers would oversubscribe the host)"""
+    try:
+        import threadpoolctl
+        _pool_worker_init.limit = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
+
+
+def _static_frame(args):
+    """one DataLoader-worker unit of the reference: RawProcessingPipeline.__call__ on one float32 frame"""
     from oracle import isp_oracle as orc
-    raw = orc.synth_raw(16, 256, 256, seed=0, kind='uniform')
+    img, chain = args
+    return orc.static_batch(img[None], orc.DRONE_CAMERA_PARAMS, *chain)[0].shape
+
+
+def cpu_baseline_static(chain=('bilinear', 'sharpening_filter', 'gaussian_denoising'), seconds=8.0, workers=16):
+    """the numpy/scipy restatement of the reference's processing() (pipeline_numpy.py:70-141)
+    on BASELINE config 1 -- 16 float32 frames of 256x256, the default static chain of train.py:96-101 -- timed
+    (i) in this process and (ii) over a pool of `workers` processes that each take whole frames, the way the
+    reference's DataLoader runs it (train.py:318 num_workers=16).  Must run before this process initialises the
+    GPU (the pool forks)."""
+    import multiprocessing as mp
+    from oracle import isp_oracle as orc
+    raw = orc.synth_raw(*C1_SHAPE, seed=0, kind='uniform')
+    px = raw.size
+    orc.static_batch(raw[:1], orc.DRONE_CAMERA_PARAMS, *chain)          # imports scipy
     t0 = time.perf_counter()
     n = 0
     while True:
-        orc.static_batch(raw, orc.DRONE_CAMERA_PARAMS, debayer, 'none', 'none')
+        orc.static_batch(raw, orc.DRONE_CAMERA_PARAMS, *chain)
         n += 1
-        dt = time.perf_counter() - t0
-        if dt > 10.0:
+        dt1 = time.perf_counter() - t0
+        if dt1 > seconds:
             break
-    return {'value': round(n * raw.size / dt / 1e6, 3), 'unit': 'Mpix/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n} x 16x256x256 frames ({debayer}, short chain), numpy/scipy oracle float64, '
-                      f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
+    one = {'value': round(n * px / dt1 / 1e6, 3), 'unit': 'Mpix/s', 'cores': 1,
+           'sample': f'{n} x config C1 (16x256x256 float32 frames), {dt1:.1f} s, 1 process'}
+    reps = max(2, int(n * min(workers, os.cpu_count() or 1) * 0.75))      # ~seconds of work for the pool
+    items = [(raw[i % 16], chain) for i in range(16 * reps)]
+    with mp.get_context('fork').Pool(workers, initializer=_pool_worker_init) as pool:
+        pool.map(_static_frame, items[:workers])                        # start-up outside the timed region
+        t0 = time.perf_counter()
+        pool.map(_static_frame, items, chunksize=1)
+        dtp = time.perf_counter() - t0
+    return {'value': round(reps * px / dtp / 1e6, 3), 'unit': 'Mpix/s', 'cores': workers, 'kind': 'port',
+            'sample': f'{reps} x config C1 (16x256x256 float32 frames; {"+".join(chain)}) through a {workers}-process '
+                      f'pool, one frame per task (train.py:318 num_workers=16), {dtp:.1f} s; numpy/scipy restatement '
+                      f'of pipeline_numpy.processing(); os.cpu_count() = {os.cpu_count()}',
+            'one_process': one}
+
+
+def cpu_baselines(size, parametrized=True):
+    out = cpu_baseline_static()
+    if parametrized:
+        out['parametrized_fwd_bwd_one_core'] = cpu_baseline_parametrized(size)
+    return out
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process, which has
+    not touched (and never touches) the GPU.  Rank 0 prints the JSON line; the exit code is non-zero if any
+    rank fails or fewer than N join."""
+    backend = os.environ.get('R2L_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and os.environ.get('R2L_BENCH_DEVICE') != 'emulation':
+        import torch
+        have = torch.cuda.device_count()                # does not initialise HIP
+        if have < args.gpus:
+            print(f'bench.py: --gpus {args.gpus} but only {have} GPU(s) visible', file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _world(args):
+    """(world, rank, local_rank) from the launcher's environment, checked against --gpus"""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU '
+                         f'(torch.distributed.run --nproc-per-node {args.gpus}) or none at all')
+    return world, int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
 def _init_distributed(torch, dist, world, local_rank):
     """one process per GPU over RCCL (backend "nccl").  R2L_BENCH_BACKEND=gloo lets the N > 1 code path be
-    exercised with several processes on ONE GPU (a functional check, not a measurement)."""
+    exercised with several processes on ONE GPU (a functional check, not a measurement);
+    R2L_BENCH_DEVICE=emulation (tests/test_bench_launcher.py only) serves CPU tensors with the host emulation of
+    the kernels, so that the launcher / rendezvous / timing protocol can be tested without a GPU."""
+    if os.environ.get('R2L_BENCH_DEVICE') == 'emulation':
+        sys.path.insert(0, os.path.join(REPO, 'tests'))
+        import conftest
+        import emul_hook
+        emul_hook.enable(conftest.build_emulation())
+        dev = torch.device('cpu')
+        if world > 1:
+            dist.init_process_group('gloo')
+        return dev
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before anything initialises HIP
     index = local_rank % max(torch.cuda.device_count(), 1)
@@ -126,72 +233,147 @@ def _init_distributed(torch, dist, world, local_rank):
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+    if world > 1 and dist.get_world_size() != world:
+        raise SystemExit(f'bench.py: {dist.get_world_size()} ranks joined, expected {world}')
     return dev
+
+
+class Clock:
+    """the contract's timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks"""
+
+    def __init__(self, torch, dist, world, dev):
+        self.torch, self.dist, self.world, self.dev = torch, dist, world, dev
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        if self.dev.type == 'cuda':
+            self.torch.cuda.synchronize()
+
+    def time_steps(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+
+def kernel_times(lib, clock, step, steps):
+    """{kernel: {launches, avg_us}} of `steps` more steps, from the library's HIP events around every launch
+    (recorded on the stream the kernels are launched on)"""
+    lib.r2l_timing_enable(1)
+    for _ in range(steps):
+        step()
+    clock.barrier()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.r2l_timing_report(buf, len(buf))
+    lib.r2l_timing_enable(0)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = {'launches': int(cnt), 'avg_us': round(1e3 * float(ms) / int(cnt), 2)}
+    return out
+
+
+def static_records(torch, lib, clock, dev):
+    """BASELINE config 3 next to the headline number: per-launch duration of the fused static kernels from HIP
+    events, as a fraction of the HBM peak at 16 algorithmic B/px (4 in + 12 out).  A process's first launches of
+    these kernels run ~12 % slower, hence the 12 warm-up launches."""
+    from raw2logit_amd import cameras, functional as F_
+    recs = []
+    chains = [('short chain (demosaic->WB->CCM->clip->gamma), bilinear', 256, 1024, ('bilinear', 'none', 'none')),
+              ('short chain (demosaic->WB->CCM->clip->gamma), bilinear', 1024, 512, ('bilinear', 'none', 'none')),
+              ('short chain (demosaic->WB->CCM->clip->gamma), Malvar2004', 256, 1024, ('malvar2004', 'none', 'none')),
+              ('train.py default chain (bilinear + sharpening_filter + gaussian_denoising)', 256, 1024,
+               ('bilinear', 'sharpening_filter', 'gaussian_denoising'))]
+    for what, B, S, chain in chains:
+        u = torch.randint(0, 4096, (B, S, S), device=dev, dtype=torch.int32,
+                          generator=torch.Generator(dev).manual_seed(0))
+        raw = u.to(torch.float32) / 4095.0
+        del u
+
+        def step():
+            return F_.static_pipeline(raw, cameras.DRONE, *chain)
+        for _ in range(12):
+            step()
+        clock.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        clock.barrier()
+        wall_ms = 1e3 * (time.perf_counter() - t0) / 20
+        k = kernel_times(lib, clock, step, 20)
+        name = max(k, key=lambda n: k[n]['launches'] * k[n]['avg_us'])
+        avg_us = sum(v['launches'] * v['avg_us'] for v in k.values()) / 20      # all launches of one call
+        ach = B * S * S * 16.0 / (avg_us * 1e-6) / 1e9
+        recs.append({'chain': what, 'shape': [B, S, S], 'kernel': name, 'avg_us': round(avg_us, 1),
+                     'ms_per_call_wall': round(wall_ms, 4), 'algo_bytes_per_px': 16.0,
+                     'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(ach / HBM_PEAK_GBS, 4),
+                     'Mpix_per_s': round(B * S * S / (wall_ms * 1e-3) / 1e6, 1)})
+        del raw
+        torch.cuda.empty_cache()
+    return recs
 
 
 def main_static(args):
     """BASELINE config 3: one step = the fused static chain over 256x1024x1024 frames per GPU (no exchange between
     ranks: static mode needs no collective)."""
+    world, rank, local_rank = _world(args)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baselines(0, parametrized=False)          # before the GPU is touched (the pool forks)
     import torch
     import torch.distributed as dist
     from raw2logit_amd import _lib, cameras, functional as F_
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dev = _init_distributed(torch, dist, world, local_rank)
-    lib = _lib.device_library()
+    lib = _lib.library_for(torch.empty(1, device=dev))[0]
+    clock = Clock(torch, dist, world, dev)
     B, S = (args.batch or 256), (args.size or 1024)
     gen = torch.Generator(dev).manual_seed(rank)
     u = torch.randint(0, 4096, (B, S, S), device=dev, generator=gen, dtype=torch.int32)
     raw = u.to(torch.uint16) if args.raw_u16 else u.to(torch.float32) / 4095.0
+    chain = (args.debayer, args.sharpening, args.denoising)
 
     def step():
-        return F_.static_pipeline(raw, cameras.DRONE, args.debayer, 'none', 'none', bits=12)
+        return F_.static_pipeline(raw, cameras.DRONE, *chain, bits=12)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = clock.time_steps(step, args.steps, args.warmup)
     px = world * B * S * S
-    lib.r2l_timing_enable(1)
-    for _ in range(args.steps):
-        step()
-    barrier()
-    buf = ctypes.create_string_buffer(1 << 14)
-    lib.r2l_timing_report(buf, len(buf))
-    lib.r2l_timing_enable(0)
-    name, cnt, ms = buf.value.decode().split()
-    avg_us = 1e3 * float(ms) / int(cnt)
-    bpp = 14.0 if args.raw_u16 else 16.0
-    ach = B * S * S * bpp / (avg_us * 1e-6) / 1e9
+    k = kernel_times(lib, clock, step, args.steps) if not args.no_roofline else {}
+    roofline = None
+    if k:
+        name = max(k, key=lambda n: k[n]['launches'] * k[n]['avg_us'])
+        avg_us = sum(v['launches'] * v['avg_us'] for v in k.values()) / args.steps
+        bpp = 14.0 if args.raw_u16 else 16.0
+        ach = B * S * S * bpp / (avg_us * 1e-6) / 1e9
+        traffic, source = (None, 'no PMC profile for 16-bit containers') if args.raw_u16 else \
+            pmc_traffic(name, B, S, PMC_STATIC, (256, 1024))
+        roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'traffic_source': source, 'avg_us': round(avg_us, 1), 'algo_bytes_per_px': bpp}
     if rank == 0:
+        short = chain[1:] == ('none', 'none')
         out = {'metric': 'ISP Mpix/s (static fwd: demosaic->WB->CCM->clip->gamma) on 1024x1024 raw batches',
                'value': round(px * args.steps / dt / 1e6, 1), 'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps,
                'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-               'config': {'workload': f'static short chain ({args.debayer}), {B}x{S}x{S} 12-bit RGGB frames per GPU'
+               'config': {'workload': ('static short chain' if short else 'static chain ' + '+'.join(chain[1:])) +
+                                      f' ({args.debayer}), {B}x{S}x{S} 12-bit RGGB frames per GPU'
                                       + (' as uint16 containers' if args.raw_u16 else '') + ', Drone camera parameters',
                           'global_batch': world * B, 'frame': [S, S],
                           'parallelism': f'batch shard x{world}, no collective' if world > 1 else 'single GPU'},
-               'roofline': {'bound': 'hbm', 'kernel': name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                            'traffic': None if args.raw_u16 else
-                            pmc_traffic(name, B, S, 'r01_pmc_traffic_static.json', (256, 1024)),
-                            'avg_us': round(avg_us, 1), 'algo_bytes_per_px': bpp}}
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline_static(args.debayer)
+               'roofline': roofline, 'kernels': k}
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -200,21 +382,25 @@ def main_static(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))           # the parent never touches the GPU
     if args.workload == 'static':
         return main_static(args)
+    world, rank, local_rank = _world(args)
+    B, S = (args.batch or 64), (args.size or 512)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baselines(S)                 # before the GPU is touched (the pool forks)
     import torch
     import torch.distributed as dist
     import numpy as np
     from raw2logit_amd import _lib, cameras         # (the oracle is only touched by the cpu_baseline leg)
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dev = _init_distributed(torch, dist, world, local_rank)
-    lib = _lib.device_library()                     # raises if the HIP extension is missing
+    lib = _lib.library_for(torch.empty(1, device=dev))[0]      # raises if the HIP extension is missing
+    clock = Clock(torch, dist, world, dev)
 
-    B, S = (args.batch or 64), (args.size or 512)
     # SURVEY.md section 8d "perf" distribution: uniform 12-bit codes, raw = u16 / 4095 (float32)
     u16 = np.random.default_rng(rank).integers(0, 4096, (B, S, S)).astype(np.uint16)
     raw = torch.from_numpy(u16 if args.raw_u16 else u16.astype(np.float32) / np.float32(4095)).to(dev)
@@ -237,23 +423,7 @@ def main():
             torch._foreach_copy_([p.grad for p in params],
                                  [c.view_as(p.grad) for c, p in zip(flat.split([p.numel() for p in params]), params)])
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = clock.time_steps(step, args.steps, args.warmup)
     px_per_step = world * B * S * S
     value = px_per_step * args.steps / dt / 1e6
 
@@ -261,16 +431,7 @@ def main():
     kernels = {}
     if not args.no_roofline:
         # second pass of the same K steps with the library's per-kernel HIP-event hooks switched on
-        lib.r2l_timing_enable(1)
-        for _ in range(args.steps):
-            step()
-        barrier()
-        buf = ctypes.create_string_buffer(1 << 16)
-        lib.r2l_timing_report(buf, len(buf))
-        lib.r2l_timing_enable(0)
-        for line in buf.value.decode().splitlines():
-            name, cnt, ms = line.split()
-            kernels[name] = {'launches': int(cnt), 'avg_us': round(1e3 * float(ms) / int(cnt), 2)}
+        kernels = kernel_times(lib, clock, step, args.steps)
         # 16-bit container variants (r2l_launch_*_u16_kernel): 2 B/px less raw traffic
         algo = dict(ALGO_BYTES_PER_PX)
         for k, v in ALGO_BYTES_PER_PX.items():
@@ -282,35 +443,47 @@ def main():
             dom = max(total, key=total.get)
             avg_us = cand[dom]['avg_us']
             bpp = algo[dom]
-            if dom.startswith('r2l_launch_fwd'):
+            if dom.startswith('r2l_launch_fwd') and cand[dom]['launches'] == 2 * args.steps:
                 # two launches per step: stats-only (raw only) and apply (raw + 12 B/px out): average bytes
                 bpp = ((bpp - 12.0) + bpp) / 2
             achieved = B * S * S * bpp / (avg_us * 1e-6) / 1e9
+            traffic, source = pmc_traffic(dom, B, S) if not args.raw_u16 else \
+                (None, 'no PMC profile for 16-bit containers')
             roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                        'traffic': pmc_traffic(dom, B, S) if not args.raw_u16 else None, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
+                        'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
+
+    static_c3 = None
+    if world == 1 and dev.type == 'cuda' and not args.no_static_c3:
+        del raw, cot
+        torch.cuda.empty_cache()
+        static_c3 = static_records(torch, lib, clock, dev)
 
     if rank == 0:
         out = {
             'metric': 'ISP Mpix/s (fwd+bwd) on 512x512 raw batches', 'value': round(value, 1),
             'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' + (' (uint16 containers)' if args.raw_u16 else ''),
+            'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic' + (' (uint16 containers)' if args.raw_u16 else '') +
+                    (' -- HOST EMULATION: functional check of the launcher, not a measurement'
+                     if dev.type != 'cuda' else ''),
             'config': {'workload': f'parametrized ISP fwd+bwd, BatchNorm train, {B}x{S}x{S} 12-bit RGGB '
                                    f'frames per GPU, Drone camera parameters',
                        'global_batch': world * B, 'frame': [S, S],
                        'parallelism': f'batch shard x{world}' if world > 1 else 'single GPU',
                        'step': 'forward + backward' + (' + 132-float grad all-reduce' if world > 1 else '')},
             'roofline': roofline,
-            # the whole step against SURVEY.md section 8d's 52 B/px (single fused backward; this kernel split
-            # moves 72 B/px)
+            # the whole step against SURVEY.md section 8d's 52 B/px (single fused backward)
             'step_roofline': {'algo_bytes_per_px': 52.0, 'achieved': round(px_per_step / world * 52.0 * args.steps / dt / 1e9, 1),
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(px_per_step / world * 52.0 * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
             'kernels': kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(S)
+        if static_c3 is not None:
+            out['static_c3'] = static_c3
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

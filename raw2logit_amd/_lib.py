@@ -1,12 +1,10 @@
 """ctypes binding of libr2l_isp.so (C ABI: include/r2l_isp.h).
 
-The product has exactly one compute path: the HIP kernels for gfx950.  If the shared library is
-missing, or a tensor is not on the GPU, every op raises -- there is no PyTorch / numpy fallback.
-
-The CPU-only test suite may register the HOST EMULATION of the same kernel source
-(tests/_build/libr2l_emul.so, built from tests/emul/r2l_emul.cpp) through
-``enable_test_emulation``; it then serves CPU tensors only, never CUDA tensors, and nothing in the
-package calls that hook."""
+The product has exactly one compute path and one dispatch target: the HIP kernels for gfx950.  If the
+shared library is missing, is not the gfx950 build, or a tensor is not on the GPU, every op raises --
+there is no PyTorch / numpy / CPU fallback and no hook for one in this package.  (The CPU-only test
+suite runs the kernel SOURCE through a host emulation; the code that serves CPU tensors with it lives
+in tests/emul_hook.py and patches this module from the outside.)"""
 import ctypes
 import os
 import subprocess
@@ -117,7 +115,7 @@ class R2LError(RuntimeError):
 
 
 class Library:
-    def __init__(self, path, allow_emulation=False):
+    def __init__(self, path):
         if not os.path.exists(path):
             raise R2LError(
                 f'{path} not found: the HIP extension is not built. Run '
@@ -130,8 +128,11 @@ class Library:
             fn.restype = restype
             fn.argtypes = argtypes
         self.is_device = bool(self.cdll.r2l_is_device_build())
-        if not self.is_device and not allow_emulation:
-            raise R2LError(f'{path} is the test-only host emulation, not the gfx950 build')
+        self._check_build()
+
+    def _check_build(self):
+        if not self.is_device:
+            raise R2LError(f'{self.path} is the test-only host emulation, not the gfx950 build')
 
     def check(self, code, what):
         if code != 0:
@@ -143,7 +144,6 @@ class Library:
 
 
 _DEVICE_LIB = None
-_EMUL_LIB = None
 
 
 def device_library():
@@ -151,13 +151,6 @@ def device_library():
     if _DEVICE_LIB is None:
         _DEVICE_LIB = Library(LIB_PATH)
     return _DEVICE_LIB
-
-
-def enable_test_emulation(path):
-    """TEST HOOK (tests/conftest.py only): serve CPU tensors with the host emulation of the kernels."""
-    global _EMUL_LIB
-    _EMUL_LIB = Library(path, allow_emulation=True) if path else None
-    return _EMUL_LIB
 
 
 def library_for(t):
@@ -170,8 +163,6 @@ def library_for(t):
             raise R2LError(f'the tensor lives on {t.device} but the current device is cuda:'
                            f'{torch.cuda.current_device()}; use torch.cuda.set_device / torch.cuda.device(...)')
         return lib, ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-    if _EMUL_LIB is not None:
-        return _EMUL_LIB, ctypes.c_void_p(0)
     raise R2LError('raw2logit_amd runs on MI355X only: the tensor is on the CPU and there is no CPU '
                    'path (move it to the GPU: tensor.cuda())')
 
@@ -180,21 +171,24 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def hipcc_command(out_path=LIB_PATH):
+def hipcc_command(out_path=LIB_PATH, extra=()):
     # -fno-slp-vectorize: packed f32 is written out by hand where it pays (r2l_p2 pairs of adjacent pixels); the
     # SLP vectoriser's own pairing adds register shuffles and ~100 live VGPRs to the backward kernels
     return ['hipcc', '-O3', '-std=c++17', '-fno-slp-vectorize', '--offload-arch=gfx950', '-shared', '-fPIC',
-            os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path]
+            *extra, os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path]
 
 
-def build_device_library(verbose=True):
+def build_device_library(verbose=True, out_path=LIB_PATH, extra=()):
     """compile libr2l_isp.so in-tree for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
            [os.path.join(REPO_ROOT, 'include', 'r2l_isp.h')]
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
-    cmd = hipcc_command()
+    if os.path.exists(out_path) and all(os.path.getmtime(out_path) >= os.path.getmtime(s) for s in srcs):
+        return out_path
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    tmp = out_path + f'.{os.getpid()}.tmp'
+    cmd = hipcc_command(tmp, extra)
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    os.replace(tmp, out_path)
+    return out_path

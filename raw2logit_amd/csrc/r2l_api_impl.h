@@ -200,12 +200,20 @@ R2L_KERNEL(r2l_launch_l2, R2LL2Args, r2l_l2_block, R2L_RED_FLOATS_N(1))
 
 // ---- grid sizing ------------------------------------------------------------------------------
 static_assert(R2L_MAX_BLOCKS == 1024, "partials are laid out for at most 1024 workgroups");
+// Launch shapes are compile-time choices of the product build.  Diagnostic builds (-DR2L_TEST_HOOKS: the host
+// emulation and tests/_build/libr2l_isp_hooks.so, never the shipped libr2l_isp.so) can override them through the
+// environment -- that is how the tests show that no result depends on the workgroup count, and how A/B runs sweep
+// band heights.
+#ifdef R2L_TEST_HOOKS
 static int r2l_env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   if (!s || !*s) return dflt;
   const int v = atoi(s);
   return v > 0 ? v : dflt;
 }
+#else
+static inline int r2l_env_int(const char*, int dflt) { return dflt; }
+#endif
 // persistent tile-walking kernels: at most `cap` workgroups (256 CUs x resident workgroups per CU),
 // a multiple of 8 when possible so that the XCD-grouped walk applies
 static int r2l_tile_grid(int ntiles, int cap) {

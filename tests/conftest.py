@@ -25,18 +25,30 @@ def build_emulation():
         return EMUL_LIB
     os.makedirs(os.path.dirname(EMUL_LIB), exist_ok=True)
     tmp = EMUL_LIB + f'.{os.getpid()}.tmp'
-    subprocess.run(['g++', '-std=c++17', '-O2', '-shared', '-fPIC', EMUL_SRC, '-o', tmp], check=True)
+    subprocess.run(['g++', '-std=c++17', '-O2', '-DR2L_TEST_HOOKS', '-shared', '-fPIC', EMUL_SRC, '-o', tmp],
+                   check=True)
     os.replace(tmp, EMUL_LIB)
     return EMUL_LIB
+
+
+HOOKS_LIB = os.path.join(REPO, 'tests', '_build', 'libr2l_isp_hooks.so')
+
+
+def build_hooks_library():
+    """the gfx950 library once more with -DR2L_TEST_HOOKS: launch shapes can be overridden through R2L_GRID_* /
+    R2L_STREAM_BANDS (the shipped libr2l_isp.so ignores them).  Built by __graft_entry__.build() so that it travels
+    to the GPU box; tests/parity_checks.py loads it for the grid-independence checks only."""
+    from raw2logit_amd import _lib
+    return _lib.build_device_library(out_path=HOOKS_LIB, extra=('-DR2L_TEST_HOOKS',))
 
 
 @pytest.fixture(scope='session')
 def emulation():
     """CPU tensors are served by the host emulation of the HIP kernels for the duration of the tests."""
-    from raw2logit_amd import _lib
-    lib = _lib.enable_test_emulation(build_emulation())
+    import emul_hook
+    lib = emul_hook.enable(build_emulation())
     yield lib
-    _lib.enable_test_emulation(None)
+    emul_hook.enable(None)
 
 
 @pytest.fixture(scope='session')

@@ -9,8 +9,8 @@ import parity_checks as pc
 dev = 'cuda' if torch.cuda.is_available() else 'cpu'
 if dev == 'cpu':       # the host emulation of the same kernels (slow: keep SECONDS small)
     import conftest
-    from raw2logit_amd import _lib
-    _lib.enable_test_emulation(conftest.build_emulation())
+    import emul_hook
+    emul_hook.enable(conftest.build_emulation())
 rng = np.random.default_rng(int(os.environ.get('SEED', '0')))
 budget = float(os.environ.get('SECONDS', '90'))
 t0 = time.time()

@@ -12,8 +12,8 @@ import parity_checks as pc
 dev = 'cuda' if torch.cuda.is_available() else 'cpu'
 if dev == 'cpu':
     import conftest
-    from raw2logit_amd import _lib
-    _lib.enable_test_emulation(conftest.build_emulation())
+    import emul_hook
+    emul_hook.enable(conftest.build_emulation())
 rng = np.random.default_rng(int(os.environ.get('SEED', '0')))
 budget = float(os.environ.get('SECONDS', '60'))
 which = os.environ.get('WHICH', 'static,raw2rgb,staged,aux').split(',')

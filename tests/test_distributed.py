@@ -28,8 +28,9 @@ def _worker(rank, world, port, emul_path, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from raw2logit_amd import _lib
-    _lib.enable_test_emulation(emul_path)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import emul_hook
+    emul_hook.enable(emul_path)
     from oracle import isp_oracle as orc
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     B, H, W = 4, 24, 40

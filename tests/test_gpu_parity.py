@@ -1,6 +1,8 @@
 """GPU (MI355X) parity: libr2l_isp.so through the C ABI against the oracle and the reference's golden
 vectors -- the same checks tests/test_emul_parity.py runs on the host emulation, plus full-size
 properties at BASELINE.json's sizes."""
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -49,7 +51,8 @@ def test_frame_shapes_around_tile_boundaries(dev):
 def test_cpu_tensor_is_refused(dev):
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     from raw2logit_amd import _lib
-    if _lib._EMUL_LIB is not None:
+    emul_hook = sys.modules.get('emul_hook')
+    if emul_hook is not None and emul_hook.active() is not None:
         pytest.skip('emulation hook active in this process')
     with pytest.raises(_lib.R2LError):
         ParametrizedProcessing()(torch.rand(1, 8, 8))
@@ -184,3 +187,44 @@ def test_weak_augmentation(dev):
 
 def test_error_behaviour(dev):
     pc.check_error_behaviour(dev)
+
+
+def _bench(args, env=None, timeout=900):
+    import json
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py')] + args, env=e, capture_output=True,
+                       text=True, timeout=timeout, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    return lines[0]
+
+
+def test_bench_line_carries_roofline_and_static_c3(dev):
+    """the default bench line: headline metric + roofline (with the source of `traffic` named) + the BASELINE
+    config 3 sub-records (fused static chain, fraction of the HBM peak from HIP-event kernel times)"""
+    out = _bench(['--steps', '5', '--warmup', '2', '--no-cpu-baseline'])
+    assert out['n_gpus'] == 1 and out['unit'] == 'Mpix/s' and out['value'] > 0
+    rf = out['roofline']
+    assert rf['bound'] == 'hbm' and 0 < rf['frac'] < 1 and 'traffic_source' in rf
+    recs = out['static_c3']
+    shapes = [tuple(r['shape']) for r in recs]
+    assert (256, 1024, 1024) in shapes and (1024, 512, 512) in shapes
+    for r in recs:
+        assert 0 < r['frac'] < 1 and r['avg_us'] > 0
+        # algorithmic bytes over HIP-event time cannot beat the wall clock of the same call
+        assert r['avg_us'] * 1e-3 <= r['ms_per_call_wall'] * 1.05
+
+
+def test_bench_two_ranks_nccl(dev):
+    """`python bench.py --gpus 2` launches its own two ranks over RCCL (one per GPU)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    out = _bench(['--gpus', '2', '--steps', '5', '--warmup', '2', '--no-roofline'])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 128
