@@ -158,6 +158,38 @@ int r2l_isp_bwd(const float *raw, const float *params, const float *additive,
 int r2l_additive_bwd(const float *grad_out, const float *out, const float *bn_mean_istd,
                      const float *bn_bwd, float *grad_additive, int B, int H, int W, void *stream);
 
+/* ---- one training step of ParametrizedProcessing in two calls ------------------------
+ * r2l_isp_step_fwd = everything ParametrizedProcessing.forward (:175-225) enqueues for one batch:
+ *   the nine parameter tensors (device pointers, in R2L_P_* order: black_level, white_balance,
+ *   colour_correction, gamma_correct, debayer.weight, sharpening_filter.weight, gaussian_blur.weight,
+ *   M_RGB_2_YUV, M_YUV_2_RGB; the table params_host itself is HOST memory) are gathered into the packed block
+ *   inside the workspace and folded by one small launch; train-mode BatchNorm: statistics pass + bookkeeping
+ *   (running statistics, num_batches_tracked: nn.BatchNorm2d semantics, momentum < 0 = cumulative average);
+ *   eval mode: (mean, 1/sqrt(var+eps)) from the running statistics; then the apply pass -> out.
+ * r2l_isp_step_bwd = the whole backward: BatchNorm backward sums, both gradient kernels -> grad_params
+ *   (float32[R2L_P_NTRAIN], may be NULL), the additive layer's gradient (may be NULL).
+ * The workspace (r2l_isp_workspace_bytes) carries the step's state from the forward to the backward: packed
+ * parameters as the forward saw them, folded weights, BatchNorm constants.  It must not be used by another
+ * step in between.
+ * raw: float32 frames (raw_u16 = 0) or 16-bit containers (raw_u16 = 1, denom = 2**bits - 1).
+ * Several ranks (train-mode BatchNorm only): the statistics / backward sums cross ranks between phase A and
+ * phase B --  A: this rank's vector lands in the workspace at r2l_isp_step_offset(R2L_STEP_STATS |
+ * R2L_STEP_BN_SUMS) (7 resp. 6 doubles); the caller all-gathers them (RCCL) and hands the rank-major result to
+ * phase B, which adds the rows in rank order.  One rank: phase = R2L_STEP_ALL.                             */
+enum { R2L_BN_NONE = 0, R2L_BN_TRAIN = 1, R2L_BN_EVAL = 2 };
+enum { R2L_STEP_ALL = 0, R2L_STEP_A = 1, R2L_STEP_B = 2 };
+enum { R2L_STEP_STATS = 0, R2L_STEP_MOMENTS = 1, R2L_STEP_BN_SUMS = 2, R2L_STEP_PACKED = 3, R2L_STEP_BN = 4 };
+size_t r2l_isp_step_offset(int which, int B, int H, int W); /* byte offset inside the workspace */
+int r2l_isp_step_fwd(const void *raw, int raw_u16, float denom, const float *const *params_host,
+                     const float *additive, int bn_mode, float *running_mean, float *running_var,
+                     long long *num_batches_tracked, double eps, double momentum, float *out, void *workspace,
+                     size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
+                     const double *gathered_stats, void *stream);
+int r2l_isp_step_bwd(const void *raw, int raw_u16, float denom, const float *additive, const float *grad_out,
+                     const float *out, float *grad_params, float *grad_additive, int bn_mode, void *workspace,
+                     size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
+                     const double *gathered_sums, void *stream);
+
 /* ---- static pipeline, numpy semantics (processing(), processing/pipeline_numpy.py:70-141, batched):
  * remove_blacklv (:152-158) -> demosaicing_CFA_Bayer_{bilinear,Malvar2004} (:92-95) -> wb (:161-162) ->
  * CCM (:165-167) -> [sharpening_filter (:180-191) | unsharp_masking (:170-177)] -> [gaussian_denoising (:203-209) | median_denoising

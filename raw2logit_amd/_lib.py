@@ -59,6 +59,16 @@ _SIGNATURES = {
                                    _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_size_t,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_void_p]),
+    'r2l_isp_step_offset': (ctypes.c_size_t, [ctypes.c_int] * 4),
+    'r2l_isp_step_fwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_void_p),
+                                        _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_double,
+                                        ctypes.c_double, _c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_void_p]),
+    'r2l_isp_step_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p,
+                                        _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
     'r2l_additive_bwd': (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'r2l_isp_fwd_u16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p,

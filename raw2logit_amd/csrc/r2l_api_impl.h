@@ -135,7 +135,10 @@ R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 *
 #define R2L_OCC_BWD1 2
 #endif
 #ifndef R2L_OCC_BWD2
-#define R2L_OCC_BWD2 2
+#define R2L_OCC_BWD2 4
+#endif
+#if R2L_OCC_BWD2 >= 4 && R2L_B2_PREFETCH
+#error "bwd2 at two workgroups per CU needs -DR2L_B2_PREFETCH=0 -DR2L_RPI_ADJ=3 (128 VGPRs)"
 #endif
 // hot instantiation (frames that tile exactly, no additive layer) + the general ones; each again for 16-bit
 // container frames (compile-time, so that the float32 kernels carry no decode code)
@@ -197,6 +200,7 @@ R2L_KERNEL(r2l_launch_axpy, R2LAxpyArgs, r2l_axpy_block, 4)
 R2L_KERNEL(r2l_launch_ssim, R2LSsimArgs, r2l_ssim_block, R2L_SSIM_LDS_FLOATS)
 R2L_KERNEL(r2l_launch_ssim_bwd, R2LSsimBwdArgs, r2l_ssim_bwd_block, R2L_SSIM_BWD_LDS_FLOATS)
 R2L_KERNEL(r2l_launch_l2, R2LL2Args, r2l_l2_block, R2L_RED_FLOATS_N(1))
+R2L_KERNEL(r2l_launch_pack_fold, R2LPackFoldArgs, r2l_pack_fold_block, R2L_P_COUNT + 2)
 
 // ---- grid sizing ------------------------------------------------------------------------------
 static_assert(R2L_MAX_BLOCKS == 1024, "partials are laid out for at most 1024 workgroups");
@@ -234,6 +238,13 @@ struct R2LWorkspace {
   unsigned* counters;  // [1 + R2L_MAX_GROUPS] arrival counters: zeroed by the fold kernel, zero after every launch
   float* gypp;
   float* debug;  // 3 x [R2L_MAX_BLOCKS][8] floats: per-phase cycle stamps of diagnostic builds (fwd, bwd1, bwd2)
+  // step block (r2l_isp_step_fwd / _bwd): what one training step keeps between its launches
+  float* packed;    // [R2L_P_COUNT] the parameter values the forward saw
+  float* bn;        // [6] mean, istd
+  float* bn_bwd;    // [6] mean(g), mean(g * xhat)
+  double* stats;    // [7] this rank's statistics sums (+ pixel count)
+  double* moments;  // [7] mean, biased var, pixel count of the global batch
+  double* bsums;    // [6] this rank's BatchNorm backward sums
   size_t total;
 };
 static size_t r2l_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -257,6 +268,15 @@ static R2LWorkspace r2l_carve(void* base, int B, int H, int W) {
   off += r2l_align_up(sizeof(unsigned) * (1 + R2L_MAX_GROUPS));
   w.debug = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * 3 * 8 * R2L_MAX_BLOCKS);
+  w.packed = (float*)(p + off);
+  off += r2l_align_up(sizeof(float) * R2L_P_COUNT);
+  w.bn = (float*)(p + off);
+  w.bn_bwd = w.bn + 8;
+  off += r2l_align_up(sizeof(float) * 16);
+  w.stats = (double*)(p + off);
+  w.moments = w.stats + 8;
+  w.bsums = w.stats + 16;
+  off += r2l_align_up(sizeof(double) * 24);
   w.gypp = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * (size_t)B * H * W);
   w.total = off;
@@ -368,7 +388,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
   a.debug = ws.debug;
   // the statistics are reduced by the last workgroups of the same launch (the workspace's arrival counters
   // are valid: this call or an earlier one on this workspace ran the fold kernel)
-  a.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6};
+  a.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6, 0};
   a.stats_out = stats;
   if (fin)
     a.fin = *fin;
@@ -420,7 +440,7 @@ int r2l_bn_bwd_reduce(const float* grad_out, const float* out, const double* tot
   // of the launch finish the reduction; otherwise a second, tiny launch does
   const bool in_kernel = (flags & R2L_F_FOLDED_VALID) != 0;
   R2LBnReduceArgs a{grad_out, out, ws.part_small, B, H, W,
-                    R2LTree{ws.part_small, nullptr, ws.gpartial, in_kernel ? ws.counters : nullptr, 6},
+                    R2LTree{ws.part_small, nullptr, ws.gpartial, in_kernel ? ws.counters : nullptr, 6, 0},
                     sums, totals, bn_bwd};
   if (int e = r2l_launch_bn_reduce(a, grid, stream)) return e;
   if (in_kernel) return 0;
@@ -472,7 +492,8 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
                   : (exact ? r2l_launch_bwd1(a1, g1, stream) : r2l_launch_bwd1_ragged(a1, g1, stream));
   if (e1) return e1;
   const int ntiles2 = B * ((H + GBwd2::TH - 1) / GBwd2::TH) * ((W + GBwd2::TW - 1) / GBwd2::TW);
-  const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", 256));
+  // bwd2 fits two workgroups per CU (<= 128 VGPRs, 68 KB of LDS): 512 workgroups
+  const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", R2L_OCC_BWD2 >= 4 ? 512 : 256));
   R2LBwd2Args a2;
   a2.raw = raw;
   a2.F = ws.folded;
@@ -482,10 +503,12 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   a2.H = H;
   a2.W = W;
   a2.debug = ws.debug + 16 * R2L_MAX_BLOCKS;
-  // B2's last workgroups reduce both kernels' partials and unfold them into the 132 gradients (the two
-  // grids are equal unless the R2L_GRID_* overrides differ: then three tiny launches do it)
-  const bool in_kernel = g1 == g2;
-  a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC};
+  // B2's last workgroups reduce both kernels' partials (B1's were written by g1 workgroups: every level-1 group
+  // of B2's grid adds the B1 partials of its own 16 workgroup ids, as far as they exist) and unfold them into the
+  // 132 gradients; if B1 ran MORE workgroups than B2 (R2L_GRID_* overrides of diagnostic builds) three tiny
+  // launches do it
+  const bool in_kernel = g1 <= g2;
+  a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC, g1};
   a2.params = params;
   a2.grad_params = grad_params;
   if (int e = raw.u16 ? r2l_launch_bwd2_u16(a2, g2, stream) : r2l_launch_bwd2(a2, g2, stream)) return e;
@@ -508,6 +531,115 @@ int r2l_additive_bwd(const float* grad_out, const float* out, const float* bn_me
   int grid = (int)((nchunk + R2L_NT - 1) / R2L_NT);
   if (grid > R2L_MAX_BLOCKS) grid = R2L_MAX_BLOCKS;
   return r2l_launch_add_bwd(a, grid, stream);
+}
+
+// ---- one training step in two calls (r2l_isp_step_fwd / r2l_isp_step_bwd) --------------------------------
+static R2LRaw r2l_raw_any(const void* raw, int raw_u16, float denom) {
+  return raw_u16 ? r2l_raw_u16((const unsigned short*)raw, denom) : r2l_raw_f32((const float*)raw);
+}
+size_t r2l_isp_step_offset(int which, int B, int H, int W) {
+  if (B < 1 || H < 1 || W < 1) return 0;
+  const R2LWorkspace ws = r2l_carve(nullptr, B, H, W);
+  switch (which) {
+    case R2L_STEP_STATS: return (size_t)((char*)ws.stats - (char*)nullptr);
+    case R2L_STEP_MOMENTS: return (size_t)((char*)ws.moments - (char*)nullptr);
+    case R2L_STEP_BN_SUMS: return (size_t)((char*)ws.bsums - (char*)nullptr);
+    case R2L_STEP_PACKED: return (size_t)((char*)ws.packed - (char*)nullptr);
+    case R2L_STEP_BN: return (size_t)((char*)ws.bn - (char*)nullptr);
+    default: return 0;
+  }
+}
+int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* const* params_host,
+                     const float* additive, int bn_mode, float* running_mean, float* running_var,
+                     long long* num_batches_tracked, double eps, double momentum, float* out, void* workspace,
+                     size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
+                     const double* gathered_stats, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!raw || !out || !workspace) return r2l_fail(-1, "r2l_isp_step_fwd: null pointer");
+  if (bn_mode != R2L_BN_NONE && bn_mode != R2L_BN_TRAIN && bn_mode != R2L_BN_EVAL)
+    return r2l_fail(-1, "r2l_isp_step_fwd: bn_mode must be R2L_BN_NONE, R2L_BN_TRAIN or R2L_BN_EVAL");
+  if (phase != R2L_STEP_ALL && phase != R2L_STEP_A && phase != R2L_STEP_B)
+    return r2l_fail(-1, "r2l_isp_step_fwd: unknown phase");
+  if (nranks < 1 || (nranks > 1 && phase == R2L_STEP_ALL && bn_mode == R2L_BN_TRAIN))
+    return r2l_fail(-1, "r2l_isp_step_fwd: several ranks exchange the statistics between phase A and phase B");
+  if (phase != R2L_STEP_ALL && bn_mode != R2L_BN_TRAIN)
+    return r2l_fail(-1, "r2l_isp_step_fwd: only train-mode BatchNorm has two phases");
+  if (phase == R2L_STEP_B && !gathered_stats) return r2l_fail(-1, "r2l_isp_step_fwd: phase B needs the gathered statistics");
+  if (bn_mode == R2L_BN_EVAL && (!running_mean || !running_var))
+    return r2l_fail(-1, "r2l_isp_step_fwd: eval-mode BatchNorm needs the running statistics");
+  if ((running_mean == nullptr) != (running_var == nullptr))
+    return r2l_fail(-1, "r2l_isp_step_fwd: running_mean and running_var go together");
+  const R2LRaw rw = r2l_raw_any(raw, raw_u16, denom);
+  const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
+  if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_step_fwd: workspace too small (r2l_isp_workspace_bytes)");
+  if (phase != R2L_STEP_B) {
+    if (!params_host) return r2l_fail(-1, "r2l_isp_step_fwd: null parameter table");
+    R2LPackFoldArgs pa;
+    for (int i = 0; i < 9; ++i) {
+      if (!params_host[i]) return r2l_fail(-1, "r2l_isp_step_fwd: null parameter pointer");
+      pa.src[i] = params_host[i];
+    }
+    pa.packed = ws.packed;
+    pa.F = ws.folded;
+    pa.counters = ws.counters;
+    pa.running_mean = bn_mode == R2L_BN_EVAL ? running_mean : nullptr;
+    pa.running_var = running_var;
+    pa.bn = ws.bn;
+    pa.eps = eps;
+    if (int e = r2l_launch_pack_fold(pa, 1, stream)) return e;
+  }
+  if (bn_mode == R2L_BN_TRAIN && phase != R2L_STEP_B) {
+    // statistics pass; one rank: the last workgroup also does the BatchNorm bookkeeping
+    R2LBnFinalizeArgs f{ws.stats, 1, ws.bn, ws.moments, running_mean, running_var, eps, momentum, num_batches_tracked};
+    if (int e = r2l_isp_fwd_impl(rw, ws.packed, additive, nullptr, nullptr, ws.stats, workspace, workspace_bytes, B, H,
+                                 W, R2L_F_STATS_ONLY | R2L_F_FOLDED_VALID, stream, phase == R2L_STEP_ALL ? &f : nullptr))
+      return e;
+    if (phase == R2L_STEP_A) return 0;
+  }
+  if (phase == R2L_STEP_B) {
+    R2LBnFinalizeArgs f{gathered_stats, nranks, ws.bn, ws.moments, running_mean, running_var, eps, momentum,
+                        num_batches_tracked};
+    if (int e = r2l_launch_bn_finalize(f, 1, stream)) return e;
+  }
+  return r2l_isp_fwd_impl(rw, ws.packed, additive, bn_mode == R2L_BN_NONE ? nullptr : ws.bn, out, nullptr, workspace,
+                          workspace_bytes, B, H, W, R2L_F_FOLDED_VALID, stream);
+}
+int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* additive, const float* grad_out,
+                     const float* out, float* grad_params, float* grad_additive, int bn_mode, void* workspace,
+                     size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
+                     const double* gathered_sums, void* stream) {
+  if (int e = r2l_check_dims(B, H, W)) return e;
+  if (!raw || !grad_out || !workspace) return r2l_fail(-1, "r2l_isp_step_bwd: null pointer");
+  if (phase != R2L_STEP_ALL && phase != R2L_STEP_A && phase != R2L_STEP_B)
+    return r2l_fail(-1, "r2l_isp_step_bwd: unknown phase");
+  if (nranks < 1 || (nranks > 1 && phase == R2L_STEP_ALL && bn_mode == R2L_BN_TRAIN))
+    return r2l_fail(-1, "r2l_isp_step_bwd: several ranks exchange the BatchNorm sums between phase A and phase B");
+  if (phase != R2L_STEP_ALL && bn_mode != R2L_BN_TRAIN)
+    return r2l_fail(-1, "r2l_isp_step_bwd: only train-mode BatchNorm has two phases");
+  if (phase == R2L_STEP_B && !gathered_sums) return r2l_fail(-1, "r2l_isp_step_bwd: phase B needs the gathered sums");
+  if (bn_mode == R2L_BN_TRAIN && !out) return r2l_fail(-1, "r2l_isp_step_bwd: train-mode BatchNorm needs the saved output");
+  const R2LRaw rw = r2l_raw_any(raw, raw_u16, denom);
+  const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
+  if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_step_bwd: workspace too small (r2l_isp_workspace_bytes)");
+  const float* bn = bn_mode == R2L_BN_NONE ? nullptr : ws.bn;
+  const float* bn_bwd = bn_mode == R2L_BN_TRAIN ? ws.bn_bwd : nullptr;
+  if (bn_mode == R2L_BN_TRAIN && phase != R2L_STEP_B) {
+    if (int e = r2l_bn_bwd_reduce(grad_out, out, ws.moments, ws.bsums, phase == R2L_STEP_ALL ? ws.bn_bwd : nullptr,
+                                  workspace, workspace_bytes, B, H, W, R2L_F_FOLDED_VALID, stream))
+      return e;
+    if (phase == R2L_STEP_A) return 0;
+  }
+  if (phase == R2L_STEP_B) {
+    R2LBnBwdMeansArgs m{gathered_sums, nranks, ws.moments + 6, ws.bn_bwd};
+    if (int e = r2l_launch_bn_bwd_means(m, 1, stream)) return e;
+  }
+  if (grad_params) {
+    if (int e = r2l_isp_bwd_impl(rw, ws.packed, additive, bn, bn_bwd, grad_out, grad_params, nullptr, workspace,
+                                 workspace_bytes, B, H, W, R2L_F_FOLDED_VALID, stream))
+      return e;
+  }
+  if (grad_additive) return r2l_additive_bwd(grad_out, out, bn, bn_bwd, grad_additive, B, H, W, stream);
+  return 0;
 }
 
 static int r2l_raw2rgb_fwd_impl(const R2LRaw& raw, const float* black_level, float* out, int B, int H, int W,

@@ -38,7 +38,11 @@ R2L_HD r2l_f4 r2l_load_f4_nt(const float* p) { return *(const r2l_f4*)p; }
 #define R2L_LANE_ID 0
 R2L_HD float r2l_wave_shr1(float x) { return x; }
 R2L_HD float r2l_wave_shl1(float x) { return x; }
+R2L_HD float r2l_row_shr1(float x, float edge) { return edge; }
+R2L_HD float r2l_row_shl1(float x, float edge) { return edge; }
 #define R2L_PHASE_BEGIN for (int tid = 0; tid < R2L_NT; ++tid) {
+#define R2L_PHASE_BEGIN_L R2L_PHASE_BEGIN
+#define R2L_PHASE_BEGIN_IF(L) R2L_PHASE_BEGIN
 #define R2L_PHASE_BEGIN_N(NT) for (int tid = 0; tid < (NT); ++tid) {
 #define R2L_PHASE_END }
 #define R2L_TREG_DECL(type, name) type name##_all[R2L_NT]
@@ -74,6 +78,16 @@ R2L_HD float r2l_wave_shr1(float x) {
 R2L_HD float r2l_wave_shl1(float x) {
   const int i = __builtin_bit_cast(int, x);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x130, 0xf, 0xf, false));
+}
+// value of x in the previous / next lane of the 16-lane DPP row (row_shr:1 / row_shl:1); lane 0 resp. lane 15 of
+// the row, which has no such neighbour, gets its own `edge`
+R2L_HD float r2l_row_shr1(float x, float edge) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
+                                                               0x111, 0xf, 0xf, false));
+}
+R2L_HD float r2l_row_shl1(float x, float edge) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
+                                                               0x101, 0xf, 0xf, false));
 }
 // Touched-once streams (a frame read once, an output written once) can take the nontemporal policy.  A pure
 // 4 B : 12 B copy of the static chain's shape gains 5 % from it (tests/probes/stream_probe.hip: 5.2 -> 5.5-5.7
@@ -118,6 +132,22 @@ R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& s) {
 #define R2L_PHASE_BEGIN \
   {                     \
     const int tid = threadIdx.x;
+// R2L_PHASE_BEGIN_L: tid is laundered, so everything the phase derives from it (item maps, LDS addresses, edge
+// flags) is recomputed inside the phase -- a few integer instructions -- instead of being hoisted out of the tile
+// loop and kept live across all other phases.  Worth ~40-80 VGPRs in the tile kernels (fwd 128 -> 99, bwd1 250 ->
+// 211, bwd2 240 -> 163) but ~5 % of their time (profiles/r02_b_lds_ab.txt): used where the registers buy a second
+// workgroup per CU (bwd2), not elsewhere.
+R2L_HD int r2l_phase_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+#define R2L_PHASE_BEGIN_L \
+  {                       \
+    const int tid = r2l_phase_tid();
+#define R2L_PHASE_BEGIN_IF(L) \
+  {                           \
+    const int tid = (L) ? r2l_phase_tid() : (int)threadIdx.x;
 #define R2L_PHASE_BEGIN_N(NT) R2L_PHASE_BEGIN
 // A phase boundary only orders LDS traffic between the waves of the workgroup.  __syncthreads() would
 // also wait for every outstanding global store (s_waitcnt vmcnt(0)), i.e. expose the full HBM write

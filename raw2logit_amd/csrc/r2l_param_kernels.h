@@ -350,7 +350,8 @@ R2L_HD void r2l_window_rows6(const float* Pl, int fy0, int fx, float w[RPI + 2][
 #define R2L_RPI_YP 4
 #endif
 #ifndef R2L_RPI_ADJ
-#define R2L_RPI_ADJ 5
+#define R2L_RPI_ADJ 3  // (5-row items: one wavefront per SIMD, -3 us at one workgroup per CU; 3-row items: a 7 x 8
+                       //  window, which is what lets bwd2 fit 128 VGPRs = two workgroups per CU: 109 -> 97 us)
 #endif
 static_assert(R2L_RPI_Y % 2 == 0, "row parity of the Y phase");
 
@@ -517,6 +518,8 @@ struct R2LTree {
   double* gpartial;       // [nslots][R2L_MAX_GROUPS]
   unsigned* counters;     // [1 + R2L_MAX_GROUPS]; null: no in-kernel reduction
   int split;
+  int nblk1;  // workgroups that wrote `partial` (slots < split), when that was another launch with another grid
+              // (bwd1: one workgroup per CU, bwd2: two); 0 = the grid of this launch
 };
 // Returns true (uniformly over the workgroup) in the ONE workgroup that arrives last; out[0..NSLOTS) then
 // holds the totals.  `out` may be LDS or global memory; lds4: 4 floats of LDS scratch for the tickets;
@@ -539,8 +542,11 @@ R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* ld
   if (tid == 0) tr.counters[1 + g] = 0;
   for (int idx = tid; idx < NSLOTS * gsize; idx += R2L_NT) {
     const int sl = idx / gsize, m = idx - sl * gsize;
-    const float* row = (sl < tr.split) ? tr.partial + (size_t)sl * nblk : tr.partial2 + (size_t)(sl - tr.split) * nblk;
-    sf[idx] = r2l_load_coherent(row + g0 + m);
+    const int n1 = tr.nblk1 > 0 ? tr.nblk1 : nblk;
+    if (sl < tr.split)
+      sf[idx] = (g0 + m < n1) ? r2l_load_coherent(tr.partial + (size_t)sl * n1 + g0 + m) : 0.f;
+    else
+      sf[idx] = r2l_load_coherent(tr.partial2 + (size_t)(sl - tr.split) * nblk + g0 + m);
   }
   R2L_PHASE_END
   R2L_PHASE_BEGIN
@@ -856,6 +862,9 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
   }
 
 
+#ifndef R2L_FWD_L
+#define R2L_FWD_L 16  // phases of the forward tile loop that launder tid (bit 4: the pixel phase): 123 VGPRs, no scratch
+#endif
 template <class G, bool ADD, bool MAYBE_RAGGED, bool U16>
 R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* lds) {
   float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
@@ -874,29 +883,29 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   R2L_PHASE_END
   R2L_STAMP_DECL
   while (have) {
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_IF(R2L_FWD_L & 1)
     r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre), a.raw);
     R2L_PHASE_END
     R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_IF(R2L_FWD_L & 2)
     if (t.border)
       r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     else
       r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
     R2L_STAMP(1)
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_IF(R2L_FWD_L & 4)
     r2l_compute_yp<G>(tid, Y, YP, F);
     R2L_PHASE_END
     R2L_STAMP(2)
     if (t.border) {
-      R2L_PHASE_BEGIN
+      R2L_PHASE_BEGIN_IF(R2L_FWD_L & 8)
       r2l_fill_yp_mirror<G>(tid, YP, t.oy, t.ox, a.H, a.W);
       R2L_PHASE_END
     R2L_STAMP(3)
     }
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_IF(R2L_FWD_L & 16)
     if (haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));  // next tile, in flight
     R2L_PRIO(R2L_PRIO_PIXELS);
     if (MAYBE_RAGGED && t.ragged)
@@ -1306,12 +1315,12 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   R2L_PHASE_END
   R2L_STAMP_DECL
   while (have) {
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre), a.raw);
     R2L_PHASE_END
     R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     // consumed in the pixel phase; one row per stencil phase (six loads per lane at once queue up in the
     // texture-address path and hold every wave at its next instruction)
     if (!MAYBE_RAGGED) r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 0);
@@ -1321,18 +1330,18 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
       r2l_compute_y<G, false>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
     R2L_PHASE_END
     R2L_STAMP(1)
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     if (!MAYBE_RAGGED) r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 1);
     r2l_compute_yp<G>(tid, Y, YP, F);
     R2L_PHASE_END
     R2L_STAMP(2)
     if (t.border) {
-      R2L_PHASE_BEGIN
+      R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
       r2l_fill_yp_mirror<G>(tid, YP, t.oy, t.ox, a.H, a.W);
       R2L_PHASE_END
     R2L_STAMP(3)
     }
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     if (haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
     if (MAYBE_RAGGED && t.ragged)
       r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD, false>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
@@ -1513,41 +1522,53 @@ template <class G, int PY, bool BORDER>
 R2L_HD void r2l_bwd2_row(const float* V, const float* Y, const float* HP, const R2LBwd2Args& a, int tx,
                          int frow, int gy, int gx0, R2LBwd2Regs& regs) {
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
-  float hw[3][6], yw[3][6], vw[3][6];
-  r2l_rows_3x6<G>(HP, tx, frow, hw);
-  r2l_rows_3x6<G>(Y, tx, frow, yw);
-  r2l_rows_3x6<G>(V, tx, frow, vw);
-  if (BORDER) {
-    R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 3; ++i) {
-      const bool rin = (unsigned)(gy - 1 + i) < (unsigned)a.H;
+  // one window at a time (HP, then Y, then V), each consumed before the next is read: at 128 VGPRs (two workgroups
+  // per CU) there is no room for the three of them side by side
+  float gy1[4];  // d loss / d Y (pre-sharpen luma)
+  float gyp[4];  // d loss / d Y' at the 4 pixels
+  {
+    float hw[3][6];
+    r2l_rows_3x6<G>(HP, tx, frow, hw);
+    if (BORDER) {
       R2L_PRAGMA_UNROLL
-      for (int j = 0; j < 6; ++j)
-        hw[i][j] = (rin && (unsigned)(gx0 - 1 + j) < (unsigned)a.W) ? hw[i][j] : 0.f;
+      for (int i = 0; i < 3; ++i) {
+        const bool rin = (unsigned)(gy - 1 + i) < (unsigned)a.H;
+        R2L_PRAGMA_UNROLL
+        for (int j = 0; j < 6; ++j)
+          hw[i][j] = (rin && (unsigned)(gx0 - 1 + j) < (unsigned)a.W) ? hw[i][j] : 0.f;
+      }
+    }
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      float s = 0.f;
+      R2L_PRAGMA_UNROLL
+      for (int i = 0; i < 3; ++i)
+        R2L_PRAGMA_UNROLL
+      for (int j = 0; j < 3; ++j)  // source q = p - (i-1, j-1) -> window index (2-i, c+2-j)
+        s = fmaf(F.sharp[i * 3 + j], hw[2 - i][c + 2 - j], s);
+      const bool valid = !BORDER || ((unsigned)gy < (unsigned)a.H && (unsigned)(gx0 + c) < (unsigned)a.W);
+      gy1[c] = valid ? s : 0.f;
+      gyp[c] = hw[1][c + 1];
     }
   }
-  float gy1[4];  // d loss / d Y (pre-sharpen luma)
-  R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) {
-    float s = 0.f;
+  R2L_SCHED_FENCE();
+  {
+    // d/d sharpening_filter.weight[i][j] = sum_p gY'(p) * Y_zero_ext(p + (i-1, j-1))
+    float yw[3][6];
+    r2l_rows_3x6<G>(Y, tx, frow, yw);
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 3; ++i)
       R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 3; ++j)  // source q = p - (i-1, j-1) -> window index (2-i, c+2-j)
-      s = fmaf(F.sharp[i * 3 + j], hw[2 - i][c + 2 - j], s);
-    const bool valid = !BORDER || ((unsigned)gy < (unsigned)a.H && (unsigned)(gx0 + c) < (unsigned)a.W);
-    gy1[c] = valid ? s : 0.f;
+    for (int j = 0; j < 3; ++j) {
+      float s = regs.acc[R2L_L2_GSHARP + i * 3 + j];
+      R2L_PRAGMA_UNROLL
+      for (int c = 0; c < 4; ++c) s = fmaf(gyp[c], yw[i][c + j], s);
+      regs.acc[R2L_L2_GSHARP + i * 3 + j] = s;
+    }
   }
-  // d/d sharpening_filter.weight[i][j] = sum_p gY'(p) * Y_zero_ext(p + (i-1, j-1)); gY'(p) = hw[1][c+1]
-  R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 3; ++i)
-    R2L_PRAGMA_UNROLL
-  for (int j = 0; j < 3; ++j) {
-    float s = regs.acc[R2L_L2_GSHARP + i * 3 + j];
-    R2L_PRAGMA_UNROLL
-    for (int c = 0; c < 4; ++c) s = fmaf(hw[1][c + 1], yw[i][c + j], s);
-    regs.acc[R2L_L2_GSHARP + i * 3 + j] = s;
-  }
+  R2L_SCHED_FENCE();
+  float vw[3][6];
+  r2l_rows_3x6<G>(V, tx, frow, vw);
   R2L_PRAGMA_UNROLL
   for (int px = 0; px < 2; ++px) {
     R2L_PRAGMA_UNROLL
@@ -1579,6 +1600,13 @@ R2L_HD void r2l_bwd2_pixels(int tid, const float* V, const float* Y, const float
   }
 }
 
+// bwd2 runs TWO workgroups per CU (-DR2L_OCC_BWD2=4, the default): that needs <= 128 VGPRs, which it gets from
+// (i) no software prefetch of the next tile (24 registers; the other workgroup's phases hide the HBM round trip),
+// (ii) 3-row items in the adjoint blur, (iii) one register window at a time in the pixel phase, (iv) R2L_PHASE_BEGIN_L.
+// profiles/r02_c_bwd2_ab.txt: 109 us (round 1) -> 116 us with (iii)+(iv) alone at one workgroup per CU -> 97 us.
+#ifndef R2L_B2_PREFETCH
+#define R2L_B2_PREFETCH 0
+#endif
 template <class G, bool U16>
 R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* lds) {
   float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
@@ -1599,29 +1627,37 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     int tx_, row_;
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
   }
+#if R2L_B2_PREFETCH
   if (have) {
     r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre_v));
     r2l_fetch_tile<G, 1>(tid, a.gypp, t, a.H, a.W, R2L_TREG(pre_g));
   }
+#endif
   R2L_PHASE_END
   R2L_STAMP_DECL
   while (have) {
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_L
+#if !R2L_B2_PREFETCH
+    // two workgroups per CU: the other workgroup's phases hide this tile's HBM round trip, and the 24 registers
+    // of a software prefetch are what keeps the kernel above 128 VGPRs
+    r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre_v));
+    r2l_fetch_tile<G, 1>(tid, a.gypp, t, a.H, a.W, R2L_TREG(pre_g));
+#endif
     r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre_v), a.raw);
     r2l_store_plane_s2<G>(tid, G2, R2L_TREG(pre_g));
     R2L_PHASE_END
     R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_L
     r2l_adjoint_blur<G>(tid, G2, HP, F);
     R2L_PHASE_END
     if (r2l_tail_rows<G>(t.oy, a.H) || r2l_tail_cols<G>(t.ox, a.W)) {  // uniform over the workgroup
-      R2L_PHASE_BEGIN
+      R2L_PHASE_BEGIN_L
       r2l_adjoint_blur_tail<G>(tid, G2, HP, F, t.oy, t.ox, a.H, a.W);
       R2L_PHASE_END
     }
     R2L_STAMP(1)
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_L
     if (t.border) {
       r2l_compute_y<G, true>(tid, V, Y, F, t.oy, t.ox, a.H, a.W);
       r2l_fold_mirror<G>(tid, HP, t.oy, t.ox, a.H, a.W);
@@ -1630,11 +1666,13 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     }
     R2L_PHASE_END
     R2L_STAMP(2)
-    R2L_PHASE_BEGIN
+    R2L_PHASE_BEGIN_L
+#if R2L_B2_PREFETCH
     if (haven) {
       r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre_v));
       r2l_fetch_tile<G, 1>(tid, a.gypp, tn, a.H, a.W, R2L_TREG(pre_g));
     }
+#endif
     if (t.border)
       r2l_bwd2_pixels<G, true>(tid, V, Y, HP, a, t, R2L_TREG(regs));
     else

@@ -19,6 +19,56 @@ R2L_BLOCKFN void r2l_fold_block(const R2LFoldArgs& a, int bid, int nblk, float* 
   R2L_PHASE_END
 }
 
+// Step prologue (r2l_isp_step_fwd): the nine parameter tensors of the module -> the packed block (kept in the
+// workspace: the backward reads the values the forward saw), the folded block, the arrival counters, and in eval
+// mode BatchNorm's (mean, 1/sqrt(var + eps)) from the running statistics.  One launch instead of torch.cat +
+// fold (+ two ATen kernels for the eval statistics).
+struct R2LPackFoldArgs {
+  const float* src[9];  // black_level, white_balance, colour_correction, gamma_correct, debayer.weight,
+                        // sharpening_filter.weight, gaussian_blur.weight, M_RGB_2_YUV, M_YUV_2_RGB
+  float* packed;        // [R2L_P_COUNT]
+  R2LFolded* F;
+  unsigned* counters;
+  const float* running_mean;  // eval mode: -> bn; else null
+  const float* running_var;
+  float* bn;
+  double eps;
+};
+R2L_HD void r2l_pack_slot(int i, int& t, int& o) {
+  const int start[10] = {R2L_P_BLACK_LEVEL, R2L_P_WHITE_BALANCE, R2L_P_CCM, R2L_P_GAMMA, R2L_P_DEBAYER,
+                         R2L_P_SHARPEN, R2L_P_BLUR, R2L_P_M_RGB2YUV, R2L_P_M_YUV2RGB, R2L_P_COUNT};
+  t = 0;
+  for (int k = 1; k < 9; ++k)
+    if (i >= start[k]) t = k;
+  o = i - start[t];
+}
+R2L_BLOCKFN void r2l_pack_fold_block(const R2LPackFoldArgs& a, int bid, int nblk, float* lds) {
+  (void)bid;
+  (void)nblk;
+  float* pl = lds;  // [R2L_P_COUNT]
+  R2L_PHASE_BEGIN
+  if (tid < R2L_P_COUNT) {
+    int t, o;
+    r2l_pack_slot(tid, t, o);
+    const float* src = a.src[0];  // (a select chain, not a dynamically indexed kernel-argument array)
+    R2L_PRAGMA_UNROLL
+    for (int k = 1; k < 9; ++k) src = (t == k) ? a.src[k] : src;
+    const float v = src[o];
+    pl[tid] = v;
+    a.packed[tid] = v;
+  }
+  if (a.counters && tid < 1 + R2L_MAX_GROUPS) a.counters[tid] = 0;
+  if (a.running_mean && tid >= 256 && tid < 259) {
+    const int k = tid - 256;
+    a.bn[k] = a.running_mean[k];
+    a.bn[3 + k] = (float)(1.0 / sqrt((double)a.running_var[k] + a.eps));
+  }
+  R2L_PHASE_END
+  R2L_PHASE_BEGIN
+  if (tid < R2L_FOLDED_NFLOATS) r2l_fold_one(pl, a.F, tid);
+  R2L_PHASE_END
+}
+
 struct R2LUnfoldArgs {
   const float* params;
   const double* sums;  // [R2L_NSUMS]

@@ -158,28 +158,49 @@ def bn_bwd_means(lib, stream, sums, moments, group):
     return bn_bwd
 
 
-def _isp_fwd(lib, raw, denom, *rest):
-    if denom is None:
-        return lib.r2l_isp_fwd(ptr(raw), *rest)
-    return lib.r2l_isp_fwd_u16(ptr(raw), denom, *rest)
+_STEP_ALL, _STEP_A, _STEP_B = 0, 1, 2
+_STEP_STATS, _STEP_MOMENTS, _STEP_BN_SUMS = 0, 1, 2
+_STEP_LAYOUT = {}
+
+
+def _step_layout(lib, B, H, W):
+    """(workspace bytes, byte offsets of the statistics / BatchNorm backward sums inside it) for a frame shape"""
+    key = (lib.path, B, H, W)
+    lay = _STEP_LAYOUT.get(key)
+    if lay is None:
+        lay = (lib.r2l_isp_workspace_bytes(B, H, W), lib.r2l_isp_step_offset(_STEP_STATS, B, H, W),
+               lib.r2l_isp_step_offset(_STEP_BN_SUMS, B, H, W))
+        _STEP_LAYOUT[key] = lay
+    return lay
 
 
 class _IspFused(torch.autograd.Function):
-    """out, batch_moments = f(raw, 7 parameter tensors, M_RGB_2_YUV, M_YUV_2_RGB, additive | None, ...).
-
-    The parameters are packed into the float32[150] block of include/r2l_isp.h inside forward; backward
-    hands each parameter a view of the single 132-float gradient the kernels produce."""
+    """out = f(raw, 7 parameter tensors, M_RGB_2_YUV, M_YUV_2_RGB, additive | None, ...): one C-ABI call for the
+    forward (r2l_isp_step_fwd: parameter gather + fold, BatchNorm statistics pass + bookkeeping, apply pass) and one
+    for the backward (r2l_isp_step_bwd: BatchNorm backward sums, both gradient kernels, additive-layer gradient).
+    The workspace tensor carries the step's state (packed parameters as the forward saw them, folded weights,
+    BatchNorm constants) from one to the other; backward hands each parameter a view of the single 132-float
+    gradient the kernels produce.  With several ranks and train-mode BatchNorm each call splits in two around an
+    all-gather of 7 resp. 6 doubles (RCCL)."""
 
     @staticmethod
     def forward(ctx, raw, bl, wb, ccm, gamma, deb, sharp, blur, m1, m2, additive, bn_mode, bn_module, eps,
                 momentum, group, bits=16):
         raw, denom = _raw_arg(raw, bits)
-        ctx.denom = denom
-        params = (bl, wb, ccm, gamma, deb, sharp, blur)
-        packed = torch.cat([p.detach().reshape(-1) for p in params] +
-                           [m1.reshape(-1), m2.reshape(-1)]).to(torch.float32)
-        if packed.numel() != _lib.R2L_P_COUNT:
-            raise ValueError(f'packed parameter block must have {_lib.R2L_P_COUNT} floats')
+        params = (bl, wb, ccm, gamma, deb, sharp, blur, m1, m2)
+        sizes = (4, 3, 9, 1, 81, 9, 25, 9, 9)
+        table = (ctypes.c_void_p * 9)()
+        keep = []
+        for i, (p, n) in enumerate(zip(params, sizes)):
+            if p.dtype != torch.float32 or p.numel() != n or p.device != raw.device:
+                raise TypeError(f'parameter {i} of the ISP must be {n} float32 values on {raw.device} '
+                                f'(got {tuple(p.shape)} {p.dtype} on {p.device}): the kernels compute in float32 '
+                                f'like the reference; .double() / .half() modules are not supported')
+            q = p.detach()
+            if not q.is_contiguous():
+                q = q.contiguous()
+                keep.append(q)
+            table[i] = q.data_ptr()
         B, H, W = raw.shape
         lib, stream = _lib.library_for(raw)
         if additive is not None:
@@ -187,52 +208,44 @@ class _IspFused(torch.autograd.Function):
             if tuple(additive.shape) != (1, 3, H, W):
                 raise RuntimeError(f'additive_layer {tuple(additive.shape)} does not broadcast to '
                                    f'frames of {H}x{W}')      # same failure the reference has (:213)
-        ws, nws = _workspace(lib, raw, B, H, W)
+        nws, off_stats, off_sums = _step_layout(lib, B, H, W)
         dev = raw.device
-        bn = moments = None
-        folded = 0
-        ctx.totals = None
-        if bn_mode == BN_TRAIN:
-            stats = torch.empty(7, dtype=torch.float64, device=dev)
-            if _group_size(group) == 1:
-                # one rank: statistics + BatchNorm bookkeeping in one launch
-                bn = torch.empty(6, dtype=torch.float32, device=dev)
-                moments = torch.empty(7, dtype=torch.float64, device=dev)
-                rm, rv, nbt = _bn_buffers(bn_module, dev)
-                tail = (ptr(packed), ptr(additive), ptr(stats), ptr(bn), ptr(moments), ptr(rm), ptr(rv), ptr(nbt),
-                        float(eps), float(momentum) if momentum is not None else -1.0, ptr(ws), nws, B, H, W, stream)
-                if denom is None:
-                    lib.check(lib.r2l_isp_fwd_stats_bn(ptr(raw), *tail), 'r2l_isp_fwd_stats_bn')
-                else:
-                    lib.check(lib.r2l_isp_fwd_stats_bn_u16(ptr(raw), denom, *tail), 'r2l_isp_fwd_stats_bn_u16')
-            else:
-                lib.check(_isp_fwd(lib, raw, denom, ptr(packed), ptr(additive), None, None, ptr(stats),
-                                   ptr(ws), nws, B, H, W, _lib.R2L_F_STATS_ONLY, stream), 'r2l_isp_fwd(stats)')
-                gathered, nranks = gather_ranks(stats, group)
-                bn, moments = bn_finalize(lib, stream, gathered, nranks, bn_module, eps, momentum)
-            folded = _lib.R2L_F_FOLDED_VALID
-            ctx.totals = moments       # [6] = pixel count of the global batch
-        elif bn_mode == BN_EVAL:
-            mean = bn_module.running_mean.detach().to(device=dev, dtype=torch.float64)
-            var = bn_module.running_var.detach().to(device=dev, dtype=torch.float64)
-            bn = torch.cat([mean, torch.rsqrt(var + eps)]).to(torch.float32)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         out = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        lib.check(_isp_fwd(lib, raw, denom, ptr(packed), ptr(additive), ptr(bn), ptr(out), None,
-                           ptr(ws), nws, B, H, W, folded, stream), 'r2l_isp_fwd')
+        rm = rv = nbt = None
+        if bn_mode == BN_TRAIN:
+            rm, rv, nbt = _bn_buffers(bn_module, dev)
+        elif bn_mode == BN_EVAL:
+            rm, rv = bn_module.running_mean, bn_module.running_var
+            if rm.device != dev or rm.dtype != torch.float32:
+                raise RuntimeError('BatchNorm buffers must be float32 on the device of the frames')
+        nranks = _group_size(group) if bn_mode == BN_TRAIN else 1
+        mom = float(momentum) if momentum is not None else -1.0
+
+        def call(phase, gathered):
+            lib.check(lib.r2l_isp_step_fwd(ptr(raw), int(denom is not None), denom or 1.0, table, ptr(additive),
+                                           bn_mode, ptr(rm), ptr(rv), ptr(nbt), float(eps), mom, ptr(out), ptr(ws),
+                                           nws, B, H, W, nranks, phase, ptr(gathered), stream), 'r2l_isp_step_fwd')
+        if nranks == 1:
+            call(_STEP_ALL, None)
+        else:
+            call(_STEP_A, None)
+            gathered, _ = gather_ranks(ws[off_stats:off_stats + 56].view(torch.float64), group)
+            call(_STEP_B, gathered)
         ctx.bn_mode = bn_mode
         ctx.group = group
+        ctx.nranks = nranks
+        ctx.denom = denom
+        ctx.off_sums = off_sums
         ctx.has_additive = additive is not None
-        ctx.shapes = [tuple(p.shape) for p in params]
-        ctx.save_for_backward(raw, packed, additive, bn, out)
-        ctx.ws = ws           # holds the folded weights of `packed`: the backward skips re-folding
-        if moments is None:
-            return out, None
-        ctx.mark_non_differentiable(moments)
-        return out, moments
+        ctx.shapes = [tuple(p.shape) for p in params[:7]]
+        ctx.save_for_backward(raw, additive, out)
+        ctx.ws = ws
+        return out
 
     @staticmethod
-    def backward(ctx, gout, _gm):
-        raw, packed, additive, bn, out = ctx.saved_tensors
+    def backward(ctx, gout):
+        raw, additive, out = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise _lib.R2LError(
                 'the fused ISP kernels do not produce d/d raw; gradients w.r.t. the raw frames are '
@@ -241,34 +254,28 @@ class _IspFused(torch.autograd.Function):
         B, H, W = raw.shape
         lib, stream = _lib.library_for(raw)
         ws, nws = ctx.ws, ctx.ws.numel()
-        bn_bwd = None
-        if ctx.bn_mode == BN_TRAIN:
-            sums = torch.empty(6, dtype=torch.float64, device=raw.device)
-            bn_bwd = torch.empty(6, dtype=torch.float32, device=raw.device)
-            lib.check(lib.r2l_bn_bwd_reduce(ptr(gout), ptr(out), ptr(ctx.totals), ptr(sums), ptr(bn_bwd),
-                                            ptr(ws), nws, B, H, W, _lib.R2L_F_FOLDED_VALID, stream),
-                      'r2l_bn_bwd_reduce')
-            if _group_size(ctx.group) > 1:
-                bn_bwd = bn_bwd_means(lib, stream, sums, ctx.totals, ctx.group)
-        grads = [None] * 7
-        if any(ctx.needs_input_grad[1:8]):
-            gp = torch.empty(_lib.R2L_P_NTRAIN, dtype=torch.float32, device=raw.device)
-            if ctx.denom is None:
-                lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(packed), ptr(additive), ptr(bn), ptr(bn_bwd),
-                                          ptr(gout), ptr(gp), None, ptr(ws), nws, B, H, W,
-                                          _lib.R2L_F_FOLDED_VALID, stream), 'r2l_isp_bwd')
+        need_p = any(ctx.needs_input_grad[1:8])
+        need_a = ctx.has_additive and ctx.needs_input_grad[10]
+        gp = torch.empty(_lib.R2L_P_NTRAIN, dtype=torch.float32, device=raw.device) if need_p else None
+        gadd = torch.empty_like(additive) if need_a else None
+        denom = ctx.denom
+
+        def call(phase, gathered):
+            lib.check(lib.r2l_isp_step_bwd(ptr(raw), int(denom is not None), denom or 1.0, ptr(additive), ptr(gout),
+                                           ptr(out), ptr(gp), ptr(gadd), ctx.bn_mode, ptr(ws), nws, B, H, W,
+                                           ctx.nranks, phase, ptr(gathered), stream), 'r2l_isp_step_bwd')
+        if need_p or need_a:
+            if ctx.nranks == 1:
+                call(_STEP_ALL, None)
             else:
-                lib.check(lib.r2l_isp_bwd_u16(ptr(raw), ctx.denom, ptr(packed), ptr(additive), ptr(bn),
-                                              ptr(bn_bwd), ptr(gout), ptr(gp), ptr(ws), nws, B, H, W,
-                                              _lib.R2L_F_FOLDED_VALID, stream), 'r2l_isp_bwd_u16')
+                call(_STEP_A, None)
+                gathered, _ = gather_ranks(ws[ctx.off_sums:ctx.off_sums + 48].view(torch.float64), ctx.group)
+                call(_STEP_B, gathered)
+        grads = [None] * 7
+        if need_p:
             for i, ((_, off, n), shape) in enumerate(zip(PARAM_LAYOUT, ctx.shapes)):
                 if ctx.needs_input_grad[1 + i]:
                     grads[i] = gp[off:off + n].view(shape)
-        gadd = None
-        if ctx.has_additive and ctx.needs_input_grad[10]:
-            gadd = torch.empty_like(additive)
-            lib.check(lib.r2l_additive_bwd(ptr(gout), ptr(out), ptr(bn), ptr(bn_bwd), ptr(gadd), B, H,
-                                           W, stream), 'r2l_additive_bwd')
         return (None, *grads, None, None, gadd, None, None, None, None, None, None)
 
 

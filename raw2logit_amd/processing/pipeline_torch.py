@@ -245,5 +245,4 @@ class ParametrizedProcessing(nn.Module):
             mode = F_.BN_TRAIN      # batch statistics; running statistics are updated on the device
         else:
             mode = F_.BN_EVAL
-        out, _moments = F_.isp_fused(raw, self, mode, self.process_group)
-        return out
+        return F_.isp_fused(raw, self, mode, self.process_group)
