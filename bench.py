@@ -77,9 +77,13 @@ def parse():
     ap.add_argument('--size', type=int, default=None, help='frame height = width (default: 512 parametrized, 1024 static)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--workload', choices=('parametrized', 'static'), default='parametrized',
+    ap.add_argument('--workload', choices=('parametrized', 'static', 'e2e-microscopy', 'e2e-drone'),
+                    default='parametrized',
                     help='parametrized = the headline metric (BASELINE config 2); static = the fused static chain '
-                         'demosaic->WB->CCM->clip->gamma on 256x1024x1024 frames per GPU (BASELINE config 3)')
+                         'demosaic->WB->CCM->clip->gamma on 256x1024x1024 frames per GPU (BASELINE config 3); '
+                         'e2e-microscopy = BASELINE config 4: ISP (Microscopy parameters) + ResNet-18, CE loss, Adam '
+                         'step, 128x256x256 per GPU; e2e-drone = config 5: ISP (Drone parameters) + U-Net, Dice loss, '
+                         '64x256x256 per GPU (512 over 8 GPUs)')
     ap.add_argument('--debayer', choices=('bilinear', 'malvar2004'), default='bilinear')
     ap.add_argument('--sharpening', default='none', help="static workload: 'none' | 'sharpening_filter' | 'unsharp_masking'")
     ap.add_argument('--denoising', default='none', help="static workload: 'none' | 'gaussian_denoising' | 'median_denoising'")
@@ -380,12 +384,103 @@ def main_static(args):
         dist.destroy_process_group()
 
 
+def main_e2e(args):
+    """BASELINE configs 4 / 5: the ISP inside a whole training step (model.py:77-146, train.py:194-236):
+    logits = classifier(processor(raw)); loss; backward; Adam over processor + classifier parameters.  The task
+    models are plain-torch stand-ins on ATen / MIOpen (tests/standin_models.py: torchvision / smp are not in the
+    image and the task models are outside the hot-path scope); with several ranks the classifier is wrapped in
+    DistributedDataParallel (RCCL all-reduce overlapped with its backward), the ISP exchanges its BatchNorm
+    statistics in its own two small all-gathers and its 132-float gradient in one all-reduce."""
+    world, rank, local_rank = _world(args)
+    import torch
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from raw2logit_amd import _lib, cameras
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import standin_models as sm
+    dev = _init_distributed(torch, dist, world, local_rank)
+    lib = _lib.library_for(torch.empty(1, device=dev))[0]
+    clock = Clock(torch, dist, world, dev)
+    micro = args.workload == 'e2e-microscopy'
+    B, S = (args.batch or (128 if micro else 64)), (args.size or 256)
+    gen = torch.Generator(dev).manual_seed(rank)
+    raw = torch.randint(0, 4096, (B, S, S), device=dev, generator=gen, dtype=torch.int32).to(torch.float32) / 4095.0
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    proc = ParametrizedProcessing(cameras.MICROSCOPY if micro else cameras.DRONE, track_stages=False,
+                                  batch_norm_output=True).to(dev).train()
+    if micro:
+        clf = sm.ResNet18(n_classes=16).to(dev).train()
+        target = torch.randint(0, 16, (B,), device=dev, generator=gen)
+
+        def loss_fn(logits):
+            return F.cross_entropy(logits, target)
+    else:
+        clf = sm.SmallUNet().to(dev).train()
+        target = torch.rand((B, S, S), device=dev, generator=gen) > 0.7
+
+        def loss_fn(logits):
+            return sm.dice_loss(logits, target)
+    isp_params = list(proc.parameters())
+    net = clf
+    if world > 1:
+        proc.process_group = dist.group.WORLD
+        if dev.type == 'cuda':
+            net = torch.nn.parallel.DistributedDataParallel(clf, device_ids=[dev.index])
+        else:
+            net = torch.nn.parallel.DistributedDataParallel(clf)
+    opt = torch.optim.Adam(isp_params + list(clf.parameters()), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(net(proc(raw)))
+        loss.backward()
+        if world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in isp_params])
+            dist.all_reduce(flat)
+            flat /= world
+            torch._foreach_copy_([p.grad for p in isp_params],
+                                 [c.view_as(p.grad) for c, p in zip(flat.split([p.numel() for p in isp_params]), isp_params)])
+        opt.step()
+        return loss
+
+    dt = clock.time_steps(step, args.steps, args.warmup)
+    kernels = kernel_times(lib, clock, step, args.steps) if not args.no_roofline else {}
+    isp_us = sum(v['launches'] * v['avg_us'] for v in kernels.values()) / max(args.steps, 1)
+    loss = float(step().item())
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        out = {'metric': 'training-step Mpix/s (raw pixels): ISP fwd+bwd + task model fwd+bwd + Adam',
+               'value': round(world * B * S * S * args.steps / dt / 1e6, 1), 'unit': 'Mpix/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': ('BASELINE config 4: ParametrizedProcessing (Microscopy camera parameters, '
+                                       'BatchNorm train) + ResNet-18 (16 classes), CE loss, Adam'
+                                       if micro else
+                                       'BASELINE config 5: ParametrizedProcessing (Drone camera parameters, BatchNorm '
+                                       'train) + U-Net (1 class), Dice loss, Adam') +
+                                      f', {B}x{S}x{S} 12-bit RGGB frames per GPU; task model = plain-torch stand-in '
+                                      f'(ATen/MIOpen, float32)',
+                          'global_batch': world * B, 'frame': [S, S],
+                          'parallelism': f'data parallel x{world} (DDP on the task model, ISP statistics all-gather + '
+                                         f'132-float all-reduce)' if world > 1 else 'single GPU'},
+               'isp': {'kernels_us_per_step': round(isp_us, 1), 'share_of_step': round(isp_us * 1e-3 / ms, 4),
+                       'kernels': kernels},
+               'loss': loss}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args))           # the parent never touches the GPU
     if args.workload == 'static':
         return main_static(args)
+    if args.workload.startswith('e2e-'):
+        return main_e2e(args)
     world, rank, local_rank = _world(args)
     B, S = (args.batch or 64), (args.size or 512)
     cpu = None

@@ -228,3 +228,89 @@ def test_bench_two_ranks_nccl(dev):
         pytest.skip('needs two GPUs')
     out = _bench(['--gpus', '2', '--steps', '5', '--warmup', '2', '--no-roofline'])
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 128
+
+
+def test_full_size_config4_microscopy(dev):
+    """BASELINE config 4's ISP share at full size: 128 x 256 x 256 frames, Microscopy camera parameters (negative
+    white-balance / colour-matrix entries: most pixels sit on the 1e-5 clip floor), BatchNorm in train mode.
+    The float64 oracle needs minutes for the whole batch, so: (i) train-mode output is normalised; (ii) eval mode
+    with the batch statistics reproduces the train-mode output (frames decouple); (iii) a 2-frame slice in that
+    eval mode -- output and all 132 gradients -- against the oracle; (iv) eval-mode gradients of the whole batch
+    are the sum of the gradients of its four quarters (the sums over 8.4 Mpix are right if the slices are)."""
+    import copy
+    B, H, W = 128, 256, 256
+    raw_np = orc.synth_raw(B, H, W, seed=4, kind='uniform')
+    cot_np = np.random.default_rng(5).standard_normal((B, 3, H, W)).astype(np.float32)
+    raw, cot = torch.from_numpy(raw_np).to(dev), torch.from_numpy(cot_np).to(dev)
+    m = ppt.ParametrizedProcessing(orc.MICROSCOPY_CAMERA_PARAMS, batch_norm_output=True).to(dev).train()
+    m.batch_norm.momentum = 1.0                 # running statistics := this batch's statistics
+    y_tr = m(raw)
+    y_tr.backward(cot)
+    n = B * H * W
+    mean = y_tr.double().mean(dim=(0, 2, 3)).cpu().numpy()
+    var = y_tr.double().var(dim=(0, 2, 3), unbiased=False).cpu().numpy()
+    pc.report('config4/train-mode output: |mean|', np.abs(mean).max(), 1e-4)
+    pc.report('config4/train-mode output: |var - 1|', np.abs(var - 1).max(), 1e-3)
+    assert np.abs(mean).max() < 1e-4 and np.abs(var - 1).max() < 1e-3
+    assert int(m.batch_norm.num_batches_tracked) == 1
+    with torch.no_grad():
+        m.batch_norm.running_var.mul_((n - 1) / n)          # unbiased -> the biased variance train mode used
+    m.eval()
+    for p in m.parameters():
+        p.grad = None
+    y_ev = m(raw)
+    y_ev.backward(cot)
+    e = (y_ev - y_tr).abs().max().item()
+    pc.report('config4/eval mode with the batch statistics vs train mode', e, 2e-5)
+    assert e <= 2e-5
+    g_full = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    # (iii) 2-frame slice against the float64 oracle
+    ms = copy.deepcopy(m)
+    for p in ms.parameters():
+        p.grad = None
+    ys = ms(raw[:2])
+    ys.backward(cot[:2])
+    P = orc.IspParams(orc.MICROSCOPY_CAMERA_PARAMS, dtype=np.float64)
+    bn = dict(training=False, running_mean=m.batch_norm.running_mean.double().cpu().numpy(),
+              running_var=m.batch_norm.running_var.double().cpu().numpy())
+    o, _, c = orc.parametrized_forward(raw_np[:2], P, bn=bn)
+    tol = pc.out_tolerance(c, True)
+    err = np.abs(ys.detach().cpu().numpy() - o)
+    w = np.unravel_index((err / tol).argmax(), err.shape)
+    pc.report('config4/2-frame slice: out vs float64 oracle', err[w], tol[w])
+    assert np.all(err <= tol), (err.max(), w)
+    assert torch.equal(ys, y_ev[:2])
+    g, _, _ = orc.parametrized_backward(P, c, cot_np[:2])
+    lo, _, _ = orc.parametrized_backward(P, c, cot_np[:2], clip_shift=1e-6)
+    hi, _, _ = orc.parametrized_backward(P, c, cot_np[:2], clip_shift=-1e-6)
+    for k, og in g.items():
+        got = pc.NAME2ATTR[k](ms).grad.detach().cpu().numpy().reshape(np.asarray(og).shape)
+        flip = max(np.abs(np.asarray(lo[k]) - og).max(), np.abs(np.asarray(hi[k]) - og).max())
+        lim = 1e-2 * (np.abs(og).max() + 1e-6) + flip
+        e = np.abs(got - og).max()
+        pc.report(f'config4/2-frame slice: grad {k} vs float64 oracle', e, lim)
+        assert e <= lim, (k, e, lim)
+    # (iv) gradients add up over the batch
+    acc = {k: torch.zeros_like(v) for k, v in g_full.items()}
+    for q in range(4):
+        mq = copy.deepcopy(m)
+        for p in mq.parameters():
+            p.grad = None
+        sl = slice(32 * q, 32 * (q + 1))
+        mq(raw[sl]).backward(cot[sl])
+        for k, p in mq.named_parameters():
+            acc[k] += p.grad
+    for k in g_full:
+        scale = g_full[k].abs().max().item() + 1e-6
+        e = (acc[k] - g_full[k]).abs().max().item()
+        pc.report(f'config4/grad {k}: whole batch vs sum of quarters', e, 1e-4 * scale)
+        assert e <= 1e-4 * scale, (k, e, scale)
+
+
+def test_bench_e2e_workloads(dev):
+    """BASELINE configs 4 and 5 end to end on one GPU (ISP + task-model stand-in + loss + Adam step)"""
+    for wl, B in (('e2e-microscopy', 128), ('e2e-drone', 64)):
+        out = _bench(['--workload', wl, '--steps', '3', '--warmup', '2'])
+        assert out['n_gpus'] == 1 and out['config']['global_batch'] == B and out['config']['frame'] == [256, 256]
+        assert np.isfinite(out['loss']) and out['value'] > 0
+        assert 0 < out['isp']['share_of_step'] < 1
