@@ -13,6 +13,7 @@
 #include "r2l_simple_kernels.h"
 #include "r2l_static_kernels.h"
 #include "r2l_static_stream.h"
+#include "r2l_static_chain.h"
 #include "r2l_static_planes.h"
 #include "r2l_staged_kernels.h"
 #include "r2l_aux_kernels.h"
@@ -71,6 +72,22 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
 #define R2L_KERNEL_NT(name, ArgsT, blockfn, NT, WAVES_PER_SIMD)                                 \
   __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void name##_kernel(const ArgsT a) {         \
     blockfn(a, (int)blockIdx.x, (int)gridDim.x, nullptr);                                      \
+  }                                                                                            \
+  static int name(const ArgsT& a, int grid, void* stream) {                                    \
+    R2LTimedLaunch t_;                                                                         \
+    const bool timed_ = r2l_timing_on;                                                         \
+    if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                      \
+    hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);       \
+    if (timed_) r2l_time_end((hipStream_t)stream, t_);                                         \
+    const hipError_t e = hipGetLastError();                                                    \
+    if (e != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(e)); \
+    return 0;                                                                                  \
+  }
+// kernels with their own workgroup size AND static LDS
+#define R2L_KERNEL_NT_LDS(name, ArgsT, NT, LDS_FLOATS, WAVES_PER_SIMD, ...)                    \
+  __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void name##_kernel(const ArgsT a) {         \
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];                             \
+    __VA_ARGS__(a, (int)blockIdx.x, (int)gridDim.x, lds);                                      \
   }                                                                                            \
   static int name(const ArgsT& a, int grid, void* stream) {                                    \
     R2LTimedLaunch t_;                                                                         \
@@ -185,6 +202,27 @@ R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_u16, 1, R2L_RAW_U16, true, 3)
 R2L_STREAM_KERNEL(r2l_launch_static_luma_bilinear_f64, 0, R2L_RAW_F64, true, 3)
 R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_f64, 1, R2L_RAW_F64, true, 2)
 R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
+#ifndef R2L_EMUL
+// row-streaming luma chains (r2l_static_chain.h): NW wavefronts side by side cover frames up to 256 * NW columns
+#ifndef R2L_CHAIN_OCC
+#define R2L_CHAIN_OCC 2
+#endif
+#define R2L_CHAIN_KERNEL(name, NW, RAWK)                                                                  \
+  R2L_KERNEL_NT_LDS(name, R2LStaticChainArgs, (NW) * 64, 2 * R2L_CHAIN_LDS_DOUBLES(NW), R2L_CHAIN_OCC,    \
+                    r2l_static_chain_block<NW, RAWK>)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w1, 1, R2L_RAW_F32)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w2, 2, R2L_RAW_F32)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w4, 4, R2L_RAW_F32)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w8, 8, R2L_RAW_F32)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w1_u16, 1, R2L_RAW_U16)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w2_u16, 2, R2L_RAW_U16)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w4_u16, 4, R2L_RAW_U16)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w8_u16, 8, R2L_RAW_U16)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w1_f64, 1, R2L_RAW_F64)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w2_f64, 2, R2L_RAW_F64)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w4_f64, 4, R2L_RAW_F64)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_w8_f64, 8, R2L_RAW_F64)
+#endif
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
 
@@ -685,9 +723,23 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
 
 // chains the single-launch kernels cover: the short chain (any demosaic) and bilinear + sharpening_filter +
 // gaussian_denoising; everything else runs as luma-plane passes and needs two float64 planes of workspace
+// chains the row-streaming luma-chain kernel covers (r2l_static_chain.h): bilinear + [sharpening_filter] +
+// [gaussian_denoising], frames up to 2048 columns, W % 4 == 0
+static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoising) {
+#ifdef R2L_EMUL
+  (void)W; (void)debayer; (void)sharpening; (void)denoising;
+  return false;  // (lane shifts and wave-level exchange: not expressible in the one-lane-at-a-time emulation)
+#else
+  if (r2l_env_int("R2L_STATIC_TILED", 0)) return false;
+  return debayer == R2L_DEBAYER_BILINEAR && (W & 3) == 0 && W <= 2048 &&
+         (sharpening == R2L_SHARPEN_NONE || sharpening == R2L_SHARPEN_FILTER) &&
+         (denoising == R2L_DENOISE_NONE || denoising == R2L_DENOISE_GAUSSIAN) &&
+         !(sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE);
+#endif
+}
 static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoising, bool f64_frames = false) {
   if (sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE) return true;
-  (void)W;
+  if (r2l_static_is_chain(W, debayer, sharpening, denoising)) return true;
   if (f64_frames) return false;  // the tile kernel of the default chain stages float32 frames in LDS
   return debayer == R2L_DEBAYER_BILINEAR && sharpening == R2L_SHARPEN_FILTER && denoising == R2L_DENOISE_GAUSSIAN;
 }
@@ -725,6 +777,31 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
   R2LStaticArgs a;
   r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma);
   const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
+#ifndef R2L_EMUL
+  if (r2l_static_is_chain(W, debayer, sharpening, denoising)) {
+    R2LStaticChainArgs ca;
+    ca.s = a;
+    // bands of ~64 rows (7 rows of halo are recomputed per band); at least ~2 workgroups per CU
+    int rows = r2l_env_int("R2L_CHAIN_BAND", 64);
+    long nband = (H + rows - 1) / rows;
+    if (nband < 1) nband = 1;
+    ca.band_h = (int)((H + nband - 1) / nband);
+    ca.band_h += ca.band_h & 1;  // bands start on even rows
+    ca.nband = (H + ca.band_h - 1) / ca.band_h;
+    const long grid = (long)B * ca.nband;
+    if (grid > (1L << 30)) return r2l_fail(-1, "r2l_static_fwd: batch too large");
+    const int nw = W <= 256 ? 1 : (W <= 512 ? 2 : (W <= 1024 ? 4 : 8));
+    const int kind = raw.u16 ? 1 : (raw.f64 ? 2 : 0);
+    typedef int (*launch_t)(const R2LStaticChainArgs&, int, void*);
+    static const launch_t table[3][4] = {
+        {r2l_launch_static_chain_w1, r2l_launch_static_chain_w2, r2l_launch_static_chain_w4, r2l_launch_static_chain_w8},
+        {r2l_launch_static_chain_w1_u16, r2l_launch_static_chain_w2_u16, r2l_launch_static_chain_w4_u16,
+         r2l_launch_static_chain_w8_u16},
+        {r2l_launch_static_chain_w1_f64, r2l_launch_static_chain_w2_f64, r2l_launch_static_chain_w4_f64,
+         r2l_launch_static_chain_w8_f64}};
+    return table[kind][nw == 1 ? 0 : (nw == 2 ? 1 : (nw == 4 ? 2 : 3))](ca, (int)grid, stream);
+  }
+#endif
   if (!r2l_static_is_fused(W, debayer, sharpening, denoising, raw.f64 != nullptr)) {
     // luma-plane passes: raw -> Y | sharpen | denoise | raw + Y'' -> RGB
     if (W & 3) return r2l_fail(-4, "r2l_static_fwd: this chain runs as plane passes, which need W % 4 == 0");

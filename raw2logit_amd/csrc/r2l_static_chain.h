@@ -1,0 +1,281 @@
+// r2l_static_chain.h -- the static chains WITH a luma stencil chain as one row-streaming kernel:
+//
+//   remove_blacklv -> demosaicing_CFA_Bayer_bilinear -> white balance -> colour matrix -> rgb2yuv ->
+//   [sharpening_filter: Y <- convolve2d(Y, K, 'same', fill 0)] -> [gaussian_denoising: Y <- gaussian_filter(Y, 0.5)]
+//   -> yuv2rgb -> clip[0,1] -> x ** (1/gamma)
+//
+// i.e. processing() (pipeline_numpy.py:70-141) with the default chain of train.py:96-101 (and the chains with only
+// one of the two luma filters).  Round 1 ran this as an LDS tile kernel (r2l_static_block: float64 planes, 115 KB
+// of LDS, one workgroup per CU, 21 % of the HBM peak).  Here, like the short chain (r2l_static_stream.h), every
+// wavefront is a line-buffer ISP: it owns a strip of 256 columns (4 per lane) and a band of rows, walks down the
+// band and keeps in registers
+//     the last 3 raw rows (float64, black level removed)            -> bilinear demosaic of the middle row
+//     the last 3 luma rows Y                                         -> 5-point sharpen  Y'
+//     a ring of 6 horizontally blurred rows  Hb = g (*)_x Y'          -> vertical 5-tap blur  Y''
+// and in a wave-private LDS ring the chroma (U, V) of the last 4 rows, which waits 3 rows for its luma.  The halo
+// of the luma chain is 1 + 2 columns each side: inside a wavefront the neighbour columns come from the
+// neighbouring lanes (DPP wave shifts); at the strip edges lane 0 / lane 63 exchange them with the neighbouring
+// wavefront of the workgroup through LDS -- 6 float64 values per wavefront and row, one barrier per row (the
+// wavefronts of a workgroup cover one image row side by side and advance in lock step; the workgroups of a CU
+// are at different rows, so the barrier of one is filled by the others).  Row latency: raw row q+1 gives Y(q),
+// Y'(q-1), Hb(q-1) and the finished output row q-3; a band re-computes 7 rows of halo.
+// Algorithmic traffic: 4 B in + 12 B out per pixel, like the short chain.  Linear part in float64 (see
+// r2l_static_kernels.h), log2 / exp2 in float32.
+#pragma once
+#include "r2l_static_stream.h"
+
+#ifndef R2L_EMUL
+
+#ifndef R2L_CHAIN_PF
+#define R2L_CHAIN_PF 3
+#endif
+
+struct R2LStaticChainArgs {
+  R2LStaticArgs s;
+  int nband, band_h;
+};
+
+// float64 value of x in the previous / next lane of the wavefront; lane 0 / lane 63 get `edge`
+R2L_HD double r2l_wave_shr1_d(double x, double edge) {
+  const unsigned long long xu = __builtin_bit_cast(unsigned long long, x), eu = __builtin_bit_cast(unsigned long long, edge);
+  const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)eu, (int)(unsigned)xu, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(eu >> 32), (int)(unsigned)(xu >> 32), 0x138, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+R2L_HD double r2l_wave_shl1_d(double x, double edge) {
+  const unsigned long long xu = __builtin_bit_cast(unsigned long long, x), eu = __builtin_bit_cast(unsigned long long, edge);
+  const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)eu, (int)(unsigned)xu, 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(eu >> 32), (int)(unsigned)(xu >> 32), 0x130, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+#define R2L_CHAIN_EX 8                                  // doubles per wavefront and buffer in the exchange area
+#define R2L_CHAIN_FIFO_DOUBLES (4 * 4 * 64 * 2)         // 4 rows x (U[4], V[4]) x 64 lanes = 16 KB per wavefront
+#define R2L_CHAIN_LDS_DOUBLES(NW) (2 * (NW) * R2L_CHAIN_EX + (NW) * R2L_CHAIN_FIFO_DOUBLES)
+
+// per-lane state of the luma chain
+struct R2LChainState {
+  double rw[3][8];   // raw rows (slot = row mod 3): columns x0-2 .. x0+5, black level removed
+  double yr[3][4];   // luma rows (slot = row mod 3)
+  double yl, yrr;    // left / right neighbour of the luma row q-1 (zero outside the image)
+  double hb[6][4];   // horizontally blurred sharpened luma (slot = row mod 6)
+};
+
+// One step of the pipeline: raw row q+1 has just entered the window (slot (K+1)%3 of rw).  K = q mod 6, a
+// compile-time constant of the 6-fold unrolled loop, makes every register-array index a constant.
+template <int NW, int K>
+R2L_HD void r2l_chain_step(const R2LStaticArgs& a, R2LChainState& st, int q, int y0, int y1, bool le, bool re,
+                           int wave, int lane, double* ex, r2l_d2* fifo, float* outb, size_t plane, int x0,
+                           bool store_ok) {
+  constexpr int PY = K & 1;
+  const int H = a.H;
+  double* yq = st.yr[K % 3];                 // Y(q)   (new)
+  const double* ym = st.yr[(K + 2) % 3];     // Y(q-1)
+  const double* yu = st.yr[(K + 1) % 3];     // Y(q-2)
+  const bool qin = (unsigned)q < (unsigned)H;
+  // ---- demosaic + colour of row q: Y(q) to the window, (U, V)(q) to the LDS ring ---------------------------
+  {
+    double d[4][3];
+    const double* u = st.rw[(K + 2) % 3];    // raw row q-1
+    const double* m = st.rw[K % 3];          // raw row q
+    const double* l = st.rw[(K + 1) % 3];    // raw row q+1
+    if (q > 0 && q < H - 1) {
+      r2l_stream_bilinear_row_interior<PY>(u, m, l, le, re, d);
+    } else {
+      // first / last image row: a mirrored row carries the sites of the row it came from
+      const int tpy[3] = {r2l_symmetric(q - 1, H) & 1, r2l_symmetric(q, H) & 1, r2l_symmetric(q + 1, H) & 1};
+      r2l_stream_bilinear_row(u, m, l, tpy, le, re, d);
+    }
+    r2l_d2 uv[4];
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      const double y = fma(a.T[0], d[c][0], fma(a.T[1], d[c][1], a.T[2] * d[c][2]));
+      uv[c].x = fma(a.T[3], d[c][0], fma(a.T[4], d[c][1], a.T[5] * d[c][2]));
+      uv[c].y = fma(a.T[6], d[c][0], fma(a.T[7], d[c][1], a.T[8] * d[c][2]));
+      yq[c] = qin ? y : 0.0;                 // convolve2d(..., fillvalue=0): no luma outside the image
+    }
+    r2l_d2* f = fifo + (size_t)(q & 3) * 4 * 64 + lane;  // [row slot][c][lane]: 16-byte lane stride, conflict-free
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) f[c * 64] = uv[c];
+  }
+  // ---- Y'(q-1) = sharpen: centre cross of a.ksharp (the corners of both K and the identity are zero) --------
+  double yp[4];
+  {
+    const double kc = a.ksharp[4], kl = a.ksharp[3], kr = a.ksharp[5], ku = a.ksharp[1], kd = a.ksharp[7];
+    // convolve2d flips the kernel: out(p) = sum K[i][j] * Y(p - (i-1, j-1))  ->  K[1][0] weighs the RIGHT
+    // neighbour, K[0][1] the row BELOW
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      const double left = (c > 0) ? ym[c > 0 ? c - 1 : 0] : st.yl, right = (c < 3) ? ym[c < 3 ? c + 1 : 3] : st.yrr;
+      yp[c] = fma(kc, ym[c], fma(kl, right, fma(kr, left, fma(ku, yq[c], kd * yu[c]))));
+    }
+  }
+  // ---- strip edges: this wavefront's edge columns to LDS, the neighbours' back ----------------------------
+  double rl_y = 0.0, rl_p2 = 0.0, rl_p3 = 0.0;  // from the left wavefront: its Y(q)[col 3], Y'(q-1)[cols 2, 3]
+  double rr_y = 0.0, rr_p0 = 0.0, rr_p1 = 0.0;  // from the right wavefront: its Y(q)[col 0], Y'(q-1)[cols 0, 1]
+  if (NW > 1) {
+    double* mine = ex + ((q & 1) * NW + wave) * R2L_CHAIN_EX;
+    if (lane == 0) {
+      mine[0] = yq[0];
+      mine[1] = yp[0];
+      mine[2] = yp[1];
+    }
+    if (lane == 63) {
+      mine[3] = yq[3];
+      mine[4] = yp[2];
+      mine[5] = yp[3];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (lane == 0 && wave > 0) {
+      const double* o = mine - R2L_CHAIN_EX;
+      rl_y = o[3];
+      rl_p2 = o[4];
+      rl_p3 = o[5];
+    }
+    if (lane == 63 && wave < NW - 1) {
+      const double* o = mine + R2L_CHAIN_EX;
+      rr_y = o[0];
+      rr_p0 = o[1];
+      rr_p1 = o[2];
+    }
+  }
+  // neighbours of Y(q) for the next step's sharpen (zero outside the image)
+  {
+    const double l = r2l_wave_shr1_d(yq[3], rl_y), r = r2l_wave_shl1_d(yq[0], rr_y);
+    st.yl = le ? 0.0 : l;
+    st.yrr = re ? 0.0 : r;
+  }
+  // ---- Hb(q-1): horizontal pass of gaussian_filter over Y'(q-1), scipy 'reflect' = symmetric columns --------
+  if ((unsigned)(q - 1) < (unsigned)H) {
+    double e[8];
+    const double l2 = r2l_wave_shr1_d(yp[2], rl_p2), l1 = r2l_wave_shr1_d(yp[3], rl_p3);
+    const double r1 = r2l_wave_shl1_d(yp[0], rr_p0), r2 = r2l_wave_shl1_d(yp[1], rr_p1);
+    e[0] = le ? yp[1] : l2;
+    e[1] = le ? yp[0] : l1;
+    e[2] = yp[0];
+    e[3] = yp[1];
+    e[4] = yp[2];
+    e[5] = yp[3];
+    e[6] = re ? yp[3] : r1;
+    e[7] = re ? yp[2] : r2;
+    double* h = st.hb[(K + 5) % 6];          // slot of row q-1
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c)
+      h[c] = fma(a.gk[2], e[c + 2], fma(a.gk[1], e[c + 1] + e[c + 3], a.gk[0] * (e[c] + e[c + 4])));
+  }
+  // ---- output row y = q-3: vertical pass over Hb(y-2 .. y+2), symmetric rows; chroma from the ring ---------
+  const int y = q - 3;
+  if (y >= y0 && y < y1) {
+    // weights of the 5 window rows: a row outside the image gives its weight to its mirror image
+    double wv[5];
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 5; ++k) wv[k] = ((unsigned)(y + k - 2) < (unsigned)H) ? a.gk[k] : 0.0;
+    if (y < 2 || y > H - 3) {
+      R2L_PRAGMA_UNROLL
+      for (int k = 0; k < 5; ++k) {
+        const int r = y + k - 2;
+        if ((unsigned)r >= (unsigned)H) {
+          const int t = r2l_symmetric(r, H) - (y - 2);  // window slot of the mirror image
+          R2L_PRAGMA_UNROLL
+          for (int j = 0; j < 5; ++j) wv[j] += (j == t) ? a.gk[k] : 0.0;
+        }
+      }
+    }
+    // rows y-2..y+2 sit in slots (K + 1 .. K + 5) % 6  (row q-1 = y+2 is slot (K+5)%6)
+    const double* h0 = st.hb[(K + 1) % 6];
+    const double* h1 = st.hb[(K + 2) % 6];
+    const double* h2 = st.hb[(K + 3) % 6];
+    const double* h3 = st.hb[(K + 4) % 6];
+    const double* h4 = st.hb[(K + 5) % 6];
+    const r2l_d2* f = fifo + (size_t)(y & 3) * 4 * 64 + lane;
+    float x[3][4];
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      const double yy = fma(wv[0], h0[c], fma(wv[1], h1[c], fma(wv[2], h2[c], fma(wv[3], h3[c], wv[4] * h4[c]))));
+      const r2l_d2 uv = f[c * 64];
+      R2L_PRAGMA_UNROLL
+      for (int k = 0; k < 3; ++k) {
+        const double rgb = fma(a.M2[k * 3], yy, fma(a.M2[k * 3 + 1], uv.x, a.M2[k * 3 + 2] * uv.y));
+        x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
+      }
+    }
+    if (store_ok) {
+      const size_t off = (size_t)y * a.W + x0;
+      R2L_PRAGMA_UNROLL
+      for (int k = 0; k < 3; ++k) {
+        r2l_f4 s4;
+        s4.x = x[k][0];
+        s4.y = x[k][1];
+        s4.z = x[k][2];
+        s4.w = x[k][3];
+        r2l_stream_store_f4(outb + (size_t)k * plane + off, s4);
+      }
+    }
+  }
+}
+
+template <int NW, int RAWK>
+R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, int nblk, float* lds_f) {
+  (void)nblk;
+  const R2LStaticArgs& a = ca.s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double* ex = (double*)lds_f;
+  r2l_d2* fifo = (r2l_d2*)(ex + 2 * NW * R2L_CHAIN_EX) + (size_t)wave * (R2L_CHAIN_FIFO_DOUBLES / 2);
+  const int band = bid % ca.nband, b = bid / ca.nband;
+  const int y0 = band * ca.band_h;
+  const int y1 = (y0 + ca.band_h < a.H) ? y0 + ca.band_h : a.H;
+  const int xs = wave * 256 + 4 * lane;
+  const bool store_ok = xs < a.W;
+  const int x0 = store_ok ? xs : a.W - 4;  // lanes beyond the image edge shadow the last column group
+  const bool le = x0 == 0, re = x0 + 4 >= a.W;
+  const size_t plane = (size_t)a.H * a.W;
+  const size_t img = (size_t)b * plane;
+  float* outb = a.out + (size_t)b * 3 * plane;
+  R2LChainState st;
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 6; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) st.hb[i][c] = 0.0;  // rows outside the image are never written: they stay finite
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) st.yr[i][c] = 0.0;
+  st.yl = st.yrr = 0.0;
+  // first luma row computed: q0 <= y0 - 3 (Hb(y0-2) needs Y'(y0-2) needs Y(y0-3)), rounded down to a multiple of 6
+  // so that q mod 6 is the unroll position; last: y1 + 2
+  int q0 = y0 - 3;
+  q0 = (q0 >= 0) ? q0 - q0 % 6 : -(((-q0) + 5) / 6) * 6;
+  const int q1 = y1 + 3;  // exclusive
+  constexpr bool LANES = R2L_HAVE_LANE_SHIFTS;
+  constexpr int PF = R2L_CHAIN_PF;
+  R2LRowStageT<RAWK> stage;
+  // warm-up: raw rows q0-1 and q0 into slots (q0-1) mod 3 = 2 and q0 mod 3 = 0
+  r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 - 1, a.H), x0, le, re, stage);
+  r2l_stream_convert_row<RAWK, LANES>(a, stage, le, re, st.rw[2]);
+  r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0, a.H), x0, le, re, stage);
+  r2l_stream_convert_row<RAWK, LANES>(a, stage, le, re, st.rw[0]);
+  R2LRowStageT<RAWK> pf[PF];  // pf[i] = raw row q + 1 + i
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i) r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 + 1 + i, a.H), x0, le, re, pf[i]);
+  for (int qb = q0; qb < q1; qb += 6) {
+#define R2L_CHAIN_STEP(K)                                                                                         \
+  if (qb + K < q1) {                                                                                              \
+    const int q = qb + K;                                                                                         \
+    r2l_stream_convert_row<RAWK, LANES>(a, pf[0], le, re, st.rw[(K + 1) % 3]);                                    \
+    R2L_PRAGMA_UNROLL                                                                                             \
+    for (int i = 0; i + 1 < PF; ++i) pf[i] = pf[i + 1];                                                           \
+    if (q + 1 + PF < q1 + 1)                                                                                      \
+      r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q + 1 + PF, a.H), x0, le, re, pf[PF - 1]);          \
+    r2l_chain_step<NW, K>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, outb, plane, x0, store_ok);            \
+  }
+    R2L_CHAIN_STEP(0)
+    R2L_CHAIN_STEP(1)
+    R2L_CHAIN_STEP(2)
+    R2L_CHAIN_STEP(3)
+    R2L_CHAIN_STEP(4)
+    R2L_CHAIN_STEP(5)
+#undef R2L_CHAIN_STEP
+  }
+}
+
+#endif  // !R2L_EMUL

@@ -191,16 +191,17 @@ class _IspFused(torch.autograd.Function):
         sizes = (4, 3, 9, 1, 81, 9, 25, 9, 9)
         table = (ctypes.c_void_p * 9)()
         keep = []
-        for i, (p, n) in enumerate(zip(params, sizes)):
-            if p.dtype != torch.float32 or p.numel() != n or p.device != raw.device:
-                raise TypeError(f'parameter {i} of the ISP must be {n} float32 values on {raw.device} '
+        f32, rdev = torch.float32, raw.device
+        for i in range(9):
+            p = params[i]
+            if p.dtype is not f32 or p.numel() != sizes[i] or p.device != rdev:
+                raise TypeError(f'parameter {i} of the ISP must be {sizes[i]} float32 values on {rdev} '
                                 f'(got {tuple(p.shape)} {p.dtype} on {p.device}): the kernels compute in float32 '
                                 f'like the reference; .double() / .half() modules are not supported')
-            q = p.detach()
-            if not q.is_contiguous():
-                q = q.contiguous()
-                keep.append(q)
-            table[i] = q.data_ptr()
+            if not p.is_contiguous():
+                p = p.detach().contiguous()
+                keep.append(p)
+            table[i] = p.data_ptr()
         B, H, W = raw.shape
         lib, stream = _lib.library_for(raw)
         if additive is not None:

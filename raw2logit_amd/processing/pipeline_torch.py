@@ -146,6 +146,72 @@ class Debayer(nn.Conv2d):
         self.weight.data[2, 2] = K_RB.clone()
 
 
+class _LazyStages(dict):
+    """``stages`` after a call on the fused kernels.  The fused path keeps every intermediate in LDS / registers,
+    so unlike the reference (:183-214) it has no stage tensors to put into the dict; they are computed by the
+    stage-by-stage kernels (no grad) the first time anybody looks into the dict, from the frames of that call --
+    callers that never read ``stages`` pay nothing, callers that do see what the reference shows them.  (The
+    frames of the last call stay referenced until the next call.  If a parameter was modified in between, the
+    stages of that call can no longer be reproduced and the access raises; track_stages=True materialises them
+    during the call, gradients included.)"""
+
+    def __init__(self, module, raw):
+        super().__init__()
+        self._pending = (module, raw, tuple(p._version for p in module.parameters()))
+
+    def _fill(self):
+        if self._pending is None:
+            return
+        module, raw, versions = self._pending
+        self._pending = None
+        if versions != tuple(p._version for p in module.parameters()):
+            raise RuntimeError('processor.stages of a fused forward call were read after the parameters changed; '
+                               'use track_stages=True to materialise the stages during the call')
+        from ..staged import staged_forward
+        with torch.no_grad():
+            staged_forward(module, raw.detach(), stages=self, with_batch_norm=False)
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def __contains__(self, k):
+        self._fill()
+        return super().__contains__(k)
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def get(self, k, default=None):
+        self._fill()
+        return super().get(k, default)
+
+    def __repr__(self):
+        self._fill()
+        return super().__repr__()
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (dict(self),))
+
+
 class ParametrizedProcessing(nn.Module):
     """Differentiable processing pipeline, reference :134-225, as fused gfx950 kernels.
 
@@ -216,8 +282,9 @@ class ParametrizedProcessing(nn.Module):
     def forward(self, raw):
         assert raw.ndim == 3, f"needs dims (B, H, W), got {raw.shape}"
 
-        self.stages = {}
-        self.buffer = {}
+        d = self.__dict__          # (plain attributes: nn.Module.__setattr__ costs microseconds per step)
+        d['stages'] = {}
+        d['buffer'] = {}
 
         # The fused kernels keep every intermediate in LDS / registers: they neither materialise the stage
         # tensors nor produce d/d raw.  Whenever a caller can observe either (track_stages=True, or frames
@@ -228,6 +295,7 @@ class ParametrizedProcessing(nn.Module):
             rgb = staged_forward(self, raw)
         else:
             rgb = self._fused_forward(raw)
+            d['stages'] = _LazyStages(self, raw)
 
         if self.track_stages and raw.requires_grad:
             for stage in self.stages.values():

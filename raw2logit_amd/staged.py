@@ -233,32 +233,34 @@ class _BatchNorm(torch.autograd.Function):
         return gx, None, None, None
 
 
-def staged_forward(module, raw):
-    """The body of ParametrizedProcessing.forward (:183-217), stage by stage; fills module.stages."""
+def staged_forward(module, raw, stages=None, with_batch_norm=True):
+    """The body of ParametrizedProcessing.forward (:183-217), stage by stage; fills module.stages (or `stages`)."""
     m = module
+    if stages is None:
+        stages = m.stages
     rgb = raw2rgb_bits(raw, m.black_level, False, 3, getattr(m, 'raw_bits', 16))          # :183
-    m.stages['demosaic'] = rgb
+    stages['demosaic'] = rgb
     rgb = _Conv33.apply(rgb, m.debayer.weight)                                           # :187
     rgb = _Mix3.apply(rgb, torch.diag(m.white_balance.reshape(3)))                       # :190
     rgb = _Mix3.apply(rgb, m.colour_correction)                                          # :191
-    m.stages['color_correct'] = rgb
+    stages['color_correct'] = rgb
     yuv = _Mix3.apply(rgb, m.M_RGB_2_YUV)                                                # :194
     yuv = _PlaneConv.apply(yuv, m.sharpening_filter.weight, False)                       # :195
     if m.track_stages:  # the reference takes the YUV->RGB->YUV round trip only then (:197-200)
         rgb = _Mix3.apply(yuv, m.M_YUV_2_RGB)                                            # :198
-        m.stages['sharpening'] = rgb
+        stages['sharpening'] = rgb
         yuv = _Mix3.apply(rgb, m.M_RGB_2_YUV)                                            # :200
     yuv = _PlaneConv.apply(yuv, m.gaussian_blur.weight, True)                            # :202
     rgb = _Mix3.apply(yuv, m.M_YUV_2_RGB)                                                # :203
-    m.stages['gaussian'] = rgb
+    stages['gaussian'] = rgb
     rgb = _Clip.apply(rgb)                                                               # :206
-    m.stages['clipped'] = rgb
+    stages['clipped'] = rgb
     rgb = _Gamma.apply(rgb, m.gamma_correct)                                             # :209
-    m.stages['gamma_correct'] = rgb
+    stages['gamma_correct'] = rgb
     if m.additive_layer is not None:                                                     # :212-214
         rgb = _Add.apply(rgb, m.additive_layer)
-        m.stages['noise'] = rgb
-    if m.batch_norm is not None:                                                         # :216-217
+        stages['noise'] = rgb
+    if m.batch_norm is not None and with_batch_norm:                                     # :216-217
         bn = m.batch_norm
         training = bn.training or bn.running_mean is None
         rgb = _BatchNorm.apply(rgb, bn, training, m.process_group)

@@ -128,6 +128,15 @@ def check_param_case(case, golden, device):
                1e-5 * (max(1.0, float(np.max(cache['istd']))) if case['bn'] else 1.0))
     assert np.all(err <= tol), (case['name'], 'out vs oracle', err.max(), np.unravel_index(err.argmax(), err.shape))
     assert m.buffer['processed_rgb'] is y
+    if not case['track']:
+        # `stages` after a fused call: filled on first access, same keys / tensors as the reference's (:183-214)
+        assert list(m.stages.keys()) == list(g[pre + 'stage_keys']), (list(m.stages.keys()), list(g[pre + 'stage_keys']))
+        for k, st in m.stages.items():
+            assert not st.requires_grad
+            se = np.abs(_sample(st.cpu().numpy(), full) - g[pre + 'stage/' + k]).max()
+            lim = 2e-4 if k in ('gamma_correct', 'noise') else 2e-6 * max(1.0, float(np.abs(g[pre + 'stage/' + k]).max()))
+            report(f'param/{case["name"]}/lazy stage {k} vs reference (golden)', se, lim)
+            assert se <= lim, (case['name'], k, se)
 
     # golden vectors of the reference (track_stages=True adds a YUV<->RGB round trip worth ~1e-7)
     gerr = np.abs(_sample(out, full) - g[pre + 'out'])

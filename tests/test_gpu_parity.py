@@ -247,8 +247,8 @@ def test_full_size_config4_microscopy(dev):
     y_tr = m(raw)
     y_tr.backward(cot)
     n = B * H * W
-    mean = y_tr.double().mean(dim=(0, 2, 3)).cpu().numpy()
-    var = y_tr.double().var(dim=(0, 2, 3), unbiased=False).cpu().numpy()
+    mean = y_tr.detach().double().mean(dim=(0, 2, 3)).cpu().numpy()
+    var = y_tr.detach().double().var(dim=(0, 2, 3), unbiased=False).cpu().numpy()
     pc.report('config4/train-mode output: |mean|', np.abs(mean).max(), 1e-4)
     pc.report('config4/train-mode output: |var - 1|', np.abs(var - 1).max(), 1e-3)
     assert np.abs(mean).max() < 1e-4 and np.abs(var - 1).max() < 1e-3
@@ -260,7 +260,7 @@ def test_full_size_config4_microscopy(dev):
         p.grad = None
     y_ev = m(raw)
     y_ev.backward(cot)
-    e = (y_ev - y_tr).abs().max().item()
+    e = (y_ev.detach() - y_tr.detach()).abs().max().item()
     pc.report('config4/eval mode with the batch statistics vs train mode', e, 2e-5)
     assert e <= 2e-5
     g_full = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
@@ -279,7 +279,7 @@ def test_full_size_config4_microscopy(dev):
     w = np.unravel_index((err / tol).argmax(), err.shape)
     pc.report('config4/2-frame slice: out vs float64 oracle', err[w], tol[w])
     assert np.all(err <= tol), (err.max(), w)
-    assert torch.equal(ys, y_ev[:2])
+    assert torch.equal(ys.detach(), y_ev.detach()[:2])
     g, _, _ = orc.parametrized_backward(P, c, cot_np[:2])
     lo, _, _ = orc.parametrized_backward(P, c, cot_np[:2], clip_shift=1e-6)
     hi, _, _ = orc.parametrized_backward(P, c, cot_np[:2], clip_shift=-1e-6)
@@ -314,3 +314,31 @@ def test_bench_e2e_workloads(dev):
         assert out['n_gpus'] == 1 and out['config']['global_batch'] == B and out['config']['frame'] == [256, 256]
         assert np.isfinite(out['loss']) and out['value'] > 0
         assert 0 < out['isp']['share_of_step'] < 1
+
+
+@pytest.mark.parametrize('shape', [(2, 130, 516), (1, 70, 1024), (1, 36, 1028), (1, 24, 2048), (3, 66, 260),
+                                   (1, 4, 8), (1, 200, 256)], ids=str)
+def test_static_luma_chain_streaming_kernel(shape, dev):
+    """the row-streaming luma-chain kernel (r2l_static_chain.h) on frames 1, 2, 4 and 8 wavefronts wide, several
+    bands high, partially filled last wavefront: every chain it serves, float32 / 16-bit / float64 frames, against
+    the oracle (the reference's own arithmetic on scipy)"""
+    from raw2logit_amd import functional as F_
+    B, H, W = shape
+    u = np.random.default_rng(W + H).integers(0, 4096, (B, H, W)).astype(np.uint16)
+    u[:, : H // 3] = np.random.default_rng(1).integers(250, 262, (B, H // 3, W))     # around the black level
+    raw_np = u.astype(np.float32) / np.float32(4095)
+    for sh, dn in (('sharpening_filter', 'gaussian_denoising'), ('sharpening_filter', 'none'),
+                   ('none', 'gaussian_denoising')):
+        ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, 'bilinear', sh, dn)
+        out = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), orc.DRONE_CAMERA_PARAMS, 'bilinear', sh, dn)
+        err = np.abs(out.cpu().numpy() - ref)
+        pc.report(f'static-chain/{shape}/{sh}+{dn}/float32 frames', err.max(), 1e-5)
+        assert err.max() <= 1e-5, (shape, sh, dn, err.max(), np.unravel_index(err.argmax(), err.shape))
+        out16 = F_.static_pipeline(torch.from_numpy(u).to(dev), orc.DRONE_CAMERA_PARAMS, 'bilinear', sh, dn, bits=12)
+        assert torch.equal(out16, out), (shape, sh, dn, '16-bit containers')
+        ref64 = orc.static_batch(raw_np.astype(np.float64), orc.DRONE_CAMERA_PARAMS, 'bilinear', sh, dn)
+        out64 = F_.static_pipeline(torch.from_numpy(raw_np.astype(np.float64)).to(dev), orc.DRONE_CAMERA_PARAMS,
+                                   'bilinear', sh, dn)
+        e64 = np.abs(out64.cpu().numpy() - ref64).max()
+        pc.report(f'static-chain/{shape}/{sh}+{dn}/float64 frames', e64, 1e-5)
+        assert e64 <= 1e-5, (shape, sh, dn, 'float64 frames', e64)
