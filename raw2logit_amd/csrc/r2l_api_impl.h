@@ -781,9 +781,12 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
   if (r2l_static_is_chain(W, debayer, sharpening, denoising)) {
     R2LStaticChainArgs ca;
     ca.s = a;
-    // bands of ~64 rows (7 rows of halo are recomputed per band); at least ~2 workgroups per CU
-    int rows = r2l_env_int("R2L_CHAIN_BAND", 64);
-    long nband = (H + rows - 1) / rows;
+    // Bands: every band re-computes 7 rows of halo, so tall bands are cheaper (256x1024x1024: 64 rows 1134 us,
+    // 128 rows 1112, 256 rows 1086; profiles/r02_f_chain_bands.txt) -- as tall as leaves ~1024 workgroups (two
+    // rounds of two per CU), but not below 64 rows
+    long nband = (1024 + B - 1) / B;
+    if (nband > H / 64) nband = H / 64;
+    nband = r2l_env_int("R2L_CHAIN_BAND", 0) ? (H + r2l_env_int("R2L_CHAIN_BAND", 64) - 1) / r2l_env_int("R2L_CHAIN_BAND", 64) : nband;
     if (nband < 1) nband = 1;
     ca.band_h = (int)((H + nband - 1) / nband);
     ca.band_h += ca.band_h & 1;  // bands start on even rows

@@ -63,12 +63,31 @@ struct R2LChainState {
 
 // One step of the pipeline: raw row q+1 has just entered the window (slot (K+1)%3 of rw).  K = q mod 6, a
 // compile-time constant of the 6-fold unrolled loop, makes every register-array index a constant.
+// The chain's 45 float64 constants are kernel arguments.  Kept live across the row loop they overflow the scalar
+// registers and get parked in VGPR lanes (35 v_readlane per row); read through a laundered pointer to the kernarg
+// segment they are re-loaded (s_load, scalar cache) in front of the section that uses them.
+typedef const __attribute__((address_space(4))) R2LStaticArgs* R2LStaticArgsK;
+R2L_HD R2LStaticArgsK r2l_chain_consts() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  R2LStaticArgsK p = (R2LStaticArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+#else
+  return nullptr;
+#endif
+}
+
 template <int NW, int K>
-R2L_HD void r2l_chain_step(const R2LStaticArgs& a, R2LChainState& st, int q, int y0, int y1, bool le, bool re,
+R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState& st, int q, int y0, int y1, bool le, bool re,
                            int wave, int lane, double* ex, r2l_d2* fifo, float* outb, size_t plane, int x0,
                            bool store_ok) {
   constexpr int PY = K & 1;
-  const int H = a.H;
+  const int H = a_.H;
+#ifdef R2L_CHAIN_ARGS_LIVE
+  const R2LStaticArgs& a = a_;
+#else
+  const __attribute__((address_space(4))) R2LStaticArgs& a = *r2l_chain_consts();
+#endif
   double* yq = st.yr[K % 3];                 // Y(q)   (new)
   const double* ym = st.yr[(K + 2) % 3];     // Y(q-1)
   const double* yu = st.yr[(K + 1) % 3];     // Y(q-2)
@@ -92,7 +111,11 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a, R2LChainState& st, int q, int
       const double y = fma(a.T[0], d[c][0], fma(a.T[1], d[c][1], a.T[2] * d[c][2]));
       uv[c].x = fma(a.T[3], d[c][0], fma(a.T[4], d[c][1], a.T[5] * d[c][2]));
       uv[c].y = fma(a.T[6], d[c][0], fma(a.T[7], d[c][1], a.T[8] * d[c][2]));
-      yq[c] = qin ? y : 0.0;                 // convolve2d(..., fillvalue=0): no luma outside the image
+      yq[c] = y;
+    }
+    if (!qin) {                                // convolve2d(..., fillvalue=0): no luma outside the image
+      R2L_PRAGMA_UNROLL
+      for (int c = 0; c < 4; ++c) yq[c] = 0.0;
     }
     r2l_d2* f = fifo + (size_t)(q & 3) * 4 * 64 + lane;  // [row slot][c][lane]: 16-byte lane stride, conflict-free
     R2L_PRAGMA_UNROLL
@@ -169,8 +192,10 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a, R2LChainState& st, int q, int
     // weights of the 5 window rows: a row outside the image gives its weight to its mirror image
     double wv[5];
     R2L_PRAGMA_UNROLL
-    for (int k = 0; k < 5; ++k) wv[k] = ((unsigned)(y + k - 2) < (unsigned)H) ? a.gk[k] : 0.0;
+    for (int k = 0; k < 5; ++k) wv[k] = a.gk[k];
     if (y < 2 || y > H - 3) {
+      R2L_PRAGMA_UNROLL
+      for (int k = 0; k < 5; ++k) wv[k] = ((unsigned)(y + k - 2) < (unsigned)H) ? a.gk[k] : 0.0;
       R2L_PRAGMA_UNROLL
       for (int k = 0; k < 5; ++k) {
         const int r = y + k - 2;
@@ -200,7 +225,7 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a, R2LChainState& st, int q, int
       }
     }
     if (store_ok) {
-      const size_t off = (size_t)y * a.W + x0;
+      const size_t off = (size_t)y * a_.W + x0;
       R2L_PRAGMA_UNROLL
       for (int k = 0; k < 3; ++k) {
         r2l_f4 s4;
@@ -254,18 +279,17 @@ R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, i
   r2l_stream_convert_row<RAWK, LANES>(a, stage, le, re, st.rw[2]);
   r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0, a.H), x0, le, re, stage);
   r2l_stream_convert_row<RAWK, LANES>(a, stage, le, re, st.rw[0]);
-  R2LRowStageT<RAWK> pf[PF];  // pf[i] = raw row q + 1 + i
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  R2LRowStageT<RAWK> pf[PF];  // ring: raw row r sits in pf[(r - 1 - q0) % PF]; step K consumes pf[K % PF] (row q + 1)
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < PF; ++i) r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 + 1 + i, a.H), x0, le, re, pf[i]);
   for (int qb = q0; qb < q1; qb += 6) {
 #define R2L_CHAIN_STEP(K)                                                                                         \
   if (qb + K < q1) {                                                                                              \
     const int q = qb + K;                                                                                         \
-    r2l_stream_convert_row<RAWK, LANES>(a, pf[0], le, re, st.rw[(K + 1) % 3]);                                    \
-    R2L_PRAGMA_UNROLL                                                                                             \
-    for (int i = 0; i + 1 < PF; ++i) pf[i] = pf[i + 1];                                                           \
+    r2l_stream_convert_row<RAWK, LANES>(a, pf[K % PF], le, re, st.rw[(K + 1) % 3]);                               \
     if (q + 1 + PF < q1 + 1)                                                                                      \
-      r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q + 1 + PF, a.H), x0, le, re, pf[PF - 1]);          \
+      r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q + 1 + PF, a.H), x0, le, re, pf[K % PF]);          \
     r2l_chain_step<NW, K>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, outb, plane, x0, store_ok);            \
   }
     R2L_CHAIN_STEP(0)
