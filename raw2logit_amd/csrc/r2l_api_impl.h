@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "r2l_simple_kernels.h"
+#include "r2l_param_stream.h"
 #include "r2l_static_kernels.h"
 #include "r2l_static_stream.h"
 #include "r2l_static_chain.h"
@@ -162,6 +163,22 @@ R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 *
 R2L_KERNEL_V(r2l_launch_fwd, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, false>)
 R2L_KERNEL_V(r2l_launch_fwd_ragged, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true, false>)
 R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, true, true, false>)
+#ifndef R2L_EMUL
+// the forward as a row-streaming kernel (r2l_param_stream.h): NW wavefronts side by side cover 256 * NW columns
+#ifndef R2L_FS_OCC
+#define R2L_FS_OCC 2
+#endif
+#define R2L_FS_KERNEL(name, NW, U16)                                                                    \
+  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC, r2l_fwd_stream_block<NW, U16>)
+R2L_FS_KERNEL(r2l_launch_fwd_stream_w1, 1, false)
+R2L_FS_KERNEL(r2l_launch_fwd_stream_w2, 2, false)
+R2L_FS_KERNEL(r2l_launch_fwd_stream_w4, 4, false)
+R2L_FS_KERNEL(r2l_launch_fwd_stream_w8, 8, false)
+R2L_FS_KERNEL(r2l_launch_fwd_stream_w1_u16, 1, true)
+R2L_FS_KERNEL(r2l_launch_fwd_stream_w2_u16, 2, true)
+R2L_FS_KERNEL(r2l_launch_fwd_stream_w4_u16, 4, true)
+R2L_FS_KERNEL(r2l_launch_fwd_stream_w8_u16, 8, true)
+#endif
 R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, false>)
 R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, false>)
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
@@ -411,6 +428,46 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     R2LFoldArgs fa{params, ws.folded, ws.counters};
     if (int e = r2l_launch_fold(fa, 1, stream)) return e;
   }
+#ifndef R2L_EMUL
+  if (!additive && (W & 3) == 0 && W <= 2048 && !r2l_env_int("R2L_FWD_TILED", 0)) {
+    // row-streaming forward: work item = (image, band of rows); short bands are cheap here (the 8 halo rows of a
+    // band only compute their luma), so aim at >= 1024 workgroups' worth of items, bands of >= 16 rows
+    R2LFwdStreamArgs fa;
+    fa.raw = raw;
+    fa.F = ws.folded;
+    fa.bn = bn_mean_istd;
+    fa.out = out;
+    fa.stat_partial = stats ? ws.part_small : nullptr;
+    fa.B = B;
+    fa.H = H;
+    fa.W = W;
+    long nband = r2l_env_int("R2L_FS_BAND", 0) ? (H + r2l_env_int("R2L_FS_BAND", 32) - 1) / r2l_env_int("R2L_FS_BAND", 32)
+                                               : (1024 + B - 1) / B;
+    if (nband > H / 16) nband = H / 16;
+    if (nband < 1) nband = 1;
+    fa.band_h = (int)((H + nband - 1) / nband);
+    fa.band_h += fa.band_h & 1;
+    fa.nband = (H + fa.band_h - 1) / fa.band_h;
+    const long nitems = (long)B * fa.nband;
+    if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_isp_fwd: batch too large");
+    fa.nitems = (int)nitems;
+    const int sgrid = (int)(nitems < r2l_env_int("R2L_GRID_FWD", R2L_MAX_BLOCKS) ? nitems
+                                                                               : r2l_env_int("R2L_GRID_FWD", R2L_MAX_BLOCKS));
+    fa.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6, 0};
+    fa.stats_out = stats;
+    if (fin)
+      fa.fin = *fin;
+    else
+      fa.fin.bn = nullptr;
+    const int nw = W <= 256 ? 0 : (W <= 512 ? 1 : (W <= 1024 ? 2 : 3));
+    typedef int (*launch_t)(const R2LFwdStreamArgs&, int, void*);
+    static const launch_t table[2][4] = {
+        {r2l_launch_fwd_stream_w1, r2l_launch_fwd_stream_w2, r2l_launch_fwd_stream_w4, r2l_launch_fwd_stream_w8},
+        {r2l_launch_fwd_stream_w1_u16, r2l_launch_fwd_stream_w2_u16, r2l_launch_fwd_stream_w4_u16,
+         r2l_launch_fwd_stream_w8_u16}};
+    return table[raw.u16 ? 1 : 0][nw](fa, sgrid, stream);
+  }
+#endif
   const int ntiles = B * ((H + GFwd::TH - 1) / GFwd::TH) * ((W + GFwd::TW - 1) / GFwd::TW);
   const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_FWD", 512));
   R2LFwdArgs a;

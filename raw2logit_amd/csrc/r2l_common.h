@@ -397,6 +397,10 @@ struct R2LFolded {
   float AY2[2][9][2];
   float AU2[2][9][2];
   float AV2[2][9][2];
+  // the 5x5 blur for the first / last two image rows, mirror padding folded into the weights (row-streaming forward:
+  // its window holds rows y-2..y+2; a row outside the image gives its weights to its mirror image y' = -y resp.
+  // 2(H-1) - y, both inside the window for H >= 4).  [0]: y = 0, [1]: y = 1, [2]: y = H-2, [3]: y = H-1
+  float blur_edge[4][25];
 };
 
 // The kernels read the folded block through the CONSTANT address space so that every weight is a
@@ -438,7 +442,24 @@ R2L_HD void r2l_fold_one(const float* P, R2LFolded* F, int idx) {
   float* out = (float*)F;
   const int o_ay = 4, o_sharp = 4 + 108, o_blur = o_sharp + 9, o_m2 = o_blur + 25, o_ig = o_m2 + 9;
   const int o_pair = o_ig + 4;
-  if (idx < 4) {
+  const int o_edge = o_pair + 108;
+  if (idx >= o_edge) {
+    const int e = idx - o_edge, set = e / 25, i = (e % 25) / 5, j = e % 5;
+    // window row i = image row y + i - 2; rows outside (top sets: i < 2 - y; bottom sets: i > 2 + (H-1-y)) are zero,
+    // their mirror images take their weights
+    const int yrel = (set == 0) ? 0 : (set == 1 ? 1 : (set == 2 ? -2 : -1));  // y, or y - H for the bottom sets
+    float w = 0.f;
+    for (int k = 0; k < 5; ++k) {  // source window row k lands on window row t
+      const int r = yrel + k - 2;  // row index relative to row 0 (top sets) or to row H (bottom sets)
+      int t;
+      if (set < 2)
+        t = (r < 0) ? (-r) - yrel + 2 : k;
+      else
+        t = (r >= 0) ? (-2 - r) - yrel + 2 : k;  // H + r -> 2(H-1) - (H + r) = H - 2 - r
+      if (t == i) w += P[R2L_P_BLUR + k * 5 + j];
+    }
+    out[idx] = w;
+  } else if (idx < 4) {
     out[idx] = P[R2L_P_BLACK_LEVEL + idx];
   } else if ((idx >= o_ay && idx < o_sharp) || (idx >= o_pair && idx < o_pair + 108)) {
     int k, par, t;

@@ -526,7 +526,7 @@ struct R2LTree {
 // scratch: LDS staging area of scratch_n doubles (>= NSLOTS * R2L_TREE_GROUP floats and >= R2L_MAX_GROUPS
 // doubles).  The coherent loads are spread over all lanes and staged through LDS, so that their latency is
 // paid once per level rather than once per addend; the additions then run in a fixed order from LDS.
-template <int NSLOTS>
+template <int NSLOTS, int NT = R2L_NT>
 R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* lds4, double* out, double* scratch,
                                  int scratch_n) {
   unsigned* lu = (unsigned*)lds4;
@@ -540,7 +540,7 @@ R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* ld
   if (lu[0] + 1 != (unsigned)gsize) return false;
   R2L_PHASE_BEGIN
   if (tid == 0) tr.counters[1 + g] = 0;
-  for (int idx = tid; idx < NSLOTS * gsize; idx += R2L_NT) {
+  for (int idx = tid; idx < NSLOTS * gsize; idx += NT) {
     const int sl = idx / gsize, m = idx - sl * gsize;
     const int n1 = tr.nblk1 > 0 ? tr.nblk1 : nblk;
     if (sl < tr.split)
@@ -550,7 +550,7 @@ R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* ld
   }
   R2L_PHASE_END
   R2L_PHASE_BEGIN
-  for (int sl = tid; sl < NSLOTS; sl += R2L_NT) {
+  for (int sl = tid; sl < NSLOTS; sl += NT) {
     double acc = 0.0;
     for (int m = 0; m < gsize; ++m) acc += (double)sf[sl * gsize + m];
     r2l_store_coherent(tr.gpartial + (size_t)sl * R2L_MAX_GROUPS + g, acc);
@@ -566,13 +566,13 @@ R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* ld
     const int cnt = (NSLOTS - s0 < chunk) ? NSLOTS - s0 : chunk;
     R2L_PHASE_BEGIN
     if (tid == 0) tr.counters[0] = 0;
-    for (int idx = tid; idx < cnt * ngroups; idx += R2L_NT) {
+    for (int idx = tid; idx < cnt * ngroups; idx += NT) {
       const int sl = idx / ngroups, q = idx - sl * ngroups;
       scratch[idx] = r2l_load_coherent(tr.gpartial + (size_t)(s0 + sl) * R2L_MAX_GROUPS + q);
     }
     R2L_PHASE_END
     R2L_PHASE_BEGIN
-    for (int sl = tid; sl < cnt; sl += R2L_NT) {
+    for (int sl = tid; sl < cnt; sl += NT) {
       double acc = 0.0;
       for (int q = 0; q < ngroups; ++q) acc += scratch[sl * ngroups + q];
       out[s0 + sl] = acc;
@@ -620,6 +620,25 @@ R2L_HD void r2l_blur_row2(const float yw[5][8], const FT& F, r2l_p2 ypp[2]) {
     R2L_PRAGMA_UNROLL
     for (int j = 0; j < 5; ++j) {
       const r2l_p2 w = r2l_splat2(F.blur[i * 5 + j]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) ypp[p] = r2l_pfma(w, (j & 1) ? O[p + j / 2] : P[p + j / 2], ypp[p]);
+    }
+  }
+}
+// the same with the 25 weights behind a pointer (interior weights, or the border-row sets of the streaming forward)
+template <class WT>
+R2L_HD void r2l_blur_row2w(const float yw[5][8], WT w25, r2l_p2 ypp[2]) {
+  ypp[0] = ypp[1] = r2l_splat2(0.f);
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 5; ++i) {
+    r2l_p2 P[4], O[3];
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 4; ++k) P[k] = r2l_mk2(yw[i][2 * k], yw[i][2 * k + 1]);
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) O[k] = r2l_straddle(P[k], P[k + 1]);
+    R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      const r2l_p2 w = r2l_splat2(w25[i * 5 + j]);
       R2L_PRAGMA_UNROLL
       for (int p = 0; p < 2; ++p) ypp[p] = r2l_pfma(w, (j & 1) ? O[p + j / 2] : P[p + j / 2], ypp[p]);
     }

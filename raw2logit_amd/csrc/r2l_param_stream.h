@@ -1,0 +1,415 @@
+// r2l_param_stream.h -- the parametrized forward (ParametrizedProcessing.forward, pipeline_torch.py:175-225) as a
+// ROW-STREAMING kernel: the same arithmetic as r2l_fwd_block (r2l_param_kernels.h), organised like the static
+// luma-chain kernel (r2l_static_chain.h) instead of as LDS tiles.
+//
+// A wavefront owns a strip of 256 columns (4 per lane) and a band of rows and walks down the band with, in
+// registers (all float32, two horizontally adjacent pixels per packed instruction):
+//     V   the last 3 rows of black-level-corrected raw values, 6 wide          -> Y, U, V of the middle row (:183-194)
+//     Y   the last 3 luma rows, 6 wide (zero outside the image, :195 padding=1)  -> Y' = sharpen(Y)
+//     Y'  a ring of 6 sharpened rows, 8 wide (mirror-extended columns, :165)      -> Y'' = 5x5 blur (:202)
+// and (U, V) of the last rows in a wave-private LDS ring until their luma arrives.  Neighbour columns come from
+// the neighbouring lanes (DPP wave shifts); the strip edges go through LDS between the wavefronts of the
+// workgroup, which cover one image row side by side: per row and wavefront 6 floats and ONE barrier (the Y' edge
+// columns travel one row late, together with the next row's Y edges).  Raw row q+1 gives Y(q), Y'(q-1) and the
+// finished output row q-4.  Row borders: mirrored raw rows are fetched as such (mirror padding keeps the Bayer
+// parity), luma rows outside the image are zero, and the blur of the first / last two image rows uses weight
+// sets with the mirror padding folded in (R2LFolded::blur_edge), so the window never needs a row it does not have.
+// Compared with the tile kernel: no halo recompute in x, 7 rows of halo per band in y, no phases, no plane
+// round trips through LDS.
+#pragma once
+#include "r2l_param_kernels.h"
+
+#ifndef R2L_EMUL
+
+#ifndef R2L_FS_PF
+#define R2L_FS_PF 3
+#endif
+
+struct R2LFwdStreamArgs {
+  R2LRaw raw;
+  const R2LFolded* F;
+  const float* bn;      // mean[3], istd[3] or null
+  float* out;           // (B,3,H,W) or null (statistics only)
+  float* stat_partial;  // [6][nblk] or null
+  int B, H, W;
+  int nband, band_h, nitems;  // work item = (image, band); workgroup bid takes items bid, bid + nblk, ...
+  R2LTree tree;
+  double* stats_out;
+  R2LBnFinalizeArgs fin;
+};
+
+R2L_HD float r2l_wshr(float x, float edge) {  // previous lane's x; lane 0 of the wavefront gets `edge`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
+                                                               0x138, 0xf, 0xf, false));
+}
+R2L_HD float r2l_wshl(float x, float edge) {  // next lane's x; lane 63 gets `edge`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
+                                                               0x130, 0xf, 0xf, false));
+}
+
+#define R2L_FS_EX 8                          // floats per wavefront and buffer in the exchange area
+#define R2L_FS_FIFO_ROWS 8
+#define R2L_FS_FIFO_F4 (R2L_FS_FIFO_ROWS * 2 * 64)  // (U[4], V[4]) of 8 rows x 64 lanes = 16 KB per wavefront
+#define R2L_FS_RED_FLOATS(NW) (14 * (NW) * 64 > 1024 ? 14 * (NW) * 64 : 1024)  // reduction scratch: (6 NT + 96) doubles, >= tree scratch
+#define R2L_FS_LDS_FLOATS(NW) (2 * (NW) * R2L_FS_EX + 16 + (NW) * R2L_FS_FIFO_F4 * 4 + R2L_FS_RED_FLOATS(NW))
+
+// one raw row in flight: the lane's 4 values (undecoded bits for 16-bit containers) + the strip-edge neighbour
+struct R2LFsStage {
+  r2l_f4 c;
+  float e;
+  int ym;  // mirrored source row
+};
+template <bool U16>
+R2L_HD void r2l_fs_fetch(const R2LFwdStreamArgs& a, size_t img0, int ym, int x0, bool le, bool re, int lane,
+                         R2LFsStage& s) {
+  const size_t e = img0 + (size_t)ym * a.W + x0;
+  s.ym = ym;
+  s.e = 0.f;
+  if (U16) {
+    const unsigned short* r = a.raw.u16 + e;
+    const r2l_f2 b = *(const r2l_f2*)r;
+    s.c.x = b.x;
+    s.c.y = b.y;
+    if ((lane == 0 && !le) || (lane == 63 && !re)) s.e = r2l_u2f((unsigned)(lane == 0 ? r[-1] : r[4]));
+  } else {
+    const float* r = a.raw.f32 + e;
+    s.c = r2l_stream_load_f4(r);
+    if ((lane == 0 && !le) || (lane == 63 && !re)) s.e = (lane == 0) ? r[-1] : r[4];
+  }
+}
+// staged row -> 6 black-level-corrected values, columns x0-1 .. x0+4 (mirror padding at the image edges: column
+// -1 is column 1, column W is column W-2; the black level follows the source site)
+template <bool U16>
+R2L_HD void r2l_fs_convert(const R2LFwdStreamArgs& a, R2LFoldedRef F, const R2LFsStage& s, bool le, bool re,
+                           float v[6]) {
+  float c0, c1, c2, c3, ee = s.e;
+  if (U16) {
+    const unsigned lo = r2l_f2u(s.c.x), hi = r2l_f2u(s.c.y);
+    c0 = r2l_raw_decode(lo & 0xffffu, a.raw);
+    c1 = r2l_raw_decode(lo >> 16, a.raw);
+    c2 = r2l_raw_decode(hi & 0xffffu, a.raw);
+    c3 = r2l_raw_decode(hi >> 16, a.raw);
+    ee = r2l_raw_decode(r2l_f2u(s.e) & 0xffffu, a.raw);
+  } else {
+    c0 = s.c.x;
+    c1 = s.c.y;
+    c2 = s.c.z;
+    c3 = s.c.w;
+  }
+  const float be = (s.ym & 1) ? F.bl[2] : F.bl[0], bo = (s.ym & 1) ? F.bl[3] : F.bl[1];
+  c0 -= be;
+  c1 -= bo;
+  c2 -= be;
+  c3 -= bo;
+  const float l = r2l_wshr(c3, ee - bo), r = r2l_wshl(c0, ee - be);  // column x0-1 is odd, x0+4 even
+  v[0] = le ? c1 : l;
+  v[1] = c0;
+  v[2] = c1;
+  v[3] = c2;
+  v[4] = c3;
+  v[5] = re ? c2 : r;
+}
+
+struct R2LFsState {
+  float v[3][6];   // V rows (slot = row mod 3)
+  float y[3][6];   // Y rows with their left / right neighbours (slot = row mod 3)
+  float yp[6][8];  // Y' rows with two neighbours each side (slot = row mod 6)
+  r2l_p2 acc[6];   // statistics: sum (x - .5), sum (x - .5)^2 per channel, per pair half
+};
+
+// 3x3 stencil with per-column-parity weights on a 6-wide 3-row window -> 4 outputs as 2 pairs
+template <class WT>
+R2L_HD void r2l_fs_stencil_parity(const float* r0, const float* r1, const float* r2, WT w /* [9][2] */, r2l_p2 o[2]) {
+  o[0] = o[1] = r2l_splat2(0.f);
+  const float* rows[3] = {r0, r1, r2};
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    const r2l_p2 wy = r2l_mk2(w[i * 3 + j][0], w[i * 3 + j][1]);
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(wy, r2l_mk2(rows[i][2 * p + j], rows[i][2 * p + j + 1]), o[p]);
+  }
+}
+
+template <int NW, bool U16, int K>
+R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0, int y1, bool le, bool re,
+                        int wave, int lane, float* ex, r2l_f4* fifo, float* ob, unsigned plane, int x0,
+                        bool store_ok, const float mean[3], const float istd[3]) {
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
+  constexpr int PY = K & 1;
+  const int H = a.H;
+  const float* vu = st.v[(K + 2) % 3];  // V(q-1)
+  const float* vm = st.v[K % 3];        // V(q)
+  const float* vl = st.v[(K + 1) % 3];  // V(q+1)
+  float* yq = st.y[K % 3];
+  const bool qin = (unsigned)q < (unsigned)H;
+  // ---- Y(q) into the window, (U, V)(q) into the ring ----------------------------------------------------------
+  {
+    r2l_p2 o[2];
+    r2l_fs_stencil_parity(vu, vm, vl, F.AY2[PY], o);
+    yq[1] = o[0][0];
+    yq[2] = o[0][1];
+    yq[3] = o[1][0];
+    yq[4] = o[1][1];
+    if (!qin) yq[1] = yq[2] = yq[3] = yq[4] = 0.f;  // zero padding of the sharpen conv (:162 padding=1)
+  }
+  // ---- strip edges: Y(q) (1 column each side) and Y'(q-2) (2 columns each side) ------------------------------
+  float* ypq2 = st.yp[(K + 4) % 6];  // Y'(q-2): own columns in [2..5], neighbours still missing
+  float rl_y = 0.f, rl_p2 = 0.f, rl_p3 = 0.f, rr_y = 0.f, rr_p0 = 0.f, rr_p1 = 0.f;
+  if (NW > 1) {
+    float* mine = ex + ((q & 1) * NW + wave) * R2L_FS_EX;
+    if (lane == 0) {
+      mine[0] = yq[1];
+      mine[1] = ypq2[2];
+      mine[2] = ypq2[3];
+    }
+    if (lane == 63) {
+      mine[3] = yq[4];
+      mine[4] = ypq2[4];
+      mine[5] = ypq2[5];
+    }
+  }
+  {
+    // (U, V)(q) into the ring while the edge values are on their way (the halo rows of a band only need luma)
+    if (q >= y0 && q < y1) {
+      r2l_p2 u[2], v[2];
+      r2l_fs_stencil_parity(vu, vm, vl, F.AU2[PY], u);
+      r2l_fs_stencil_parity(vu, vm, vl, F.AV2[PY], v);
+      r2l_f4* f = fifo + (size_t)(q & (R2L_FS_FIFO_ROWS - 1)) * 2 * 64 + lane;
+      r2l_f4 fu, fv;
+      fu.x = u[0][0];
+      fu.y = u[0][1];
+      fu.z = u[1][0];
+      fu.w = u[1][1];
+      fv.x = v[0][0];
+      fv.y = v[0][1];
+      fv.z = v[1][0];
+      fv.w = v[1][1];
+      f[0] = fu;
+      f[64] = fv;
+    }
+  }
+  if (NW > 1) {
+    float* mine = ex + ((q & 1) * NW + wave) * R2L_FS_EX;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (lane == 0 && wave > 0) {
+      const float* o = mine - R2L_FS_EX;
+      rl_y = o[3];
+      rl_p2 = o[4];
+      rl_p3 = o[5];
+    }
+    if (lane == 63 && wave < NW - 1) {
+      const float* o = mine + R2L_FS_EX;
+      rr_y = o[0];
+      rr_p0 = o[1];
+      rr_p1 = o[2];
+    }
+  }
+  {
+    const float l = r2l_wshr(yq[4], rl_y), r = r2l_wshl(yq[1], rr_y);
+    yq[0] = le ? 0.f : l;  // zero padding
+    yq[5] = re ? 0.f : r;
+    const float l2 = r2l_wshr(ypq2[4], rl_p2), l1 = r2l_wshr(ypq2[5], rl_p3);
+    const float r1 = r2l_wshl(ypq2[2], rr_p0), r2 = r2l_wshl(ypq2[3], rr_p1);
+    // mirror padding of the blur (:165 reflect): column -1 = column 1, -2 = 2; W = W-2, W+1 = W-3
+    const float m1 = ypq2[3], m2 = ypq2[4];
+    ypq2[0] = le ? m2 : l2;
+    ypq2[1] = le ? m1 : l1;
+    ypq2[6] = re ? m2 : r1;
+    ypq2[7] = re ? m1 : r2;
+  }
+  // ---- Y'(q-1) = sharpen(Y): 3x3 cross-correlation over rows q-2, q-1, q ---------------------------------------
+  {
+    float* ypn = st.yp[(K + 5) % 6];
+    const float* yu = st.y[(K + 1) % 3];  // Y(q-2)
+    const float* ym = st.y[(K + 2) % 3];  // Y(q-1)
+    r2l_p2 o[2];
+    o[0] = o[1] = r2l_splat2(0.f);
+    const float* rows[3] = {yu, ym, yq};
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      const r2l_p2 ws = r2l_splat2(F.sharp[i * 3 + j]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(ws, r2l_mk2(rows[i][2 * p + j], rows[i][2 * p + j + 1]), o[p]);
+    }
+    ypn[2] = o[0][0];
+    ypn[3] = o[0][1];
+    ypn[4] = o[1][0];
+    ypn[5] = o[1][1];
+  }
+  // ---- output row y = q-4 ------------------------------------------------------------------------------------
+  const int y = q - 4;
+  if (y >= y0 && y < y1) {
+    r2l_p2 ypp[2];
+    {
+      // window rows y-2 .. y+2 = q-6 .. q-2 sit in ring slots K .. K+4
+      float yw[5][8];
+      R2L_PRAGMA_UNROLL
+      for (int i = 0; i < 5; ++i)
+        R2L_PRAGMA_UNROLL
+      for (int j = 0; j < 8; ++j) yw[i][j] = st.yp[(K + i) % 6][j];
+      // the first / last two image rows take the weight sets with the mirror padding folded in
+      const int set = (y < 2) ? y : (y - (H - 2)) + 2;
+      const __attribute__((address_space(4))) float* w25 =
+          (y >= 2 && y < H - 2) ? &F.blur[0] : &F.blur_edge[0][0] + 25 * set;
+      r2l_blur_row2w(yw, w25, ypp);
+    }
+    const r2l_f4* f = fifo + (size_t)(y & (R2L_FS_FIFO_ROWS - 1)) * 2 * 64 + lane;
+    const r2l_f4 fu = f[0], fv = f[64];
+    const r2l_p2 u[2] = {r2l_mk2(fu.x, fu.y), r2l_mk2(fu.z, fu.w)}, v[2] = {r2l_mk2(fv.x, fv.y), r2l_mk2(fv.z, fv.w)};
+    const unsigned off0 = (unsigned)y * (unsigned)a.W + (unsigned)x0;
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      r2l_p2 x[2];
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) {
+        r2l_p2 rgb = r2l_pmul(r2l_splat2(F.M2[k * 3]), ypp[p]);
+        rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 1]), u[p], rgb);
+        rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 2]), v[p], rgb);
+        const r2l_p2 lg = r2l_mk2(r2l_log2(fminf(fmaxf(rgb[0], 1e-5f), 1.0f)),     // :206
+                                  r2l_log2(fminf(fmaxf(rgb[1], 1e-5f), 1.0f)));
+        const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));                    // :209
+        x[p] = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
+        if (a.stat_partial && store_ok) {
+          const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-0.5f));
+          st.acc[k] = r2l_padd(st.acc[k], d);
+          st.acc[3 + k] = r2l_pfma(d, d, st.acc[3 + k]);
+        }
+      }
+      if (ob && store_ok) {
+        R2L_PRAGMA_UNROLL
+        for (int p = 0; p < 2; ++p)
+          x[p] = r2l_pmul(r2l_padd(x[p], r2l_splat2(-mean[k])), r2l_splat2(istd[k]));  // :217
+        r2l_f4 s4;
+        s4.x = x[0][0];
+        s4.y = x[0][1];
+        s4.z = x[1][0];
+        s4.w = x[1][1];
+        *(r2l_f4*)(ob + (unsigned)k * plane + off0) = s4;
+      }
+    }
+  }
+  // rows of Y' that lie outside the image only ever meet zero weights, but must stay finite
+  if ((unsigned)(q - 1) >= (unsigned)H) {
+    float* ypn = st.yp[(K + 5) % 6];
+    ypn[2] = ypn[3] = ypn[4] = ypn[5] = 0.f;
+  }
+}
+
+template <int NW, bool U16>
+R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
+  constexpr int NT = NW * 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* ex = lds;
+  r2l_f4* fifo = (r2l_f4*)(lds + 2 * NW * R2L_FS_EX + 16) + (size_t)wave * R2L_FS_FIFO_F4;
+  float* red = lds + 2 * NW * R2L_FS_EX + 16 + NW * R2L_FS_FIFO_F4 * 4;  // [8][NT] reduction scratch
+  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
+  const int xs = wave * 256 + 4 * lane;
+  const bool store_ok = xs < a.W;
+  const int x0 = store_ok ? xs : a.W - 4;
+  const bool le = x0 == 0, re = x0 + 4 >= a.W;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  float mean[3] = {0.f, 0.f, 0.f}, istd[3] = {1.f, 1.f, 1.f};
+  if (a.bn) {
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      mean[k] = a.bn[k];
+      istd[k] = a.bn[3 + k];
+    }
+  }
+  R2LFsState st;
+  // statistics: float32 pair accumulators per work item (<= band_h x 4 pixels per lane), flushed into float64 lane
+  // totals after every item -- the rounding of a lane's sum then does not grow with the items a workgroup walks,
+  // i.e. does not depend on the grid
+  double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  constexpr int PF = R2L_FS_PF;
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  for (int item = bid; item < a.nitems; item += nblk) {
+    const int band = item % a.nband, b = item / a.nband;
+    const int y0 = band * a.band_h;
+    const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
+    const size_t img = (size_t)b * plane;
+    float* ob = a.out ? a.out + (size_t)b * 3 * plane : nullptr;
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 6; ++i) st.acc[i] = r2l_splat2(0.f);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 6; ++j) st.y[i][j] = 0.f;
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 6; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 8; ++j) st.yp[i][j] = 0.f;
+    // first luma row: q0 <= y0 - 4 (Y'(y0-2) needs Y(y0-3); its strip edges travel one step later), a multiple of 6
+    int q0 = y0 - 4;
+    q0 = (q0 >= 0) ? q0 - q0 % 6 : -(((-q0) + 5) / 6) * 6;
+    const int q1 = y1 + 4;  // exclusive: output row y1-1 leaves at step q = y1+3
+    R2LFsStage stage;
+    r2l_fs_fetch<U16>(a, img, r2l_mirror(q0 - 1, a.H), x0, le, re, lane, stage);
+    r2l_fs_convert<U16>(a, F, stage, le, re, st.v[2]);
+    r2l_fs_fetch<U16>(a, img, r2l_mirror(q0, a.H), x0, le, re, lane, stage);
+    r2l_fs_convert<U16>(a, F, stage, le, re, st.v[0]);
+    R2LFsStage pf[PF];
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < PF; ++i) r2l_fs_fetch<U16>(a, img, r2l_mirror(q0 + 1 + i, a.H), x0, le, re, lane, pf[i]);
+    for (int qb = q0; qb < q1; qb += 6) {
+#define R2L_FS_STEP(K)                                                                                          \
+  if (qb + K < q1) {                                                                                            \
+    const int q = qb + K;                                                                                       \
+    r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
+    if (q + 1 + PF <= q1) r2l_fs_fetch<U16>(a, img, r2l_mirror(q + 1 + PF, a.H), x0, le, re, lane, pf[K % PF]); \
+    r2l_fs_step<NW, U16, K>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, plane, x0, store_ok, mean, istd); \
+  }
+      R2L_FS_STEP(0)
+      R2L_FS_STEP(1)
+      R2L_FS_STEP(2)
+      R2L_FS_STEP(3)
+      R2L_FS_STEP(4)
+      R2L_FS_STEP(5)
+#undef R2L_FS_STEP
+    }
+    if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // exchange buffers free for the next item
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 6; ++i) tot[i] += (double)st.acc[i][0] + (double)st.acc[i][1];
+  }
+  // ---- statistics: lanes -> one partial per slot and workgroup (fixed order), then the shared tree ------------
+  if (a.stat_partial) {
+    double* redd = (double*)red;  // [6][NT] lane totals, then [6][16] partial sums
+    R2L_PRAGMA_UNROLL
+    for (int s = 0; s < 6; ++s) redd[s * NT + tid] = tot[s];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int t = tid; t < 6 * 16; t += NT) {  // 16 lanes per slot add NT / 16 values each, then one lane adds the 16
+      const int s = t >> 4, part = t & 15;
+      double acc = 0.0;
+      for (int j = part; j < NT; j += 16) acc += redd[s * NT + j];
+      redd[6 * NT + t] = acc;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid < 6) {
+      double acc = 0.0;
+      for (int j = 0; j < 16; ++j) acc += redd[6 * NT + tid * 16 + j];
+      r2l_store_coherent(&a.stat_partial[(size_t)tid * nblk + bid], (float)acc);
+    }
+    R2L_STORES_DONE();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    double* sl = (double*)(red + 4);  // totals in LDS: the bookkeeping below reads them back
+    if (a.tree.counters &&
+        r2l_tree_finish<6, NT>(a.tree, bid, nblk, red, sl, (double*)(red + 512), (R2L_FS_RED_FLOATS(NW) - 512) / 2)) {
+      if (tid == 0) sl[6] = (double)a.B * (double)a.H * (double)a.W;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 7) a.stats_out[tid] = sl[tid];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (a.fin.bn) {
+        R2LBnFinalizeArgs f = a.fin;
+        f.tot = sl;
+        f.nranks = 1;
+        r2l_bn_finalize_phases(f);
+      }
+    }
+  }
+}
+
+#endif  // !R2L_EMUL

@@ -413,6 +413,7 @@ def check_grid_independence(device, B=40, H=64, W=64):
                 {'R2L_GRID_FWD': '24', 'R2L_GRID_BWD1': '24', 'R2L_GRID_BWD2': '24'},
                 {'R2L_GRID_BWD1': '8', 'R2L_GRID_BWD2': '16'}):
         y1, g1, rv1, _ = run(env)
+        report(f"grid-independence/{sorted(env.items())}/out", np.abs(y1 - y0).max(), 2e-5)
         assert np.abs(y1 - y0).max() <= 2e-5, (env, np.abs(y1 - y0).max())
         assert np.allclose(rv1, rv0, rtol=1e-5, atol=0)
         for n in g0:

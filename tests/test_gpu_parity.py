@@ -342,3 +342,42 @@ def test_static_luma_chain_streaming_kernel(shape, dev):
         e64 = np.abs(out64.cpu().numpy() - ref64).max()
         pc.report(f'static-chain/{shape}/{sh}+{dn}/float64 frames', e64, 1e-5)
         assert e64 <= 1e-5, (shape, sh, dn, 'float64 frames', e64)
+
+
+@pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
+                                   (5, 18, 8), (2, 514, 512)], ids=str)
+def test_fused_forward_streaming_kernel(shape, dev):
+    """the row-streaming forward (r2l_param_stream.h) on frames 1, 2, 4 and 8 wavefronts wide, several bands high,
+    a partially filled last wavefront, perturbed weights (dense debayer / sharpen / blur): output without BatchNorm,
+    with train-mode BatchNorm (statistics reduced inside the launch), 16-bit containers, against the float64 oracle;
+    and against the tile kernel of the diagnostic build, which computes the same arithmetic in another order"""
+    import os
+    B, H, W = shape
+    u = np.rint(orc.synth_raw(B, H, W, seed=H + W, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
+    raw_np = u.astype(np.float32) / np.float32(4095)
+    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+    P.perturb(7)
+    case = dict(camera='drone', track=False, additive=False, training=True)
+    for bn in (False, True):
+        m = pc.make_module(dict(case, bn=bn), P, dev)
+        with torch.no_grad():
+            y = m(torch.from_numpy(raw_np).to(dev))
+            m16 = pc.make_module(dict(case, bn=bn), P, dev)
+            m16.raw_bits = 12
+            y16 = m16(torch.from_numpy(u).to(dev))
+        assert torch.equal(y, y16), (shape, bn, '16-bit containers')
+        o, _, c = orc.parametrized_forward(raw_np, P.astype(np.float64), bn=pc.oracle_bn(dict(case, bn=bn)))
+        tol = pc.out_tolerance(c, bn)
+        err = np.abs(y.cpu().numpy() - o)
+        w = np.unravel_index((err / tol).argmax(), err.shape)
+        pc.report(f'fwd-stream/{shape}/bn={bn}/out vs float64 oracle', err[w], tol[w])
+        assert np.all(err <= tol), (shape, bn, err.max(), np.unravel_index(err.argmax(), err.shape))
+        os.environ['R2L_FWD_TILED'] = '1'
+        try:
+            with pc.launch_shape_overrides(dev), torch.no_grad():
+                yt = pc.make_module(dict(case, bn=bn), P, dev)(torch.from_numpy(raw_np).to(dev))
+        finally:
+            del os.environ['R2L_FWD_TILED']
+        e2 = (y - yt).abs().max().item()
+        pc.report(f'fwd-stream/{shape}/bn={bn}/streaming vs tile kernel', e2, 2e-5 * (float(c['istd'].max()) if bn else 1.0))
+        assert e2 <= 2e-5 * (float(c['istd'].max()) if bn else 1.0), (shape, bn, e2)
