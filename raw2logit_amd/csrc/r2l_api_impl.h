@@ -166,7 +166,7 @@ R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GF
 #ifndef R2L_EMUL
 // the forward as a row-streaming kernel (r2l_param_stream.h): NW wavefronts side by side cover 256 * NW columns
 #ifndef R2L_FS_OCC
-#define R2L_FS_OCC 2
+#define R2L_FS_OCC 3
 #endif
 #define R2L_FS_KERNEL(name, NW, U16)                                                                    \
   R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC, r2l_fwd_stream_block<NW, U16>)
@@ -258,7 +258,7 @@ R2L_KERNEL(r2l_launch_l2, R2LL2Args, r2l_l2_block, R2L_RED_FLOATS_N(1))
 R2L_KERNEL(r2l_launch_pack_fold, R2LPackFoldArgs, r2l_pack_fold_block, R2L_P_COUNT + 2)
 
 // ---- grid sizing ------------------------------------------------------------------------------
-static_assert(R2L_MAX_BLOCKS == 1024, "partials are laid out for at most 1024 workgroups");
+static_assert(R2L_MAX_BLOCKS == 2048 && 1 + R2L_MAX_GROUPS <= R2L_NT, "partials / arrival counters are laid out for at most 2048 workgroups");
 // Launch shapes are compile-time choices of the product build.  Diagnostic builds (-DR2L_TEST_HOOKS: the host
 // emulation and tests/_build/libr2l_isp_hooks.so, never the shipped libr2l_isp.so) can override them through the
 // environment -- that is how the tests show that no result depends on the workgroup count, and how A/B runs sweep
@@ -431,7 +431,8 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
 #ifndef R2L_EMUL
   if (!additive && (W & 3) == 0 && W <= 2048 && !r2l_env_int("R2L_FWD_TILED", 0)) {
     // row-streaming forward: work item = (image, band of rows); short bands are cheap here (the 8 halo rows of a
-    // band only compute their luma), so aim at >= 1024 workgroups' worth of items, bands of >= 16 rows
+    // band only compute their luma), so aim at ~2048 items (three wavefronts per SIMD: the kernel's row step is a
+    // chain of scalar-load waits, which only other wavefronts can fill), bands of >= 16 rows
     R2LFwdStreamArgs fa;
     fa.raw = raw;
     fa.F = ws.folded;
@@ -441,8 +442,11 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     fa.B = B;
     fa.H = H;
     fa.W = W;
+    // one round of resident workgroups: 256 CUs x 12 wavefronts (three per SIMD) / wavefronts per workgroup
+    const int nwv = W <= 256 ? 1 : (W <= 512 ? 2 : (W <= 1024 ? 4 : 8));
+    const long resident = 256L * (12 / nwv);
     long nband = r2l_env_int("R2L_FS_BAND", 0) ? (H + r2l_env_int("R2L_FS_BAND", 32) - 1) / r2l_env_int("R2L_FS_BAND", 32)
-                                               : (1024 + B - 1) / B;
+                                               : resident / B;
     if (nband > H / 16) nband = H / 16;
     if (nband < 1) nband = 1;
     fa.band_h = (int)((H + nband - 1) / nband);
@@ -451,8 +455,9 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     const long nitems = (long)B * fa.nband;
     if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_isp_fwd: batch too large");
     fa.nitems = (int)nitems;
-    const int sgrid = (int)(nitems < r2l_env_int("R2L_GRID_FWD", R2L_MAX_BLOCKS) ? nitems
-                                                                               : r2l_env_int("R2L_GRID_FWD", R2L_MAX_BLOCKS));
+    long cap = r2l_env_int("R2L_GRID_FWD", (int)(resident < R2L_MAX_BLOCKS ? resident : R2L_MAX_BLOCKS));
+    if (cap > R2L_MAX_BLOCKS) cap = R2L_MAX_BLOCKS;
+    const int sgrid = (int)(nitems < cap ? nitems : cap);
     fa.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6, 0};
     fa.stats_out = stats;
     if (fin)

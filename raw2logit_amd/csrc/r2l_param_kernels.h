@@ -508,7 +508,7 @@ R2L_HD void r2l_rows_3x6(const float* Pl, int tx, int frow, float w[3][6]) {
 // overlaps with workgroups that are still computing.  counters[1 + g] / counters[0] count arrivals; they are
 // zero before the launch (the fold kernel initialises a fresh workspace) and are reset by the last arriver.
 #ifndef R2L_MAX_BLOCKS
-#define R2L_MAX_BLOCKS 1024
+#define R2L_MAX_BLOCKS 2048
 #endif
 #define R2L_TREE_GROUP 16
 #define R2L_MAX_GROUPS (R2L_MAX_BLOCKS / R2L_TREE_GROUP)

@@ -22,7 +22,7 @@
 #ifndef R2L_EMUL
 
 #ifndef R2L_FS_PF
-#define R2L_FS_PF 3
+#define R2L_FS_PF 2
 #endif
 
 struct R2LFwdStreamArgs {
@@ -48,10 +48,12 @@ R2L_HD float r2l_wshl(float x, float edge) {  // next lane's x; lane 63 gets `ed
 }
 
 #define R2L_FS_EX 8                          // floats per wavefront and buffer in the exchange area
-#define R2L_FS_FIFO_ROWS 8
-#define R2L_FS_FIFO_F4 (R2L_FS_FIFO_ROWS * 2 * 64)  // (U[4], V[4]) of 8 rows x 64 lanes = 16 KB per wavefront
-#define R2L_FS_RED_FLOATS(NW) (14 * (NW) * 64 > 1024 ? 14 * (NW) * 64 : 1024)  // reduction scratch: (6 NT + 96) doubles, >= tree scratch
-#define R2L_FS_LDS_FLOATS(NW) (2 * (NW) * R2L_FS_EX + 16 + (NW) * R2L_FS_FIFO_F4 * 4 + R2L_FS_RED_FLOATS(NW))
+#define R2L_FS_FIFO_ROWS 6                   // (chroma waits 4 rows for its luma; slot = row mod 6 = unroll position)
+#define R2L_FS_FIFO_F4 (R2L_FS_FIFO_ROWS * 2 * 64)  // (U[4], V[4]) of 6 rows x 64 lanes = 12 KB per wavefront
+// reduction scratch ((6 NT + 96) doubles, >= the tree's scratch): it reuses the chroma rings, which are idle by then
+#define R2L_FS_RED_FLOATS(NW) (14 * (NW) * 64 > 1024 ? 14 * (NW) * 64 : 1024)
+#define R2L_FS_RING_FLOATS(NW) ((NW) * R2L_FS_FIFO_F4 * 4 > R2L_FS_RED_FLOATS(NW) ? (NW) * R2L_FS_FIFO_F4 * 4 : R2L_FS_RED_FLOATS(NW))
+#define R2L_FS_LDS_FLOATS(NW) (2 * (NW) * R2L_FS_EX + 16 + R2L_FS_RING_FLOATS(NW) + 12 * (NW))  // + 6 doubles per wave
 
 // one raw row in flight: the lane's 4 values (undecoded bits for 16-bit containers) + the strip-edge neighbour
 struct R2LFsStage {
@@ -137,6 +139,11 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
                         int wave, int lane, float* ex, r2l_f4* fifo, float* ob, unsigned plane, int x0,
                         bool store_ok, const float mean[3], const float istd[3]) {
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
+#ifndef R2L_FS_NO_HOIST_BLUR
+  R2LFoldedRef Fh = R2L_FOLDED_REF(a.F);  // not laundered: the 25 blur weights stay in scalar registers (-1 %)
+#else
+  R2LFoldedRef Fh = F;
+#endif
   constexpr int PY = K & 1;
   const int H = a.H;
   const float* vu = st.v[(K + 2) % 3];  // V(q-1)
@@ -157,7 +164,12 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
   // ---- strip edges: Y(q) (1 column each side) and Y'(q-2) (2 columns each side) ------------------------------
   float* ypq2 = st.yp[(K + 4) % 6];  // Y'(q-2): own columns in [2..5], neighbours still missing
   float rl_y = 0.f, rl_p2 = 0.f, rl_p3 = 0.f, rr_y = 0.f, rr_p0 = 0.f, rr_p1 = 0.f;
-  if (NW > 1) {
+#ifdef R2L_FS_NOEXCHANGE  // timing experiment only: wrong results at the strip edges
+  constexpr bool EXCH = false;
+#else
+  constexpr bool EXCH = NW > 1;
+#endif
+  if (EXCH) {
     float* mine = ex + ((q & 1) * NW + wave) * R2L_FS_EX;
     if (lane == 0) {
       mine[0] = yq[1];
@@ -176,7 +188,7 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
       r2l_p2 u[2], v[2];
       r2l_fs_stencil_parity(vu, vm, vl, F.AU2[PY], u);
       r2l_fs_stencil_parity(vu, vm, vl, F.AV2[PY], v);
-      r2l_f4* f = fifo + (size_t)(q & (R2L_FS_FIFO_ROWS - 1)) * 2 * 64 + lane;
+      r2l_f4* f = fifo + (K % R2L_FS_FIFO_ROWS) * 2 * 64 + lane;
       r2l_f4 fu, fv;
       fu.x = u[0][0];
       fu.y = u[0][1];
@@ -190,7 +202,7 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
       f[64] = fv;
     }
   }
-  if (NW > 1) {
+  if (EXCH) {
     float* mine = ex + ((q & 1) * NW + wave) * R2L_FS_EX;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (lane == 0 && wave > 0) {
@@ -254,10 +266,10 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
       // the first / last two image rows take the weight sets with the mirror padding folded in
       const int set = (y < 2) ? y : (y - (H - 2)) + 2;
       const __attribute__((address_space(4))) float* w25 =
-          (y >= 2 && y < H - 2) ? &F.blur[0] : &F.blur_edge[0][0] + 25 * set;
+          (y >= 2 && y < H - 2) ? &Fh.blur[0] : &F.blur_edge[0][0] + 25 * set;
       r2l_blur_row2w(yw, w25, ypp);
     }
-    const r2l_f4* f = fifo + (size_t)(y & (R2L_FS_FIFO_ROWS - 1)) * 2 * 64 + lane;
+    const r2l_f4* f = fifo + ((K + 2) % R2L_FS_FIFO_ROWS) * 2 * 64 + lane;  // row q-4
     const r2l_f4 fu = f[0], fv = f[64];
     const r2l_p2 u[2] = {r2l_mk2(fu.x, fu.y), r2l_mk2(fu.z, fu.w)}, v[2] = {r2l_mk2(fv.x, fv.y), r2l_mk2(fv.z, fv.w)};
     const unsigned off0 = (unsigned)y * (unsigned)a.W + (unsigned)x0;
@@ -305,7 +317,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float* ex = lds;
   r2l_f4* fifo = (r2l_f4*)(lds + 2 * NW * R2L_FS_EX + 16) + (size_t)wave * R2L_FS_FIFO_F4;
-  float* red = lds + 2 * NW * R2L_FS_EX + 16 + NW * R2L_FS_FIFO_F4 * 4;  // [8][NT] reduction scratch
+  float* red = lds + 2 * NW * R2L_FS_EX + 16;  // reduction scratch: over the chroma rings, after the last item
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   const int xs = wave * 256 + 4 * lane;
   const bool store_ok = xs < a.W;
@@ -321,10 +333,12 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     }
   }
   R2LFsState st;
-  // statistics: float32 pair accumulators per work item (<= band_h x 4 pixels per lane), flushed into float64 lane
-  // totals after every item -- the rounding of a lane's sum then does not grow with the items a workgroup walks,
-  // i.e. does not depend on the grid
-  double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  // statistics: float32 pair accumulators per work item (<= band_h x 4 pixels per lane); after every item the
+  // wavefront adds its 64 lane sums (float64, fixed butterfly order) into its float64 totals in LDS -- the rounding
+  // of a sum then does not grow with the items a workgroup walks, i.e. does not depend on the grid, and the totals
+  // cost no registers
+  double* tots = (double*)(lds + 2 * NW * R2L_FS_EX + 16 + R2L_FS_RING_FLOATS(NW)) + wave * 6;
+  if (lane < 6) tots[lane] = 0.0;
   constexpr int PF = R2L_FS_PF;
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
   for (int item = bid; item < a.nitems; item += nblk) {
@@ -343,21 +357,44 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     for (int i = 0; i < 6; ++i)
       R2L_PRAGMA_UNROLL
     for (int j = 0; j < 8; ++j) st.yp[i][j] = 0.f;
-    // first luma row: q0 <= y0 - 4 (Y'(y0-2) needs Y(y0-3); its strip edges travel one step later), a multiple of 6
-    int q0 = y0 - 4;
-    q0 = (q0 >= 0) ? q0 - q0 % 6 : -(((-q0) + 5) / 6) * 6;
+    // first luma row computed: qf = y0 - 3 (Y'(y0-2) needs Y(y0-3)).  The loop is unrolled 6-fold with q = qb + K,
+    // qb a multiple of 6, so that every window slot is a compile-time index; the first pass enters it at K0 = qf - q0
+    // (the steps before qf are skipped, not computed), and the warm-up rows go to the slots that position implies.
+    const int qf = y0 - 3;
+    const int q0 = (qf >= 0) ? qf - qf % 6 : -(((-qf) + 5) / 6) * 6;
+    const int k0 = qf - q0;
     const int q1 = y1 + 4;  // exclusive: output row y1-1 leaves at step q = y1+3
-    R2LFsStage stage;
-    r2l_fs_fetch<U16>(a, img, r2l_mirror(q0 - 1, a.H), x0, le, re, lane, stage);
-    r2l_fs_convert<U16>(a, F, stage, le, re, st.v[2]);
-    r2l_fs_fetch<U16>(a, img, r2l_mirror(q0, a.H), x0, le, re, lane, stage);
-    r2l_fs_convert<U16>(a, F, stage, le, re, st.v[0]);
-    R2LFsStage pf[PF];
+    {
+      R2LFsStage s0, s1;
+      r2l_fs_fetch<U16>(a, img, r2l_mirror(qf - 1, a.H), x0, le, re, lane, s0);
+      r2l_fs_fetch<U16>(a, img, r2l_mirror(qf, a.H), x0, le, re, lane, s1);
+      switch (k0 % 3) {  // rows qf-1, qf -> slots (k0 + 2) % 3, k0 % 3
+        case 0:
+          r2l_fs_convert<U16>(a, F, s0, le, re, st.v[2]);
+          r2l_fs_convert<U16>(a, F, s1, le, re, st.v[0]);
+          break;
+        case 1:
+          r2l_fs_convert<U16>(a, F, s0, le, re, st.v[0]);
+          r2l_fs_convert<U16>(a, F, s1, le, re, st.v[1]);
+          break;
+        default:
+          r2l_fs_convert<U16>(a, F, s0, le, re, st.v[1]);
+          r2l_fs_convert<U16>(a, F, s1, le, re, st.v[2]);
+          break;
+      }
+    }
+    R2LFsStage pf[PF];  // ring: step K consumes pf[K % PF] (raw row q + 1) and refills it with row q + 1 + PF
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < PF; ++i) r2l_fs_fetch<U16>(a, img, r2l_mirror(q0 + 1 + i, a.H), x0, le, re, lane, pf[i]);
+    for (int i = 0; i < PF; ++i) {
+      R2LFsStage t;
+      r2l_fs_fetch<U16>(a, img, r2l_mirror(qf + 1 + i, a.H), x0, le, re, lane, t);
+      R2L_PRAGMA_UNROLL
+      for (int j = 0; j < PF; ++j)
+        if ((k0 + i) % PF == j) pf[j] = t;
+    }
     for (int qb = q0; qb < q1; qb += 6) {
 #define R2L_FS_STEP(K)                                                                                          \
-  if (qb + K < q1) {                                                                                            \
+  if (qb + K >= qf && qb + K < q1) {                                                                            \
     const int q = qb + K;                                                                                       \
     r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
     if (q + 1 + PF <= q1) r2l_fs_fetch<U16>(a, img, r2l_mirror(q + 1 + PF, a.H), x0, le, re, lane, pf[K % PF]); \
@@ -372,25 +409,27 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
 #undef R2L_FS_STEP
     }
     if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // exchange buffers free for the next item
-    R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 6; ++i) tot[i] += (double)st.acc[i][0] + (double)st.acc[i][1];
+    if (a.stat_partial) {
+      double part[6];
+      R2L_PRAGMA_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        double v = (double)st.acc[i][0] + (double)st.acc[i][1];
+        R2L_PRAGMA_UNROLL
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        part[i] = v;
+      }
+      if (lane == 0) {
+        R2L_PRAGMA_UNROLL
+        for (int i = 0; i < 6; ++i) tots[i] += part[i];
+      }
+    }
   }
   // ---- statistics: lanes -> one partial per slot and workgroup (fixed order), then the shared tree ------------
   if (a.stat_partial) {
-    double* redd = (double*)red;  // [6][NT] lane totals, then [6][16] partial sums
-    R2L_PRAGMA_UNROLL
-    for (int s = 0; s < 6; ++s) redd[s * NT + tid] = tot[s];
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int t = tid; t < 6 * 16; t += NT) {  // 16 lanes per slot add NT / 16 values each, then one lane adds the 16
-      const int s = t >> 4, part = t & 15;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wavefront is done with its chroma ring
+    if (tid < 6) {  // the wavefronts' totals in wavefront order
       double acc = 0.0;
-      for (int j = part; j < NT; j += 16) acc += redd[s * NT + j];
-      redd[6 * NT + t] = acc;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (tid < 6) {
-      double acc = 0.0;
-      for (int j = 0; j < 16; ++j) acc += redd[6 * NT + tid * 16 + j];
+      for (int w = 0; w < NW; ++w) acc += (tots - wave * 6)[w * 6 + tid];
       r2l_store_coherent(&a.stat_partial[(size_t)tid * nblk + bid], (float)acc);
     }
     R2L_STORES_DONE();

@@ -64,7 +64,7 @@ class _L2(torch.autograd.Function):
         if x.numel() % 4:
             raise ValueError('l2_regularization: the element count must be a multiple of 4')
         lib, stream = _lib.library_for(x)
-        ws = torch.empty(4 * 1024, dtype=torch.uint8, device=x.device)
+        ws = torch.empty(lib.r2l_aux_workspace_bytes(1, 1, 2, 2), dtype=torch.uint8, device=x.device)
         out = torch.empty(1, dtype=torch.float64, device=x.device)
         lib.check(lib.r2l_l2_fwd(ptr(x), ptr(y), ptr(out), ptr(ws), ws.numel(), x.numel(), stream), 'r2l_l2_fwd')
         ctx.save_for_backward(x, y)
