@@ -37,13 +37,21 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# algorithmic HBM bytes per raw pixel of each kernel (DESIGN.md section "bytes per pixel")
-ALGO_BYTES_PER_PX = {
-    'r2l_launch_fwd_kernel': 16.0,          # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0)
-    'r2l_launch_bwd1_kernel': 20.0,       # raw 4 + grad_out 12 in, dL/dY'' 4 out
-    'r2l_launch_bwd2_kernel': 8.0,        # raw 4 + dL/dY'' 4 in
-    'r2l_launch_bn_reduce_kernel': 24.0,  # grad_out 12 + saved output 12 in
-}
+# algorithmic HBM bytes per raw pixel of each kernel family, by kernel-name prefix; the
+# `_u16` instantiations (16-bit containers) read 2 B/px less raw
+ALGO_BYTES_PER_PX = (
+    ('r2l_launch_fwd', 16.0),        # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0); tile or row-streaming
+    ('r2l_launch_bwd1', 20.0),       # raw 4 + grad_out 12 in, dL/dY'' 4 out
+    ('r2l_launch_bwd2', 8.0),        # raw 4 + dL/dY'' 4 in
+    ('r2l_launch_bn_reduce', 24.0),  # grad_out 12 + saved output 12 in
+)
+
+
+def algo_bytes_per_px(kernel):
+    for prefix, bpp in ALGO_BYTES_PER_PX:
+        if kernel.startswith(prefix):
+            return bpp - (2.0 if '_u16' in kernel and 'bn_reduce' not in kernel else 0.0)
+    return None
 
 
 PMC_PARAM = 'r02_pmc_traffic.json'
@@ -527,17 +535,12 @@ def main():
     if not args.no_roofline:
         # second pass of the same K steps with the library's per-kernel HIP-event hooks switched on
         kernels = kernel_times(lib, clock, step, args.steps)
-        # 16-bit container variants (r2l_launch_*_u16_kernel): 2 B/px less raw traffic
-        algo = dict(ALGO_BYTES_PER_PX)
-        for k, v in ALGO_BYTES_PER_PX.items():
-            if 'bn_reduce' not in k:
-                algo[k.replace('_kernel', '_u16_kernel')] = v - 2.0
-        cand = {k: v for k, v in kernels.items() if k in algo}
+        cand = {k: v for k, v in kernels.items() if algo_bytes_per_px(k) is not None}
         if cand:
             total = {k: v['launches'] * v['avg_us'] for k, v in cand.items()}
             dom = max(total, key=total.get)
             avg_us = cand[dom]['avg_us']
-            bpp = algo[dom]
+            bpp = algo_bytes_per_px(dom)
             if dom.startswith('r2l_launch_fwd') and cand[dom]['launches'] == 2 * args.steps:
                 # two launches per step: stats-only (raw only) and apply (raw + 12 B/px out): average bytes
                 bpp = ((bpp - 12.0) + bpp) / 2

@@ -3,9 +3,9 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 ROOT=$PWD
-OUT=$ROOT/gpurun_out/pmc_static
+OUT=$ROOT/gpurun_out/${OUTNAME:-pmc_static}
 rm -rf $OUT; mkdir -p $OUT
-run() { n=$1; shift; (cd /tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $ROOT/bench.py --workload static --steps 3 --warmup 1 --no-cpu-baseline --no-roofline ${DEB:+--debayer $DEB} > $OUT/$n.log 2>&1); }
+run() { n=$1; shift; (cd /tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $ROOT/bench.py --workload static --steps 3 --warmup 1 --no-cpu-baseline --no-roofline ${DEB:+--debayer $DEB} $EXTRA > $OUT/$n.log 2>&1); }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM
 run tcc1 FETCH_SIZE

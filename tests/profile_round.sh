@@ -4,7 +4,7 @@
 # Results land in gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-TAG=${1:-r01_f}
+TAG=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -48,6 +48,10 @@ rm -rf $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/tcc1 $OUT/tcc2
 # the other measured paths: 16-bit ingest, static chains (BASELINE config 3), auxiliary losses, phase stamps
 python3 bench.py --steps 30 --warmup 5 --raw-u16 --no-cpu-baseline > $OUT/bench_u16.json 2>> $OUT/bench.err
 python3 bench.py --workload static --steps 30 --warmup 10 > $OUT/bench_static.json 2>> $OUT/bench.err
+python3 bench.py --workload static --sharpening sharpening_filter --denoising gaussian_denoising --steps 30 --warmup 12 --no-cpu-baseline > $OUT/bench_static_default_chain.json 2>> $OUT/bench.err
+python3 bench.py --workload e2e-microscopy --steps 20 > $OUT/bench_e2e_microscopy.json 2>> $OUT/bench.err
+python3 bench.py --workload e2e-drone --steps 20 > $OUT/bench_e2e_drone.json 2>> $OUT/bench.err
+bash tests/sizes.sh > $OUT/sizes.txt 2>&1
 python3 bench.py --workload static --steps 30 --warmup 10 --debayer malvar2004 --no-cpu-baseline > $OUT/bench_static_malvar.json 2>> $OUT/bench.err
 python3 tests/bench_static.py > $OUT/static.txt 2>&1
 python3 tests/bench_aux.py > $OUT/aux.txt 2>&1
