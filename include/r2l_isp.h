@@ -272,10 +272,16 @@ int r2l_stage_point(int op, const float *x, const float *g, const float *w, cons
  *   r2l_augment    y = rot90^k(vflip(hflip(x))), k counted like x.rot90(k, dims=(-1, -2)); y is N planes of
  *                  H x W (even k) or W x H (odd k).  inverse != 0: x has y's shape and the inverse map is
  *                  applied (the VJP).  The random draws stay on the host, in the reference's order.
- *   r2l_add_noise  y = x + noise * std (AddGaussianNoise; the caller draws `noise`)                      */
+ *   r2l_add_noise  y = x + noise * std (AddGaussianNoise; the caller draws `noise`)
+ *   r2l_add_noise_philox  y[i] = x[i] + std * n(seed, offset, i): the N(0,1) deviates are generated in the kernel
+ *                  (Philox4x32-10, counter = (i / 4, offset), key = seed, Box-Muller on the four outputs), a pure
+ *                  function of its arguments -- no noise tensor exists.  Same distribution as the reference's
+ *                  torch.randn_like (utils/augmentation.py:17-30), not the same stream.                       */
 int r2l_augment(const float *x, float *y, int N, int H, int W, int hflip, int vflip, int k, int inverse,
                 void *stream);
 int r2l_add_noise(const float *x, const float *noise, float std, float *y, size_t n, void *stream);
+int r2l_add_noise_philox(const float *x, float *y, float std, unsigned long long seed, unsigned long long offset,
+                         size_t n, void *stream);
 
 /* ---- adversarial auxiliary losses between the outputs of two processors (SURVEY.md section 8f rank 2;
  * AuxLoss, utils/base.py:346-358: img1 = the default processor's output, img2 = the adversarial processor's).

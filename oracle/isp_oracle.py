@@ -728,3 +728,43 @@ def l2_regularization(x, y):
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
     return ((x - y) ** 2).sum(), 2 * (y - x)
+
+
+# --------------------------------------------------------------------------------------------------------
+# additive Gaussian noise with a counter-based generator
+# --------------------------------------------------------------------------------------------------------
+def philox4x32_10(c, k):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011: "Parallel random numbers: as easy as 1, 2, 3"), vectorised:
+    c (n,4) uint32 counters, k (2,) uint32 key -> (n,4) uint32.  Published algorithm; the known-answer vectors of
+    the Random123 distribution are checked in tests/test_oracle_golden.py."""
+    c = np.array(c, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    k0, k1 = np.uint64(int(k[0])), np.uint64(int(k[1]))
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c[:, 0]
+        p1 = M1 * c[:, 2]
+        c = np.stack([((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & mask, p1 & mask,
+                      ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & mask, p0 & mask], axis=1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32)
+
+
+def philox_normal(n, seed, offset=0):
+    """the N(0,1) deviates of r2l_add_noise_philox for elements 0..n-1: counter = (i // 4 as 64 bits, offset as 64
+    bits), key = seed; Box-Muller in float32 on output pairs (0,1) and (2,3)."""
+    g = np.arange((n + 3) // 4, dtype=np.uint64)
+    c = np.stack([g & np.uint64(0xFFFFFFFF), g >> np.uint64(32),
+                  np.full_like(g, int(offset) & 0xFFFFFFFF), np.full_like(g, (int(offset) >> 32) & 0xFFFFFFFF)], axis=1)
+    o = philox4x32_10(c, (int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF))
+    s = np.float32(2.3283064365386963e-10)
+    out = np.empty((len(g), 4), dtype=np.float32)
+    for h in (0, 1):
+        u1 = (o[:, 2 * h].astype(np.float32) + np.float32(1)) * s
+        u2 = o[:, 2 * h + 1].astype(np.float32) * s
+        r = np.sqrt(np.float32(-2) * np.log(u1))
+        t = np.float32(6.2831853071795865) * u2
+        out[:, 2 * h] = r * np.cos(t)
+        out[:, 2 * h + 1] = r * np.sin(t)
+    return out.reshape(-1)[:n]

@@ -86,6 +86,8 @@ _SIGNATURES = {
     'r2l_augment': (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     'r2l_add_noise': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_float, _c_float_p, ctypes.c_size_t,
                                      ctypes.c_void_p]),
+    'r2l_add_noise_philox': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64,
+                                            ctypes.c_size_t, ctypes.c_void_p]),
     'r2l_aux_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'r2l_ssim_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t] +
                      [ctypes.c_int] * 5 + [ctypes.c_void_p]),

@@ -110,19 +110,39 @@ class RandomRotate90:  # Note: not the same as T.RandomRotation(90)
         return self.__class__.__name__
 
 
+class _PhiloxNoise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, std, seed, offset):
+        x = _f32c(x, 'x')
+        lib, stream = _lib.library_for(x)
+        y = torch.empty_like(x)
+        lib.check(lib.r2l_add_noise_philox(ptr(x), ptr(y), float(std), int(seed), int(offset), x.numel(), stream),
+                  'r2l_add_noise_philox')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None          # the noise does not depend on x
+
+
+def add_gaussian_noise(x, std, seed, offset=0):
+    """x + std * N(0,1), the deviates generated inside the kernel (Philox4x32-10 keyed by `seed`, Box-Muller): a pure
+    function of (seed, offset, element index)"""
+    return _PhiloxNoise.apply(x, std, seed, offset)
+
+
 class AddGaussianNoise:
-    """utils/augmentation.py:17-31 (the noise is drawn by torch.randn_like on the device, the add is a kernel)."""
+    """utils/augmentation.py:17-31: x + randn_like(x) * std.  The deviates come from an in-kernel Philox generator
+    (no noise tensor, one pass over x); its 63-bit seed is drawn from torch's CPU generator, which
+    ``set_global_seed`` seeds -- a seeded run reproduces its noise (same distribution as the reference's
+    torch.randn_like, not the same stream)."""
 
     def __init__(self, std=0.01):
         self.std = std
 
     def __call__(self, x):
-        x = _f32c(x, 'x')
-        noise = torch.randn_like(x)
-        lib, stream = _lib.library_for(x)
-        y = torch.empty_like(x)
-        lib.check(lib.r2l_add_noise(ptr(x), ptr(noise), float(self.std), ptr(y), x.numel(), stream), 'r2l_add_noise')
-        return y
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        return add_gaussian_noise(x, self.std, seed)
 
     def __repr__(self):
         return self.__class__.__name__ + f'(std={self.std})'

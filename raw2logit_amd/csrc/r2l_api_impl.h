@@ -252,6 +252,7 @@ R2L_KERNEL(r2l_launch_pconv_bwd, R2LStageArgs, r2l_pconv_bwd_block, R2L_RED_FLOA
 R2L_KERNEL(r2l_launch_point, R2LPointArgs, r2l_point_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_aug, R2LAugArgs, r2l_aug_block, 4)
 R2L_KERNEL(r2l_launch_axpy, R2LAxpyArgs, r2l_axpy_block, 4)
+R2L_KERNEL(r2l_launch_philox_noise, R2LPhiloxArgs, r2l_philox_noise_block, 4)
 R2L_KERNEL(r2l_launch_ssim, R2LSsimArgs, r2l_ssim_block, R2L_SSIM_LDS_FLOATS)
 R2L_KERNEL(r2l_launch_ssim_bwd, R2LSsimBwdArgs, r2l_ssim_bwd_block, R2L_SSIM_BWD_LDS_FLOATS)
 R2L_KERNEL(r2l_launch_l2, R2LL2Args, r2l_l2_block, R2L_RED_FLOATS_N(1))
@@ -812,8 +813,10 @@ static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W, int d
   // than the halo rows every band re-reads (they come from L2): same-buffer A/B on 256x1024x1024, bilinear,
   // 128 rows per band 862 us, 32 rows 830, 16 rows 800, 8 rows 735-756, 5 rows 754, 4 rows 778, 2 rows 1012.
   // Malvar (4 halo rows, 5-row window) is flat between 24 and 48 rows per band.
+  // Round 2, other frame widths (profiles/r02_j_stream_bands.txt): 6-row bands are as good on 1024-wide frames
+  // (0.711 vs 0.709 of the HBM peak) and better on 512- and 256-wide ones (0.718 vs 0.692, 0.724 vs 0.700).
   sa.nseg = (W + 255) / 256;
-  const int rows = (debayer == R2L_DEBAYER_MALVAR2004) ? 32 : 8;
+  const int rows = (debayer == R2L_DEBAYER_MALVAR2004) ? 32 : 6;
   long nband = (H + rows - 1) / rows;
   nband = r2l_env_int("R2L_STREAM_BANDS", (int)nband);
   if (nband > H / 2) nband = H / 2;
@@ -1140,6 +1143,14 @@ int r2l_add_noise(const float* x, const float* noise, float std, float* y, size_
   size_t g = (n + R2L_NT - 1) / R2L_NT;
   if (g > 8192) g = 8192;
   return r2l_launch_axpy(a, (int)g, stream);
+}
+int r2l_add_noise_philox(const float* x, float* y, float std, unsigned long long seed, unsigned long long offset,
+                         size_t n, void* stream) {
+  if (!x || !y || n == 0) return r2l_fail(-1, "r2l_add_noise_philox: null pointer / empty");
+  R2LPhiloxArgs a{x, y, std, seed, offset, n};
+  size_t g = ((n + 3) / 4 + R2L_NT - 1) / R2L_NT;
+  if (g > 8192) g = 8192;
+  return r2l_launch_philox_noise(a, (int)g, stream);
 }
 
 // ---- adversarial auxiliary losses (utils/ssim.py, utils/base.py:342-358) -------------------------------

@@ -382,3 +382,72 @@ R2L_BLOCKFN void r2l_axpy_block(const R2LAxpyArgs& a, int bid, int nblk, float* 
   for (size_t e = (size_t)bid * R2L_NT + tid; e < a.n; e += (size_t)nblk * R2L_NT) a.y[e] = a.x[e] + a.noise[e] * a.std;
   R2L_PHASE_END
 }
+
+// ---- AddGaussianNoise with the normal deviates generated in the kernel -------------
+// y[i] = x[i] + std * n[i], n ~ N(0,1) from Philox4x32-10 (Salmon et al. 2011; the counter-based generator torch
+// uses on GPUs) + Box-Muller.  Counter = (group index i/4 as 64 bits, offset as 64 bits), key = seed: the four
+// 32-bit outputs of one counter give the four deviates of elements 4g .. 4g+3, so the result is a pure function
+// of (seed, offset, i) -- independent of grid and launch shape, reproducible, and restated bit for bit (up to the
+// float32 log / sin / cos) by the oracle.  No noise tensor is read or written: 4 B in + 4 B out per element instead
+// of the 16 B/element of torch.randn_like + axpy.
+struct R2LPhiloxArgs {
+  const float* x;
+  float* y;
+  float std;
+  unsigned long long seed, offset;
+  size_t n;
+};
+R2L_HD void r2l_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                              unsigned o[4]) {
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  o[0] = c0;
+  o[1] = c1;
+  o[2] = c2;
+  o[3] = c3;
+}
+R2L_HD void r2l_box_muller(unsigned a, unsigned b, float& n0, float& n1) {
+  const float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]: (a + 1) / 2^32 (float32 rounding may reach 1)
+  const float u2 = (float)b * 2.3283064365386963e-10f;           // [0, 1]
+  const float r = sqrtf(-2.0f * logf(u1));
+  const float t = 6.2831853071795865f * u2;
+  n0 = r * cosf(t);
+  n1 = r * sinf(t);
+}
+R2L_BLOCKFN void r2l_philox_noise_block(const R2LPhiloxArgs& a, int bid, int nblk, float* lds) {
+  (void)lds;
+  const size_t ngroups = (a.n + 3) / 4;
+  R2L_PHASE_BEGIN
+  for (size_t g = (size_t)bid * R2L_NT + tid; g < ngroups; g += (size_t)nblk * R2L_NT) {
+    unsigned o[4];
+    r2l_philox4x32_10((unsigned)g, (unsigned)(g >> 32), (unsigned)a.offset, (unsigned)(a.offset >> 32),
+                      (unsigned)a.seed, (unsigned)(a.seed >> 32), o);
+    float nz[4];
+    r2l_box_muller(o[0], o[1], nz[0], nz[1]);
+    r2l_box_muller(o[2], o[3], nz[2], nz[3]);
+    const size_t e = 4 * g;
+    if (e + 3 < a.n && (((uintptr_t)(a.x + e) | (uintptr_t)(a.y + e)) & 15) == 0) {
+      const r2l_f4 v = *(const r2l_f4*)(a.x + e);
+      r2l_f4 w;
+      w.x = fmaf(nz[0], a.std, v.x);
+      w.y = fmaf(nz[1], a.std, v.y);
+      w.z = fmaf(nz[2], a.std, v.z);
+      w.w = fmaf(nz[3], a.std, v.w);
+      *(r2l_f4*)(a.y + e) = w;
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (e + k < a.n) a.y[e + k] = fmaf(nz[k], a.std, a.x[e + k]);
+    }
+  }
+  R2L_PHASE_END
+}

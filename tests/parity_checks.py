@@ -577,11 +577,31 @@ def check_augmentation(device):
         aug.set_global_seed(seed_used)
         assert torch.equal(gm.cpu(), eager(mask.cpu()))
     assert len(seen) == 2            # both orientations occurred
+    # AddGaussianNoise: the deviates are generated inside the kernel (Philox4x32-10 + Box-Muller) -- against the
+    # oracle's restatement of the same counter-based generator, element by element, for odd sizes and offsets
+    for shape, seed, off in (((2, 3, 17, 23), 12345, 0), ((1, 3, 64, 64), 2 ** 61 + 7, 5), ((7,), 1, 2 ** 40)):
+        xs = torch.randn(shape, generator=torch.Generator().manual_seed(1)).to(device)
+        ys = aug.add_gaussian_noise(xs, 0.25, seed, off)
+        want = xs.cpu().numpy().reshape(-1) + np.float32(0.25) * orc.philox_normal(xs.numel(), seed, off)
+        e = np.abs(ys.cpu().numpy().reshape(-1) - want).max()
+        report(f'augmentation/philox noise {shape} vs oracle', e, 2e-6)
+        assert e <= 2e-6, (shape, e)
+        assert torch.equal(ys, aug.add_gaussian_noise(xs, 0.25, seed, off))          # a pure function of its arguments
+        assert not torch.equal(ys, aug.add_gaussian_noise(xs, 0.25, seed + 1, off))
+    big = aug.add_gaussian_noise(torch.zeros(1 << 20, device=device), 1.0, 99).cpu().double()
+    assert abs(big.mean().item()) < 4e-3 and abs(big.std().item() - 1) < 4e-3 and big.abs().max().item() < 7
+    assert abs((big ** 3).mean().item()) < 2e-2 and abs((big ** 4).mean().item() - 3) < 5e-2   # N(0,1) moments
     n = aug.AddGaussianNoise(std=0.25)
-    torch.manual_seed(3)
+    aug.set_global_seed(3)
     y = n(x)
-    torch.manual_seed(3)
-    assert torch.allclose(y, x + torch.randn_like(x) * 0.25, rtol=0, atol=1e-7)
+    aug.set_global_seed(3)
+    assert torch.equal(y, n(x))                 # a seeded run reproduces its noise
+    assert not torch.equal(y, n(x))
+    d = (y - x).cpu().double()
+    assert abs(d.std().item() - 0.25) < 0.02
+    xg = x.clone().requires_grad_(True)
+    (n(xg) * 2).sum().backward()
+    assert torch.equal(xg.grad, torch.full_like(x, 2.0))
 
 
 def check_error_behaviour(device):

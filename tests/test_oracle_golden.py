@@ -154,3 +154,17 @@ def test_aux_loss_oracle_matches_reference(golden):
         l2, l2g = orc.l2_regularization(x, y)
         assert abs(l2 - float(g[case['name'] + '/l2'])) <= 2e-6 * l2
         assert np.abs(l2g - g[case['name'] + '/l2_grad']).max() < 1e-6
+
+
+def test_philox_restatement_against_the_published_known_answers():
+    """Philox4x32-10 known-answer vectors of the Random123 distribution (kat_vectors: philox4x32 10) pin the
+    oracle's generator; the Box-Muller deviates built on it have the moments of N(0,1)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        assert tuple(int(v) for v in orc.philox4x32_10(np.array([c]), k)[0]) == want
+    z = orc.philox_normal(1 << 20, 1234).astype(np.float64)
+    assert abs(z.mean()) < 4e-3 and abs(z.std() - 1) < 4e-3 and abs((z ** 4).mean() - 3) < 5e-2
+    assert np.array_equal(orc.philox_normal(10, 5, 3)[:6], orc.philox_normal(6, 5, 3))
