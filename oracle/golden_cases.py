@@ -11,7 +11,7 @@ the oracle and the HIP path against the stored vectors).  Test infrastructure on
 #   additive   append_additive_layer (requires 256x256 frames)
 #   perturb    seed for non-default weights (None = reference defaults)
 #   full       store full tensors (False: strided samples only, for the large 256x256 case)
-#   grad_rtol  tolerance of float32 parameter gradients relative to max|grad| (default 3e-3).  With the
+#   grad_rtol  tolerance of float32 parameter gradients relative to max|grad| (default 1.5e-3; 5e-3 here).  With the
 #              Microscopy parameters ~90 % of the pixels sit below the 1e-5 clip floor and most of the rest
 #              within a decade of it, where d/dx x^(1/gamma) ~ x^-0.55 turns 1e-7 of float32 round-off
 #              into ~1e-3 of gradient: the reference's own float32 result is 3e-3 from float64 there.
@@ -25,9 +25,9 @@ PARAM_CASES = [
     dict(name='drone_bn_eval', seed=0, shape=(2, 16, 16), kind='scene', camera='drone',
          bn=True, training=False, track=False, additive=False, perturb=None),
     dict(name='micro_bn_train', seed=1, shape=(1, 64, 64), kind='scene', camera='microscopy',
-         bn=True, training=True, track=False, additive=False, perturb=None, grad_rtol=1e-2),
+         bn=True, training=True, track=False, additive=False, perturb=None, grad_rtol=5e-3),
     dict(name='micro_nobn_track', seed=2, shape=(1, 64, 64), kind='uniform', camera='microscopy',
-         bn=False, training=True, track=True, additive=False, perturb=None, grad_rtol=1e-2),
+         bn=False, training=True, track=True, additive=False, perturb=None, grad_rtol=5e-3),
     dict(name='identity_bn_train', seed=0, shape=(1, 64, 64), kind='uniform', camera='identity',
          bn=True, training=True, track=False, additive=False, perturb=None),
     dict(name='drone_perturbed_bn_train', seed=3, shape=(2, 32, 48), kind='scene', camera='drone',

@@ -80,12 +80,17 @@ def _sample(a, full):
     return a if full else a[..., ::SAMPLE_STRIDE, ::SAMPLE_STRIDE]
 
 
+LOW_BAND_TOL = 5e-5
+DEFAULT_GRAD_RTOL = 1.5e-3      # of max|grad| (round 1: 3e-3; achieved <= 20 % of that on every golden case)
+
+
 def out_tolerance(cache, has_bn, base=1e-5):
     """1e-5 wherever the power law is well conditioned.  The reference clips at
     1e-5 before x^(1/gamma) (pipeline_torch.py:206-209): the slope there is up to 241, so float32
     round-off of ~2e-7 in the linear part is worth up to 5e-5 after the gamma for pre-gamma values
-    below 1e-3; BatchNorm multiplies everything by 1/std."""
-    tol = np.where(cache['rgb'] > 1e-3, base, 1e-4)
+    below 1e-3 (round 1 allowed 1e-4 there; the achieved errors, profiles/r02_k_parity_gpu.tsv, stay below
+    half of the tighter bound); BatchNorm multiplies everything by 1/std."""
+    tol = np.where(cache['rgb'] > 1e-3, base, LOW_BAND_TOL)
     if has_bn:
         tol = tol * np.maximum(1.0, cache['istd'].reshape(1, 3, 1, 1))
     return tol
@@ -94,7 +99,7 @@ def out_tolerance(cache, has_bn, base=1e-5):
 def check_param_case(case, golden, device):
     """fused forward + backward of one PARAM_CASES entry vs the float64 oracle and the golden vectors."""
     g = golden['param_cases']
-    grad_rtol = case.get('grad_rtol', 3e-3)
+    grad_rtol = case.get('grad_rtol', DEFAULT_GRAD_RTOL)
     pre = case['name'] + '/'
     full = case.get('full', True)
     B, H, W = case['shape']
@@ -123,9 +128,11 @@ def check_param_case(case, golden, device):
     worst = np.unravel_index((err / tol).argmax(), err.shape)
     report(f'param/{case["name"]}/out vs float64 oracle', err[worst], tol[worst])
     well = cache['rgb'] > 1e-3          # where x ** (1/gamma) is well conditioned: the 1e-5 bar itself
+    scale = (max(1.0, float(np.max(cache['istd']))) if case['bn'] else 1.0)
     if well.any():
-        report(f'param/{case["name"]}/out vs float64 oracle (pre-gamma > 1e-3)', err[well].max(),
-               1e-5 * (max(1.0, float(np.max(cache['istd']))) if case['bn'] else 1.0))
+        report(f'param/{case["name"]}/out vs float64 oracle (pre-gamma > 1e-3)', err[well].max(), 1e-5 * scale)
+    if (~well).any():
+        report(f'param/{case["name"]}/out vs float64 oracle (pre-gamma <= 1e-3)', err[~well].max(), LOW_BAND_TOL * scale)
     assert np.all(err <= tol), (case['name'], 'out vs oracle', err.max(), np.unravel_index(err.argmax(), err.shape))
     assert m.buffer['processed_rgb'] is y
     if not case['track']:
@@ -677,7 +684,7 @@ def check_staged_case(case, golden, device):
     require grad here, which makes the module take the stage-by-stage kernels (d/d raw exists, stages are
     filled like the reference's, no stage gradients are retained)."""
     g = golden['param_cases']
-    grad_rtol = case.get('grad_rtol', 3e-3)
+    grad_rtol = case.get('grad_rtol', DEFAULT_GRAD_RTOL)
     pre = case['name'] + '/'
     full = case.get('full', True)
     B, H, W = case['shape']
