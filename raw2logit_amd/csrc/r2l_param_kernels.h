@@ -585,23 +585,27 @@ R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* ld
 // sums (float64 in LDS) -> the 132 parameter gradients; tg (R2L_UNFOLD_TG doubles) and pl (R2L_P_COUNT floats)
 // are LDS
 #define R2L_UNFOLD_TG 126
+// (every phase walks its work items with a stride of NT threads, so workgroups smaller than R2L_NT can run it too)
+template <int NT = R2L_NT>
 R2L_BLOCKFN void r2l_unfold_phases(const float* params, const double* sums, double* tg, float* pl,
                                    float* grad_params) {
   R2L_PHASE_BEGIN
-  if (tid < R2L_P_COUNT) pl[tid] = params[tid];
+  for (int t = tid; t < R2L_P_COUNT; t += NT) pl[t] = params[t];
   R2L_PHASE_END
   R2L_PHASE_BEGIN
-  if (tid < 9) {
-    tg[tid] = r2l_fold_T_one(pl, tid / 3, tid % 3);
-  } else if (tid >= 64 && tid < 73) {
-    tg[9 + tid - 64] = r2l_unfold_gT(pl, sums, (tid - 64) / 3, (tid - 64) % 3);
-  } else if (tid >= 128 && tid < 128 + 108) {
-    const int e = tid - 128;
-    tg[18 + e] = r2l_fold_A_one(pl, e / 36, (e % 36) / 9, e % 9);
+  for (int t = tid; t < 128 + 108; t += NT) {
+    if (t < 9) {
+      tg[t] = r2l_fold_T_one(pl, t / 3, t % 3);
+    } else if (t >= 64 && t < 73) {
+      tg[9 + t - 64] = r2l_unfold_gT(pl, sums, (t - 64) / 3, (t - 64) % 3);
+    } else if (t >= 128) {
+      const int e = t - 128;
+      tg[18 + e] = r2l_fold_A_one(pl, e / 36, (e % 36) / 9, e % 9);
+    }
   }
   R2L_PHASE_END
   R2L_PHASE_BEGIN
-  if (tid < R2L_P_NTRAIN) grad_params[tid] = r2l_unfold_one(pl, sums, tid, tg);
+  for (int t = tid; t < R2L_P_NTRAIN; t += NT) grad_params[t] = r2l_unfold_one(pl, sums, t, tg);
   R2L_PHASE_END
 }
 
