@@ -12,7 +12,6 @@
 
 #include "r2l_simple_kernels.h"
 #include "r2l_param_stream.h"
-#include "r2l_param_stream_bwd.h"
 #include "r2l_static_kernels.h"
 #include "r2l_static_stream.h"
 #include "r2l_static_chain.h"
@@ -179,9 +178,9 @@ R2L_FS_KERNEL(r2l_launch_fwd_stream_w1_u16, 1, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w2_u16, 2, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w4_u16, 4, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w8_u16, 8, true)
-// kernel B2 of the backward as a row-streaming kernel (r2l_param_stream_bwd.h): two wavefronts per SIMD (256 VGPRs)
+#endif
 #define R2L_BS_KERNEL(name, NW, U16)                                                                    \
-  R2L_KERNEL_NT_LDS(name, R2LBwd2StreamArgs, (NW) * 64, R2L_BS_LDS_FLOATS(NW), 2, r2l_bwd2_stream_block<NW, U16>)
+  R2L_KERNEL_NT_LDS(name, R2LBwd2StreamArgs, (NW) * 64, R2L_BS_LDS_FLOATS(NW), R2L_BS_OCC, r2l_bwd2_stream_block<NW, U16>)
 R2L_BS_KERNEL(r2l_launch_bwd2_stream_w1, 1, false)
 R2L_BS_KERNEL(r2l_launch_bwd2_stream_w2, 2, false)
 R2L_BS_KERNEL(r2l_launch_bwd2_stream_w4, 4, false)
@@ -604,53 +603,6 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
     e1 = additive ? r2l_launch_bwd1_add(a1, g1, stream)
                   : (exact ? r2l_launch_bwd1(a1, g1, stream) : r2l_launch_bwd1_ragged(a1, g1, stream));
   if (e1) return e1;
-#ifndef R2L_EMUL
-  if ((W & 3) == 0 && W <= 2048 && H >= 6 && !r2l_env_int("R2L_BWD2_TILED", 0)) {
-    // row-streaming B2: work item = (image, band of rows), bands a multiple of 6 rows (the kernel's unroll), about one
-    // round of resident workgroups (256 CUs x 8 wavefronts / wavefronts per workgroup)
-    const int nwv = W <= 256 ? 1 : (W <= 512 ? 2 : (W <= 1024 ? 4 : 8));
-    const long resident = 256L * (8 / nwv);
-    long nband = resident / B;
-    if (nband < 1) nband = 1;
-    int band_h = r2l_env_int("R2L_BS_BAND", (int)((H + nband - 1) / nband));
-    band_h = (band_h + 5) / 6 * 6;
-    if (band_h < 12) band_h = 12;
-    R2LBwd2StreamArgs sa;
-    sa.raw = raw;
-    sa.F = ws.folded;
-    sa.gypp = ws.gypp;
-    sa.partial = ws.part_b2;
-    sa.B = B;
-    sa.H = H;
-    sa.W = W;
-    sa.band_h = band_h;
-    sa.nband = (H + band_h - 1) / band_h;
-    const long nitems = (long)B * sa.nband;
-    if (nitems > (1L << 30)) return r2l_fail(-1, "r2l_isp_bwd: batch too large");
-    sa.nitems = (int)nitems;
-    long cap = r2l_env_int("R2L_GRID_BWD2S", (int)(resident < R2L_MAX_BLOCKS ? resident : R2L_MAX_BLOCKS));
-    if (cap > R2L_MAX_BLOCKS) cap = R2L_MAX_BLOCKS;
-    const int sgrid = (int)(nitems < cap ? nitems : cap);
-    const bool in_k = g1 <= sgrid;
-    sa.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_k ? ws.counters : nullptr, R2L_B1_NACC, g1};
-    sa.params = params;
-    sa.grad_params = grad_params;
-    const int nw = W <= 256 ? 0 : (W <= 512 ? 1 : (W <= 1024 ? 2 : 3));
-    typedef int (*launch_t)(const R2LBwd2StreamArgs&, int, void*);
-    static const launch_t table[2][4] = {
-        {r2l_launch_bwd2_stream_w1, r2l_launch_bwd2_stream_w2, r2l_launch_bwd2_stream_w4, r2l_launch_bwd2_stream_w8},
-        {r2l_launch_bwd2_stream_w1_u16, r2l_launch_bwd2_stream_w2_u16, r2l_launch_bwd2_stream_w4_u16,
-         r2l_launch_bwd2_stream_w8_u16}};
-    if (int e = table[raw.u16 ? 1 : 0][nw](sa, sgrid, stream)) return e;
-    if (in_k) return 0;
-    R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0, nullptr};
-    if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
-    R2LReduceRowsArgs r2{ws.part_b2, ws.sums + R2L_B1_NACC, sgrid, 1.0, nullptr};
-    if (int e = r2l_launch_reduce_rows(r2, R2L_B2_NACC, stream)) return e;
-    R2LUnfoldArgs ua{params, ws.sums, grad_params, 1.0f};
-    return r2l_launch_unfold(ua, 1, stream);
-  }
-#endif
   const int ntiles2 = B * ((H + GBwd2::TH - 1) / GBwd2::TH) * ((W + GBwd2::TW - 1) / GBwd2::TW);
   // bwd2 fits two workgroups per CU (<= 128 VGPRs, 68 KB of LDS): 512 workgroups
   const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", R2L_OCC_BWD2 >= 4 ? 512 : 256));

@@ -401,11 +401,6 @@ struct R2LFolded {
   // its window holds rows y-2..y+2; a row outside the image gives its weights to its mirror image y' = -y resp.
   // 2(H-1) - y, both inside the window for H >= 4).  [0]: y = 0, [1]: y = 1, [2]: y = H-2, [3]: y = H-1
   float blur_edge[4][25];
-  // the ADJOINT of the mirror-padded 5x5 blur in window form, for the row-streaming backward: dL/dY'(r)[c] =
-  // sum_{k,j} adj[s][k*5+j] * G(r-2+k, c+2-j) with G = dL/dY'' (zero outside the image).  [0]: interior rows,
-  // adj[0][k][j] = blur[4-k][j]; [1]: r = 1, [2]: r = 2, [3]: r = H-3, [4]: r = H-2 -- rows whose mirror images
-  // (-1, -2, H+1, H) received gradient through the padding get it folded into their weights (H >= 6).
-  float adj[5][25];
 };
 
 // The kernels read the folded block through the CONSTANT address space so that every weight is a
@@ -448,25 +443,7 @@ R2L_HD void r2l_fold_one(const float* P, R2LFolded* F, int idx) {
   const int o_ay = 4, o_sharp = 4 + 108, o_blur = o_sharp + 9, o_m2 = o_blur + 25, o_ig = o_m2 + 9;
   const int o_pair = o_ig + 4;
   const int o_edge = o_pair + 108;
-  const int o_adj = o_edge + 100;
-  if (idx >= o_adj) {
-    const int e = idx - o_adj, set = e / 25, k = (e % 25) / 5, j = e % 5;
-    // window row k <-> source row r-2+k.  Rows q with mirror(q) = r, q in [-2, H+1]: q = r always; q = -r for r in
-    // {1, 2}; q = 2(H-1) - r for r in {H-3, H-2}.  A tap i of the blur at output row q reads source row q - i + 2,
-    // i.e. window row k = q - r + 4 - i
-    float w = P[R2L_P_BLUR + (4 - k) * 5 + j];
-    int dq = 0;  // q - r of the mirror image
-    bool has = false;
-    if (set == 1) { dq = -2; has = true; }       // r = 1: q = -1
-    else if (set == 2) { dq = -4; has = true; }  // r = 2: q = -2
-    else if (set == 3) { dq = 4; has = true; }   // r = H-3: q = H+1
-    else if (set == 4) { dq = 2; has = true; }   // r = H-2: q = H
-    if (has) {
-      const int i = dq + 4 - k;
-      if (i >= 0 && i <= 4) w += P[R2L_P_BLUR + i * 5 + j];
-    }
-    out[idx] = w;
-  } else if (idx >= o_edge) {
+  if (idx >= o_edge) {
     const int e = idx - o_edge, set = e / 25, i = (e % 25) / 5, j = e % 5;
     // window row i = image row y + i - 2; rows outside (top sets: i < 2 - y; bottom sets: i > 2 + (H-1-y)) are zero,
     // their mirror images take their weights

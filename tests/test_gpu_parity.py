@@ -344,42 +344,6 @@ def test_static_luma_chain_streaming_kernel(shape, dev):
         assert e64 <= 1e-5, (shape, sh, dn, 'float64 frames', e64)
 
 
-BWD_STREAM_SHAPES = [(6, 8), (7, 12), (13, 260), (18, 516), (70, 520), (131, 256), (40, 1028), (36, 2048)]
-
-
-def test_backward_streaming_kernel(dev):
-    """kernel B2 of the backward as a row-streaming kernel (r2l_param_stream_bwd.h): frames 1, 2, 4 and 8 wavefronts
-    wide, one to several bands high, the minimum height (6 rows: every row carries folded mirror rows), a partially
-    filled last wavefront.  All 132 parameter gradients against the float64 oracle (perturbed weights), then against
-    the tile kernel of the diagnostic build (same arithmetic, another order), with bands of the minimum height."""
-    import os
-    worst = pc.check_frame_shapes(dev, shapes=BWD_STREAM_SHAPES, B=2)
-    pc.report('bwd2-stream/frame shapes/worst gradient error over its limit', worst, 1.0)
-    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
-    P.perturb(7)
-    case = dict(camera='drone', track=False, additive=False, training=True, bn=True)
-    for (H, W) in BWD_STREAM_SHAPES + [(514, 512)]:
-        raw = torch.from_numpy(orc.synth_raw(3, H, W, seed=H + W, kind='scene')).to(dev)
-        cot = torch.from_numpy(np.random.default_rng(H).standard_normal((3, 3, H, W)).astype(np.float32)).to(dev)
-        grads = {}
-        for name, env in (('stream', {}), ('bands', {'R2L_BS_BAND': '12'}), ('tile', {'R2L_BWD2_TILED': '1'})):
-            m = pc.make_module(case, P, dev)
-            os.environ.update(env)
-            try:
-                with pc.launch_shape_overrides(dev):
-                    (m(raw) * cot).sum().backward()
-            finally:
-                for k in env:
-                    del os.environ[k]
-            grads[name] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
-        for n, ref in grads['tile'].items():
-            for name in ('stream', 'bands'):
-                e = np.abs(grads[name][n] - ref).max()
-                lim = 2e-4 * (np.abs(ref).max() + 1e-6)
-                pc.report(f'bwd2-stream/{(H, W)}/{name} vs tile kernel/{n}', e, lim)
-                assert e <= lim, ((H, W), name, n, e, lim)
-
-
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
                                    (5, 18, 8), (2, 514, 512)], ids=str)
 def test_fused_forward_streaming_kernel(shape, dev):
