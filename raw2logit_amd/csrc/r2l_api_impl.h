@@ -179,17 +179,6 @@ R2L_FS_KERNEL(r2l_launch_fwd_stream_w2_u16, 2, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w4_u16, 4, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w8_u16, 8, true)
 #endif
-#define R2L_BS_KERNEL(name, NW, U16)                                                                    \
-  R2L_KERNEL_NT_LDS(name, R2LBwd2StreamArgs, (NW) * 64, R2L_BS_LDS_FLOATS(NW), R2L_BS_OCC, r2l_bwd2_stream_block<NW, U16>)
-R2L_BS_KERNEL(r2l_launch_bwd2_stream_w1, 1, false)
-R2L_BS_KERNEL(r2l_launch_bwd2_stream_w2, 2, false)
-R2L_BS_KERNEL(r2l_launch_bwd2_stream_w4, 4, false)
-R2L_BS_KERNEL(r2l_launch_bwd2_stream_w8, 8, false)
-R2L_BS_KERNEL(r2l_launch_bwd2_stream_w1_u16, 1, true)
-R2L_BS_KERNEL(r2l_launch_bwd2_stream_w2_u16, 2, true)
-R2L_BS_KERNEL(r2l_launch_bwd2_stream_w4_u16, 4, true)
-R2L_BS_KERNEL(r2l_launch_bwd2_stream_w8_u16, 8, true)
-#endif
 R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, false>)
 R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, false>)
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
