@@ -224,21 +224,42 @@ R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
 #ifndef R2L_CHAIN_OCC
 #define R2L_CHAIN_OCC 2
 #endif
-#define R2L_CHAIN_KERNEL(name, NW, RAWK)                                                                  \
-  R2L_KERNEL_NT_LDS(name, R2LStaticChainArgs, (NW) * 64, 2 * R2L_CHAIN_LDS_DOUBLES(NW), R2L_CHAIN_OCC,    \
-                    r2l_static_chain_block<NW, RAWK>)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w1, 1, R2L_RAW_F32)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w2, 2, R2L_RAW_F32)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w4, 4, R2L_RAW_F32)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w8, 8, R2L_RAW_F32)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w1_u16, 1, R2L_RAW_U16)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w2_u16, 2, R2L_RAW_U16)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w4_u16, 4, R2L_RAW_U16)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w8_u16, 8, R2L_RAW_U16)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w1_f64, 1, R2L_RAW_F64)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w2_f64, 2, R2L_RAW_F64)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w4_f64, 4, R2L_RAW_F64)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_w8_f64, 8, R2L_RAW_F64)
+// (the workgroup size and the LDS size follow the frame width at launch time: 64 threads and 16.1 KB per strip)
+#define R2L_CHAIN_KERNEL(name, RAWK, DEB, DN)                                                                 \
+  __global__ __launch_bounds__(512, R2L_CHAIN_OCC) void name##_kernel(const R2LStaticChainArgs a) {           \
+    extern __shared__ __attribute__((aligned(16))) float r2l_chain_lds[];                                     \
+    r2l_static_chain_block<RAWK, DEB, DN>(a, (int)blockIdx.x, (int)gridDim.x, r2l_chain_lds);                 \
+  }                                                                                                           \
+  static int name(const R2LStaticChainArgs& a, int grid, void* stream) {                                      \
+    const size_t lds_bytes = sizeof(double) * R2L_CHAIN_LDS_DOUBLES(a.nw);                                    \
+    static size_t lds_ok = 48 * 1024;                                                                         \
+    if (lds_bytes > lds_ok) {                                                                                 \
+      const hipError_t ea = hipFuncSetAttribute((const void*)name##_kernel,                                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+      if (ea != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(ea));            \
+      lds_ok = lds_bytes;                                                                                     \
+    }                                                                                                         \
+    R2LTimedLaunch t_;                                                                                        \
+    const bool timed_ = r2l_timing_on;                                                                        \
+    if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                                     \
+    hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(a.nw * 64), lds_bytes, (hipStream_t)stream, a);        \
+    if (timed_) r2l_time_end((hipStream_t)stream, t_);                                                        \
+    const hipError_t e = hipGetLastError();                                                                   \
+    if (e != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(e));                \
+    return 0;                                                                                                 \
+  }
+R2L_CHAIN_KERNEL(r2l_launch_static_chain, R2L_RAW_F32, 0, 0)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_median, R2L_RAW_F32, 0, 1)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar, R2L_RAW_F32, 1, 0)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_median, R2L_RAW_F32, 1, 1)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_u16, R2L_RAW_U16, 0, 0)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_median_u16, R2L_RAW_U16, 0, 1)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_u16, R2L_RAW_U16, 1, 0)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_median_u16, R2L_RAW_U16, 1, 1)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_f64, R2L_RAW_F64, 0, 0)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_median_f64, R2L_RAW_F64, 0, 1)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_f64, R2L_RAW_F64, 1, 0)
+R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_median_f64, R2L_RAW_F64, 1, 1)
 #endif
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
@@ -794,9 +815,8 @@ static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoisin
   return false;  // (lane shifts and wave-level exchange: not expressible in the one-lane-at-a-time emulation)
 #else
   if (r2l_env_int("R2L_STATIC_TILED", 0)) return false;
-  return debayer == R2L_DEBAYER_BILINEAR && (W & 3) == 0 && W <= 2048 &&
-         (sharpening == R2L_SHARPEN_NONE || sharpening == R2L_SHARPEN_FILTER) &&
-         (denoising == R2L_DENOISE_NONE || denoising == R2L_DENOISE_GAUSSIAN) &&
+  (void)debayer;  // bilinear and Malvar2004 both
+  return (W & 3) == 0 && W <= 2048 && (sharpening == R2L_SHARPEN_NONE || sharpening == R2L_SHARPEN_FILTER) &&
          !(sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE);
 #endif
 }
@@ -858,16 +878,18 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     ca.nband = (H + ca.band_h - 1) / ca.band_h;
     const long grid = (long)B * ca.nband;
     if (grid > (1L << 30)) return r2l_fail(-1, "r2l_static_fwd: batch too large");
-    const int nw = W <= 256 ? 1 : (W <= 512 ? 2 : (W <= 1024 ? 4 : 8));
+    ca.nw = W <= 256 ? 1 : (W <= 512 ? 2 : (W <= 1024 ? 4 : 8));
     const int kind = raw.u16 ? 1 : (raw.f64 ? 2 : 0);
+    const int deb = debayer == R2L_DEBAYER_MALVAR2004 ? 1 : 0, dn = denoising == R2L_DENOISE_MEDIAN ? 1 : 0;
     typedef int (*launch_t)(const R2LStaticChainArgs&, int, void*);
-    static const launch_t table[3][4] = {
-        {r2l_launch_static_chain_w1, r2l_launch_static_chain_w2, r2l_launch_static_chain_w4, r2l_launch_static_chain_w8},
-        {r2l_launch_static_chain_w1_u16, r2l_launch_static_chain_w2_u16, r2l_launch_static_chain_w4_u16,
-         r2l_launch_static_chain_w8_u16},
-        {r2l_launch_static_chain_w1_f64, r2l_launch_static_chain_w2_f64, r2l_launch_static_chain_w4_f64,
-         r2l_launch_static_chain_w8_f64}};
-    return table[kind][nw == 1 ? 0 : (nw == 2 ? 1 : (nw == 4 ? 2 : 3))](ca, (int)grid, stream);
+    static const launch_t table[3][2][2] = {
+        {{r2l_launch_static_chain, r2l_launch_static_chain_median},
+         {r2l_launch_static_chain_malvar, r2l_launch_static_chain_malvar_median}},
+        {{r2l_launch_static_chain_u16, r2l_launch_static_chain_median_u16},
+         {r2l_launch_static_chain_malvar_u16, r2l_launch_static_chain_malvar_median_u16}},
+        {{r2l_launch_static_chain_f64, r2l_launch_static_chain_median_f64},
+         {r2l_launch_static_chain_malvar_f64, r2l_launch_static_chain_malvar_median_f64}}};
+    return table[kind][deb][dn](ca, (int)grid, stream);
   }
 #endif
   if (!r2l_static_is_fused(W, debayer, sharpening, denoising, raw.f64 != nullptr)) {

@@ -1,11 +1,16 @@
 // r2l_static_chain.h -- the static chains WITH a luma stencil chain as one row-streaming kernel:
 //
-//   remove_blacklv -> demosaicing_CFA_Bayer_bilinear -> white balance -> colour matrix -> rgb2yuv ->
-//   [sharpening_filter: Y <- convolve2d(Y, K, 'same', fill 0)] -> [gaussian_denoising: Y <- gaussian_filter(Y, 0.5)]
+//   remove_blacklv -> demosaicing_CFA_Bayer_bilinear | _Malvar2004 -> white balance -> colour matrix -> rgb2yuv ->
+//   [sharpening_filter: Y <- convolve2d(Y, K, 'same', fill 0)] ->
+//   [gaussian_denoising: Y <- gaussian_filter(Y, 0.5)  |  median_denoising: Y <- median_filter(Y, 3)]
 //   -> yuv2rgb -> clip[0,1] -> x ** (1/gamma)
 //
-// i.e. processing() (pipeline_numpy.py:70-141) with the default chain of train.py:96-101 (and the chains with only
-// one of the two luma filters).  Round 1 ran this as an LDS tile kernel (r2l_static_block: float64 planes, 115 KB
+// i.e. processing() (pipeline_numpy.py:70-141) with the default chain of train.py:96-101, the chains with only one
+// of the two luma filters, and the Malvar2004 / median_denoising alternates of the reference's sweeps
+// (figures/train.sh:49-79; pipeline_numpy.py:94-95, :194-200).  Template parameters: DEB (0 bilinear: 3-row raw
+// window; 1 Malvar2004: 5-row window in a ring of 6) and DN (0 Gaussian: ring of 6 horizontally blurred rows, output
+// row q-3; 1 median: the last 3 sharpened rows with one neighbour column each side, output row q-2).
+// Round 1 ran the default chain as an LDS tile kernel (r2l_static_block: float64 planes, 115 KB
 // of LDS, one workgroup per CU, 21 % of the HBM peak).  Here, like the short chain (r2l_static_stream.h), every
 // wavefront is a line-buffer ISP: it owns a strip of 256 columns (4 per lane) and a band of rows, walks down the
 // band and keeps in registers
@@ -33,6 +38,7 @@
 struct R2LStaticChainArgs {
   R2LStaticArgs s;
   int nband, band_h;
+  int nw;  // wavefronts per workgroup = 256-column strips per image row (1, 2, 4, 8)
 };
 
 // float64 value of x in the previous / next lane of the wavefront; lane 0 / lane 63 get `edge`
@@ -54,12 +60,22 @@ R2L_HD double r2l_wave_shl1_d(double x, double edge) {
 #define R2L_CHAIN_LDS_DOUBLES(NW) (2 * (NW) * R2L_CHAIN_EX + (NW) * R2L_CHAIN_FIFO_DOUBLES)
 
 // per-lane state of the luma chain
+template <int DEB, int DN>
 struct R2LChainState {
-  double rw[3][8];   // raw rows (slot = row mod 3): columns x0-2 .. x0+5, black level removed
-  double yr[3][4];   // luma rows (slot = row mod 3)
-  double yl, yrr;    // left / right neighbour of the luma row q-1 (zero outside the image)
-  double hb[6][4];   // horizontally blurred sharpened luma (slot = row mod 6)
+  double rw[DEB ? 6 : 3][8];  // raw rows (slot = row mod 3 / mod 6): columns x0-2 .. x0+5, black level removed
+  double yr[3][4];            // luma rows (slot = row mod 3)
+  double yl, yrr;             // left / right neighbour of the luma row q-1 (zero outside the image)
+  // DN 0: horizontally blurred sharpened luma, own columns (slot = row mod 6)
+  // DN 1: sharpened luma, columns x0-1 .. x0+4 (symmetric at the image edges) (slot = row mod 3)
+  double hb[DN == 0 ? 6 : 3][DN == 0 ? 4 : 6];
 };
+
+R2L_HD void r2l_chain_cswap(double& a, double& b) {
+  const double lo = fmin(a, b), hi = fmax(a, b);
+  a = lo;
+  b = hi;
+}
+R2L_HD double r2l_chain_med3(double a, double b, double c) { return fmax(fmin(a, b), fmin(fmax(a, b), c)); }
 
 // One step of the pipeline: raw row q+1 has just entered the window (slot (K+1)%3 of rw).  K = q mod 6, a
 // compile-time constant of the 6-fold unrolled loop, makes every register-array index a constant.
@@ -77,10 +93,10 @@ R2L_HD R2LStaticArgsK r2l_chain_consts() {
 #endif
 }
 
-template <int NW, int K>
-R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState& st, int q, int y0, int y1, bool le, bool re,
-                           int wave, int lane, double* ex, r2l_d2* fifo, float* outb, size_t plane, int x0,
-                           bool store_ok) {
+template <int DEB, int DN, int K>
+R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, DN>& st, int q, int y0, int y1, bool le,
+                           bool re, int NW, int wave, int lane, double* ex, r2l_d2* fifo, float* outb, size_t plane,
+                           int x0, bool store_ok) {
   constexpr int PY = K & 1;
   const int H = a_.H;
 #ifdef R2L_CHAIN_ARGS_LIVE
@@ -95,15 +111,23 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState& st, int q, in
   // ---- demosaic + colour of row q: Y(q) to the window, (U, V)(q) to the LDS ring ---------------------------
   {
     double d[4][3];
-    const double* u = st.rw[(K + 2) % 3];    // raw row q-1
-    const double* m = st.rw[K % 3];          // raw row q
-    const double* l = st.rw[(K + 1) % 3];    // raw row q+1
-    if (q > 0 && q < H - 1) {
-      r2l_stream_bilinear_row_interior<PY>(u, m, l, le, re, d);
+    if (DEB == 0) {
+      const double* u = st.rw[(K + 2) % 3];    // raw row q-1
+      const double* m = st.rw[K % 3];          // raw row q
+      const double* l = st.rw[(K + 1) % 3];    // raw row q+1
+      if (q > 0 && q < H - 1) {
+        r2l_stream_bilinear_row_interior<PY>(u, m, l, le, re, d);
+      } else {
+        // first / last image row: a mirrored row carries the sites of the row it came from
+        const int tpy[3] = {r2l_symmetric(q - 1, H) & 1, r2l_symmetric(q, H) & 1, r2l_symmetric(q + 1, H) & 1};
+        r2l_stream_bilinear_row(u, m, l, tpy, le, re, d);
+      }
     } else {
-      // first / last image row: a mirrored row carries the sites of the row it came from
-      const int tpy[3] = {r2l_symmetric(q - 1, H) & 1, r2l_symmetric(q, H) & 1, r2l_symmetric(q + 1, H) & 1};
-      r2l_stream_bilinear_row(u, m, l, tpy, le, re, d);
+      // Malvar2004 convolves the UNMASKED mosaic (mirrored rows / columns are plain values) and selects by the
+      // output pixel's site: rows q-2 .. q+2 of the ring of 6
+      constexpr int R = DEB ? 6 : 3;
+      r2l_stream_malvar_row<PY>(st.rw[(K + 4) % R], st.rw[(K + 5) % R], st.rw[K % R], st.rw[(K + 1) % R],
+                                st.rw[(K + 2) % R], d);
     }
     r2l_d2 uv[4];
     R2L_PRAGMA_UNROLL
@@ -162,11 +186,74 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState& st, int q, in
       rr_p1 = o[2];
     }
   }
+  (void)rl_p2;
+  (void)rr_p1;
   // neighbours of Y(q) for the next step's sharpen (zero outside the image)
   {
     const double l = r2l_wave_shr1_d(yq[3], rl_y), r = r2l_wave_shl1_d(yq[0], rr_y);
     st.yl = le ? 0.0 : l;
     st.yrr = re ? 0.0 : r;
+  }
+  if (DN == 1) {
+    // ---- median_filter(Y', 3), scipy 'reflect' = symmetric rows and columns: row q-1 joins the window ----------
+    if ((unsigned)(q - 1) < (unsigned)H) {
+      const double l1 = r2l_wave_shr1_d(yp[3], rl_p3), r1 = r2l_wave_shl1_d(yp[0], rr_p0);
+      double* m = st.hb[(K + 2) % 3];  // slot of row q-1
+      m[0] = le ? yp[0] : l1;
+      m[1] = yp[0];
+      m[2] = yp[1];
+      m[3] = yp[2];
+      m[4] = yp[3];
+      m[5] = re ? yp[3] : r1;
+    }
+    const int y = q - 2;  // rows y-1, y, y+1 sit in slots K % 3, (K + 1) % 3, (K + 2) % 3
+    if (y >= y0 && y < y1) {
+      const double* r0 = st.hb[K % 3];
+      const double* r1 = st.hb[(K + 1) % 3];
+      const double* r2 = st.hb[(K + 2) % 3];
+      // columns sorted once (lo <= mid <= hi), then per pixel: median(max of the los, median of the mids, min of
+      // the his) -- the median of 9 as a selection, bit-identical to sorting
+      double lo[6], mi[6], hi[6];
+      const bool top = y == 0, bot = y == H - 1;  // the row mirrored in from outside is the edge row itself
+      R2L_PRAGMA_UNROLL
+      for (int j = 0; j < 6; ++j) {
+        double p = top ? r1[j] : r0[j], c = r1[j], n = bot ? r1[j] : r2[j];
+        r2l_chain_cswap(p, c);
+        r2l_chain_cswap(c, n);
+        r2l_chain_cswap(p, c);
+        lo[j] = p;
+        mi[j] = c;
+        hi[j] = n;
+      }
+      const r2l_d2* f = fifo + (size_t)(y & 3) * 4 * 64 + lane;
+      float x[3][4];
+      R2L_PRAGMA_UNROLL
+      for (int c = 0; c < 4; ++c) {
+        const double a0 = fmax(fmax(lo[c], lo[c + 1]), lo[c + 2]);
+        const double b0 = r2l_chain_med3(mi[c], mi[c + 1], mi[c + 2]);
+        const double c0 = fmin(fmin(hi[c], hi[c + 1]), hi[c + 2]);
+        const double yy = r2l_chain_med3(a0, b0, c0);
+        const r2l_d2 uv = f[c * 64];
+        R2L_PRAGMA_UNROLL
+        for (int k = 0; k < 3; ++k) {
+          const double rgb = fma(a.M2[k * 3], yy, fma(a.M2[k * 3 + 1], uv.x, a.M2[k * 3 + 2] * uv.y));
+          x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
+        }
+      }
+      if (store_ok) {
+        const size_t off = (size_t)y * a_.W + x0;
+        R2L_PRAGMA_UNROLL
+        for (int k = 0; k < 3; ++k) {
+          r2l_f4 s4;
+          s4.x = x[k][0];
+          s4.y = x[k][1];
+          s4.z = x[k][2];
+          s4.w = x[k][3];
+          r2l_stream_store_f4(outb + (size_t)k * plane + off, s4);
+        }
+      }
+    }
+    return;
   }
   // ---- Hb(q-1): horizontal pass of gaussian_filter over Y'(q-1), scipy 'reflect' = symmetric columns --------
   if ((unsigned)(q - 1) < (unsigned)H) {
@@ -181,7 +268,7 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState& st, int q, in
     e[5] = yp[3];
     e[6] = re ? yp[3] : r1;
     e[7] = re ? yp[2] : r2;
-    double* h = st.hb[(K + 5) % 6];          // slot of row q-1
+    double* h = st.hb[(K + 5) % (DN == 0 ? 6 : 3)];  // slot of row q-1
     R2L_PRAGMA_UNROLL
     for (int c = 0; c < 4; ++c)
       h[c] = fma(a.gk[2], e[c + 2], fma(a.gk[1], e[c + 1] + e[c + 3], a.gk[0] * (e[c] + e[c + 4])));
@@ -207,11 +294,11 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState& st, int q, in
       }
     }
     // rows y-2..y+2 sit in slots (K + 1 .. K + 5) % 6  (row q-1 = y+2 is slot (K+5)%6)
-    const double* h0 = st.hb[(K + 1) % 6];
-    const double* h1 = st.hb[(K + 2) % 6];
-    const double* h2 = st.hb[(K + 3) % 6];
-    const double* h3 = st.hb[(K + 4) % 6];
-    const double* h4 = st.hb[(K + 5) % 6];
+    const double* h0 = st.hb[(K + 1) % (DN == 0 ? 6 : 3)];
+    const double* h1 = st.hb[(K + 2) % (DN == 0 ? 6 : 3)];
+    const double* h2 = st.hb[(K + 3) % (DN == 0 ? 6 : 3)];
+    const double* h3 = st.hb[(K + 4) % (DN == 0 ? 6 : 3)];
+    const double* h4 = st.hb[(K + 5) % (DN == 0 ? 6 : 3)];
     const r2l_d2* f = fifo + (size_t)(y & 3) * 4 * 64 + lane;
     float x[3][4];
     R2L_PRAGMA_UNROLL
@@ -239,10 +326,11 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState& st, int q, in
   }
 }
 
-template <int NW, int RAWK>
+template <int RAWK, int DEB, int DN>
 R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, int nblk, float* lds_f) {
   (void)nblk;
   const R2LStaticArgs& a = ca.s;
+  const int NW = ca.nw;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double* ex = (double*)lds_f;
   r2l_d2* fifo = (r2l_d2*)(ex + 2 * NW * R2L_CHAIN_EX) + (size_t)wave * (R2L_CHAIN_FIFO_DOUBLES / 2);
@@ -256,41 +344,46 @@ R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, i
   const size_t plane = (size_t)a.H * a.W;
   const size_t img = (size_t)b * plane;
   float* outb = a.out + (size_t)b * 3 * plane;
-  R2LChainState st;
+  R2LChainState<DEB, DN> st;
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < (DN == 0 ? 6 : 3); ++i)
     R2L_PRAGMA_UNROLL
-  for (int c = 0; c < 4; ++c) st.hb[i][c] = 0.0;  // rows outside the image are never written: they stay finite
+  for (int c = 0; c < (DN == 0 ? 4 : 6); ++c) st.hb[i][c] = 0.0;  // rows outside the image are never written: they stay finite
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 3; ++i)
     R2L_PRAGMA_UNROLL
   for (int c = 0; c < 4; ++c) st.yr[i][c] = 0.0;
   st.yl = st.yrr = 0.0;
-  // first luma row computed: q0 <= y0 - 3 (Hb(y0-2) needs Y'(y0-2) needs Y(y0-3)), rounded down to a multiple of 6
-  // so that q mod 6 is the unroll position; last: y1 + 2
-  int q0 = y0 - 3;
+  // Output row y = q - LAG.  First luma row computed: q0 <= y0 - LAG (Gaussian: Hb(y0-2) needs Y'(y0-2) needs
+  // Y(y0-3); median: Y'(y0-1) needs Y(y0-2)), rounded down to a multiple of 6 so that q mod 6 is the unroll
+  // position; last: y1 + LAG - 1
+  constexpr int LAG = DN == 0 ? 3 : 2;
+  constexpr int LA = DEB ? 2 : 1;  // raw rows the demosaic looks ahead
+  constexpr int NR = DEB ? 6 : 3;
+  int q0 = y0 - LAG;
   q0 = (q0 >= 0) ? q0 - q0 % 6 : -(((-q0) + 5) / 6) * 6;
-  const int q1 = y1 + 3;  // exclusive
+  const int q1 = y1 + LAG;  // exclusive
   constexpr bool LANES = R2L_HAVE_LANE_SHIFTS;
-  constexpr int PF = R2L_CHAIN_PF;
+  constexpr int PF = DEB ? 2 : R2L_CHAIN_PF;
   R2LRowStageT<RAWK> stage;
-  // warm-up: raw rows q0-1 and q0 into slots (q0-1) mod 3 = 2 and q0 mod 3 = 0
-  r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 - 1, a.H), x0, le, re, stage);
-  r2l_stream_convert_row<RAWK, LANES>(a, stage, le, re, st.rw[2]);
-  r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0, a.H), x0, le, re, stage);
-  r2l_stream_convert_row<RAWK, LANES>(a, stage, le, re, st.rw[0]);
-  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
-  R2LRowStageT<RAWK> pf[PF];  // ring: raw row r sits in pf[(r - 1 - q0) % PF]; step K consumes pf[K % PF] (row q + 1)
+  // warm-up: raw rows q0-LA .. q0+LA-1 into their slots (q0 is a multiple of 6, hence of NR)
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < PF; ++i) r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 + 1 + i, a.H), x0, le, re, pf[i]);
+  for (int i = -LA; i < LA; ++i) {
+    r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 + i, a.H), x0, le, re, stage);
+    r2l_stream_convert_row<RAWK, LANES>(a, stage, le, re, st.rw[(i + NR) % NR]);
+  }
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  R2LRowStageT<RAWK> pf[PF];  // ring: step K consumes pf[K % PF] (raw row q + LA) and refills it with row q + LA + PF
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i) r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 + LA + i, a.H), x0, le, re, pf[i]);
   for (int qb = q0; qb < q1; qb += 6) {
 #define R2L_CHAIN_STEP(K)                                                                                         \
   if (qb + K < q1) {                                                                                              \
     const int q = qb + K;                                                                                         \
-    r2l_stream_convert_row<RAWK, LANES>(a, pf[K % PF], le, re, st.rw[(K + 1) % 3]);                               \
-    if (q + 1 + PF < q1 + 1)                                                                                      \
-      r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q + 1 + PF, a.H), x0, le, re, pf[K % PF]);          \
-    r2l_chain_step<NW, K>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, outb, plane, x0, store_ok);            \
+    r2l_stream_convert_row<RAWK, LANES>(a, pf[K % PF], le, re, st.rw[(K + LA) % NR]);                             \
+    if (q + PF < q1)                                                                                              \
+      r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q + LA + PF, a.H), x0, le, re, pf[K % PF]);         \
+    r2l_chain_step<DEB, DN, K>(a, st, q, y0, y1, le, re, NW, wave, lane, ex, fifo, outb, plane, x0, store_ok);   \
   }
     R2L_CHAIN_STEP(0)
     R2L_CHAIN_STEP(1)

@@ -320,28 +320,31 @@ def test_bench_e2e_workloads(dev):
                                    (1, 4, 8), (1, 200, 256)], ids=str)
 def test_static_luma_chain_streaming_kernel(shape, dev):
     """the row-streaming luma-chain kernel (r2l_static_chain.h) on frames 1, 2, 4 and 8 wavefronts wide, several
-    bands high, partially filled last wavefront: every chain it serves, float32 / 16-bit / float64 frames, against
-    the oracle (the reference's own arithmetic on scipy)"""
+    bands high, partially filled last wavefront: every chain it serves (bilinear / Malvar2004 x [sharpening_filter] x
+    [gaussian_denoising | median_denoising]), float32 / 16-bit / float64 frames, against the oracle (the reference's own
+    arithmetic on scipy)"""
     from raw2logit_amd import functional as F_
     B, H, W = shape
     u = np.random.default_rng(W + H).integers(0, 4096, (B, H, W)).astype(np.uint16)
     u[:, : H // 3] = np.random.default_rng(1).integers(250, 262, (B, H // 3, W))     # around the black level
     raw_np = u.astype(np.float32) / np.float32(4095)
-    for sh, dn in (('sharpening_filter', 'gaussian_denoising'), ('sharpening_filter', 'none'),
-                   ('none', 'gaussian_denoising')):
-        ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, 'bilinear', sh, dn)
-        out = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), orc.DRONE_CAMERA_PARAMS, 'bilinear', sh, dn)
-        err = np.abs(out.cpu().numpy() - ref)
-        pc.report(f'static-chain/{shape}/{sh}+{dn}/float32 frames', err.max(), 1e-5)
-        assert err.max() <= 1e-5, (shape, sh, dn, err.max(), np.unravel_index(err.argmax(), err.shape))
-        out16 = F_.static_pipeline(torch.from_numpy(u).to(dev), orc.DRONE_CAMERA_PARAMS, 'bilinear', sh, dn, bits=12)
-        assert torch.equal(out16, out), (shape, sh, dn, '16-bit containers')
-        ref64 = orc.static_batch(raw_np.astype(np.float64), orc.DRONE_CAMERA_PARAMS, 'bilinear', sh, dn)
-        out64 = F_.static_pipeline(torch.from_numpy(raw_np.astype(np.float64)).to(dev), orc.DRONE_CAMERA_PARAMS,
-                                   'bilinear', sh, dn)
-        e64 = np.abs(out64.cpu().numpy() - ref64).max()
-        pc.report(f'static-chain/{shape}/{sh}+{dn}/float64 frames', e64, 1e-5)
-        assert e64 <= 1e-5, (shape, sh, dn, 'float64 frames', e64)
+    for deb in ('bilinear', 'malvar2004'):
+        for sh, dn in (('sharpening_filter', 'gaussian_denoising'), ('sharpening_filter', 'none'),
+                       ('none', 'gaussian_denoising'), ('sharpening_filter', 'median_denoising'),
+                       ('none', 'median_denoising')):
+            ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
+            out = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
+            err = np.abs(out.cpu().numpy() - ref)
+            pc.report(f'static-chain/{shape}/{deb}+{sh}+{dn}/float32 frames', err.max(), 1e-5)
+            assert err.max() <= 1e-5, (shape, deb, sh, dn, err.max(), np.unravel_index(err.argmax(), err.shape))
+            out16 = F_.static_pipeline(torch.from_numpy(u).to(dev), orc.DRONE_CAMERA_PARAMS, deb, sh, dn, bits=12)
+            assert torch.equal(out16, out), (shape, deb, sh, dn, '16-bit containers')
+            ref64 = orc.static_batch(raw_np.astype(np.float64), orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
+            out64 = F_.static_pipeline(torch.from_numpy(raw_np.astype(np.float64)).to(dev), orc.DRONE_CAMERA_PARAMS,
+                                       deb, sh, dn)
+            e64 = np.abs(out64.cpu().numpy() - ref64).max()
+            pc.report(f'static-chain/{shape}/{deb}+{sh}+{dn}/float64 frames', e64, 1e-5)
+            assert e64 <= 1e-5, (shape, deb, sh, dn, 'float64 frames', e64)
 
 
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
