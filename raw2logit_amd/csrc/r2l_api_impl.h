@@ -225,13 +225,13 @@ R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
 #define R2L_CHAIN_OCC 2
 #endif
 // (the workgroup size and the LDS size follow the frame width at launch time: 64 threads and 16.1 KB per strip)
-#define R2L_CHAIN_KERNEL(name, RAWK, DEB, DN)                                                                 \
-  __global__ __launch_bounds__(512, R2L_CHAIN_OCC) void name##_kernel(const R2LStaticChainArgs a) {           \
+#define R2L_CHAIN_KERNEL(name, RAWK, DEB, SH, DN)                                                             \
+  __global__ __launch_bounds__((SH) ? 256 : 512, R2L_CHAIN_OCC) void name##_kernel(const R2LStaticChainArgs a) { \
     extern __shared__ __attribute__((aligned(16))) float r2l_chain_lds[];                                     \
-    r2l_static_chain_block<RAWK, DEB, DN>(a, (int)blockIdx.x, (int)gridDim.x, r2l_chain_lds);                 \
+    r2l_static_chain_block<RAWK, DEB, SH, DN>(a, (int)blockIdx.x, (int)gridDim.x, r2l_chain_lds);             \
   }                                                                                                           \
   static int name(const R2LStaticChainArgs& a, int grid, void* stream) {                                      \
-    const size_t lds_bytes = sizeof(double) * R2L_CHAIN_LDS_DOUBLES(a.nw);                                    \
+    const size_t lds_bytes = sizeof(double) * R2L_CHAIN_LDS_DOUBLES(a.nw, SH);                                \
     static size_t lds_ok = 48 * 1024;                                                                         \
     if (lds_bytes > lds_ok) {                                                                                 \
       const hipError_t ea = hipFuncSetAttribute((const void*)name##_kernel,                                   \
@@ -248,18 +248,19 @@ R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
     if (e != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(e));                \
     return 0;                                                                                                 \
   }
-R2L_CHAIN_KERNEL(r2l_launch_static_chain, R2L_RAW_F32, 0, 0)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_median, R2L_RAW_F32, 0, 1)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar, R2L_RAW_F32, 1, 0)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_median, R2L_RAW_F32, 1, 1)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_u16, R2L_RAW_U16, 0, 0)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_median_u16, R2L_RAW_U16, 0, 1)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_u16, R2L_RAW_U16, 1, 0)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_median_u16, R2L_RAW_U16, 1, 1)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_f64, R2L_RAW_F64, 0, 0)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_median_f64, R2L_RAW_F64, 0, 1)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_f64, R2L_RAW_F64, 1, 0)
-R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_median_f64, R2L_RAW_F64, 1, 1)
+// [16-bit / float64 frames] x [Malvar2004] x [unsharp_masking] x [median_denoising]
+#define R2L_CHAIN_KERNELS(sfx, RAWK)                                               \
+  R2L_CHAIN_KERNEL(r2l_launch_static_chain##sfx, RAWK, 0, 0, 0)                    \
+  R2L_CHAIN_KERNEL(r2l_launch_static_chain_median##sfx, RAWK, 0, 0, 1)             \
+  R2L_CHAIN_KERNEL(r2l_launch_static_chain_unsharp##sfx, RAWK, 0, 1, 0)            \
+  R2L_CHAIN_KERNEL(r2l_launch_static_chain_unsharp_median##sfx, RAWK, 0, 1, 1)     \
+  R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar##sfx, RAWK, 1, 0, 0)             \
+  R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_median##sfx, RAWK, 1, 0, 1)      \
+  R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_unsharp##sfx, RAWK, 1, 1, 0)     \
+  R2L_CHAIN_KERNEL(r2l_launch_static_chain_malvar_unsharp_median##sfx, RAWK, 1, 1, 1)
+R2L_CHAIN_KERNELS(, R2L_RAW_F32)
+R2L_CHAIN_KERNELS(_u16, R2L_RAW_U16)
+R2L_CHAIN_KERNELS(_f64, R2L_RAW_F64)
 #endif
 R2L_KERNEL(r2l_launch_static_short, R2LStaticArgs, r2l_static_short_block<GStatic>,
            R2L_STATIC_SHORT_LDS_FLOATS)
@@ -815,8 +816,9 @@ static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoisin
   return false;  // (lane shifts and wave-level exchange: not expressible in the one-lane-at-a-time emulation)
 #else
   if (r2l_env_int("R2L_STATIC_TILED", 0)) return false;
-  (void)debayer;  // bilinear and Malvar2004 both
-  return (W & 3) == 0 && W <= 2048 && (sharpening == R2L_SHARPEN_NONE || sharpening == R2L_SHARPEN_FILTER) &&
+  (void)debayer;  // every demosaic, sharpening and denoising the library knows -- but for the chain without a luma stage
+  // (behind unsharp_masking the chroma waits 7 rows for its luma: 28 KB of LDS per 256-column strip, 4 strips at most)
+  return (W & 3) == 0 && W <= (sharpening == R2L_SHARPEN_UNSHARP ? 1024 : 2048) &&
          !(sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE);
 #endif
 }
@@ -882,14 +884,15 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     const int kind = raw.u16 ? 1 : (raw.f64 ? 2 : 0);
     const int deb = debayer == R2L_DEBAYER_MALVAR2004 ? 1 : 0, dn = denoising == R2L_DENOISE_MEDIAN ? 1 : 0;
     typedef int (*launch_t)(const R2LStaticChainArgs&, int, void*);
-    static const launch_t table[3][2][2] = {
-        {{r2l_launch_static_chain, r2l_launch_static_chain_median},
-         {r2l_launch_static_chain_malvar, r2l_launch_static_chain_malvar_median}},
-        {{r2l_launch_static_chain_u16, r2l_launch_static_chain_median_u16},
-         {r2l_launch_static_chain_malvar_u16, r2l_launch_static_chain_malvar_median_u16}},
-        {{r2l_launch_static_chain_f64, r2l_launch_static_chain_median_f64},
-         {r2l_launch_static_chain_malvar_f64, r2l_launch_static_chain_malvar_median_f64}}};
-    return table[kind][deb][dn](ca, (int)grid, stream);
+    const int sh = sharpening == R2L_SHARPEN_UNSHARP ? 1 : 0;
+#define R2L_CHAIN_ROW(sfx)                                                                                          \
+  {{{r2l_launch_static_chain##sfx, r2l_launch_static_chain_median##sfx},                                            \
+    {r2l_launch_static_chain_unsharp##sfx, r2l_launch_static_chain_unsharp_median##sfx}},                           \
+   {{r2l_launch_static_chain_malvar##sfx, r2l_launch_static_chain_malvar_median##sfx},                              \
+    {r2l_launch_static_chain_malvar_unsharp##sfx, r2l_launch_static_chain_malvar_unsharp_median##sfx}}}
+    static const launch_t table[3][2][2][2] = {R2L_CHAIN_ROW(), R2L_CHAIN_ROW(_u16), R2L_CHAIN_ROW(_f64)};
+#undef R2L_CHAIN_ROW
+    return table[kind][deb][sh][dn](ca, (int)grid, stream);
   }
 #endif
   if (!r2l_static_is_fused(W, debayer, sharpening, denoising, raw.f64 != nullptr)) {
@@ -935,12 +938,8 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
       pa.W = W;
       pa.op = ops[i];
       for (int k = 0; k < 5; ++k) pa.gk[k] = a.gk[k];
-      {  // scipy _gaussian_kernel1d(sigma = 1, radius = int(4 * 1 + 0.5) = 4), normalised
-        double w[9], sum = 0;
-        for (int k = -4; k <= 4; ++k) sum += (w[k + 4] = exp(-0.5 * k * k));
-        for (int k = 0; k <= 4; ++k) pa.uk[k] = w[4 + k] / sum;
-        pa.amount = 1.0;
-      }
+      for (int k = 0; k < 5; ++k) pa.uk[k] = a.uk[k];
+      pa.amount = a.amount;
       size_t g = ((size_t)B * H * W / 2 + R2L_NT - 1) / R2L_NT;
       if (g > 16384) g = 16384;
       if (int e = r2l_launch_plane_filter(pa, (int)g, stream)) return e;

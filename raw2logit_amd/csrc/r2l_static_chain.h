@@ -56,15 +56,19 @@ R2L_HD double r2l_wave_shl1_d(double x, double edge) {
 }
 
 #define R2L_CHAIN_EX 8                                  // doubles per wavefront and buffer in the exchange area
-#define R2L_CHAIN_FIFO_DOUBLES (4 * 4 * 64 * 2)         // 4 rows x (U[4], V[4]) x 64 lanes = 16 KB per wavefront
-#define R2L_CHAIN_LDS_DOUBLES(NW) (2 * (NW) * R2L_CHAIN_EX + (NW) * R2L_CHAIN_FIFO_DOUBLES)
+// chroma ring: FR rows x (U[4], V[4]) x 64 lanes: 4 rows = 16 KB per wavefront (7 rows, 28 KB, behind unsharp_masking)
+#define R2L_CHAIN_FIFO_ROWS(SH) ((SH) ? 7 : 4)
+#define R2L_CHAIN_FIFO_DOUBLES(SH) (R2L_CHAIN_FIFO_ROWS(SH) * 4 * 64 * 2)
+#define R2L_CHAIN_LDS_DOUBLES(NW, SH) (2 * (NW) * R2L_CHAIN_EX + (NW) * R2L_CHAIN_FIFO_DOUBLES(SH))
 
 // per-lane state of the luma chain
-template <int DEB, int DN>
+template <int DEB, int SH, int DN>
 struct R2LChainState {
   double rw[DEB ? 6 : 3][8];  // raw rows (slot = row mod 3 / mod 6): columns x0-2 .. x0+5, black level removed
-  double yr[3][4];            // luma rows (slot = row mod 3)
-  double yl, yrr;             // left / right neighbour of the luma row q-1 (zero outside the image)
+  // SH 0: luma rows q-2 .. q (slot = row mod 3).  SH 1 (unsharp_masking: 9 rows, which no ring that divides the
+  // 6-fold unroll holds): rows q-8 .. q as a shift register, [8] = row q
+  double yr[SH ? 9 : 3][4];
+  double yl, yrr;             // SH 0: left / right neighbour of the luma row q-1 (zero outside the image)
   // DN 0: horizontally blurred sharpened luma, own columns (slot = row mod 6)
   // DN 1: sharpened luma, columns x0-1 .. x0+4 (symmetric at the image edges) (slot = row mod 3)
   double hb[DN == 0 ? 6 : 3][DN == 0 ? 4 : 6];
@@ -93,20 +97,23 @@ R2L_HD R2LStaticArgsK r2l_chain_consts() {
 #endif
 }
 
-template <int DEB, int DN, int K>
-R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, DN>& st, int q, int y0, int y1, bool le,
+template <int DEB, int SH, int DN, int K0>
+R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, SH, DN>& st, int q_, int y0, int y1, bool le,
                            bool re, int NW, int wave, int lane, double* ex, r2l_d2* fifo, float* outb, size_t plane,
                            int x0, bool store_ok) {
-  constexpr int PY = K & 1;
+  constexpr int PY = K0 & 1;
+  constexpr int FR = R2L_CHAIN_FIFO_ROWS(SH);
   const int H = a_.H;
 #ifdef R2L_CHAIN_ARGS_LIVE
   const R2LStaticArgs& a = a_;
 #else
   const __attribute__((address_space(4))) R2LStaticArgs& a = *r2l_chain_consts();
 #endif
-  double* yq = st.yr[K % 3];                 // Y(q)   (new)
-  const double* ym = st.yr[(K + 2) % 3];     // Y(q-1)
-  const double* yu = st.yr[(K + 1) % 3];     // Y(q-2)
+  double yq[4];  // Y(q) (new)
+  double yp[4];  // the sharpened row it completes
+  {
+  constexpr int K = K0;
+  const int q = q_;
   const bool qin = (unsigned)q < (unsigned)H;
   // ---- demosaic + colour of row q: Y(q) to the window, (U, V)(q) to the LDS ring ---------------------------
   {
@@ -141,13 +148,54 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, DN>& st, 
       R2L_PRAGMA_UNROLL
       for (int c = 0; c < 4; ++c) yq[c] = 0.0;
     }
-    r2l_d2* f = fifo + (size_t)(q & 3) * 4 * 64 + lane;  // [row slot][c][lane]: 16-byte lane stride, conflict-free
+    r2l_d2* f = fifo + (size_t)((q + 2 * FR) % FR) * 4 * 64 + lane;  // [row slot][c][lane]: 16-byte lane stride, conflict-free
     R2L_PRAGMA_UNROLL
     for (int c = 0; c < 4; ++c) f[c * 64] = uv[c];
   }
-  // ---- Y'(q-1) = sharpen: centre cross of a.ksharp (the corners of both K and the identity are zero) --------
-  double yp[4];
-  {
+  if (SH == 1) {
+    // ---- Y'(q-4) = unsharp_mask(Y, radius 1, amount 1) as the reference calls it (multichannel=True on the 2-D
+    // plane: every column is a channel, so the sigma-1 Gaussian runs down the columns only; pipeline_numpy.py:170-177):
+    // Y + (Y - g (*)_y Y) * amount, 9 taps, scipy 'reflect' = symmetric rows ------------------------------------
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 8; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) st.yr[i][c] = st.yr[i + 1][c];
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) st.yr[SH ? 8 : 2][c] = yq[c];
+    const int r = q - 4;
+    double wv[9];
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 9; ++k) wv[k] = a.uk[k < 4 ? 4 - k : k - 4];
+    if (r < 4 || r > H - 5) {  // a row outside the image gives its weight to its mirror image
+      R2L_PRAGMA_UNROLL
+      for (int k = 0; k < 9; ++k) wv[k] = ((unsigned)(r + k - 4) < (unsigned)H) ? a.uk[k < 4 ? 4 - k : k - 4] : 0.0;
+      R2L_PRAGMA_UNROLL
+      for (int k = 0; k < 9; ++k) {
+        const int rr = r + k - 4;
+        if ((unsigned)rr >= (unsigned)H) {
+          const int t = r2l_symmetric(rr, H) - (r - 4);  // window slot of the mirror image
+          R2L_PRAGMA_UNROLL
+          for (int j = 0; j < 9; ++j) wv[j] += (j == t) ? a.uk[k < 4 ? 4 - k : k - 4] : 0.0;
+        }
+      }
+    }
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      // scipy correlate1d sums w0 * c + sum_k (up_k + down_k) * w_k; the mirrored form keeps the same terms
+      double bl = wv[4] * st.yr[SH ? 4 : 0][c];
+      R2L_PRAGMA_UNROLL
+      for (int k = 1; k <= 4; ++k)
+        bl += st.yr[SH ? 4 - k : 0][c] * wv[4 - k] + st.yr[SH ? 4 + k : 0][c] * wv[4 + k];
+      const double cc = st.yr[SH ? 4 : 0][c];
+      yp[c] = cc + (cc - bl) * a.amount;
+    }
+  } else {
+    // ---- Y'(q-1) = sharpen: centre cross of a.ksharp (the corners of both K and the identity are zero) --------
+    double* ynew = st.yr[K % 3];
+    const double* ym = st.yr[(K + 2) % 3];     // Y(q-1)
+    const double* yu = st.yr[(K + 1) % 3];     // Y(q-2)
+    R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c) ynew[c] = yq[c];
     const double kc = a.ksharp[4], kl = a.ksharp[3], kr = a.ksharp[5], ku = a.ksharp[1], kd = a.ksharp[7];
     // convolve2d flips the kernel: out(p) = sum K[i][j] * Y(p - (i-1, j-1))  ->  K[1][0] weighs the RIGHT
     // neighbour, K[0][1] the row BELOW
@@ -157,6 +205,10 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, DN>& st, 
       yp[c] = fma(kc, ym[c], fma(kl, right, fma(kr, left, fma(ku, yq[c], kd * yu[c]))));
     }
   }
+  }
+  // From here on in terms of q = q_ - 3 behind unsharp_masking (its Y' row is q_ - 4 = q - 1, as behind the 3x3).
+  constexpr int K = SH ? (K0 + 3) % 6 : K0;
+  const int q = SH ? q_ - 3 : q_;
   // ---- strip edges: this wavefront's edge columns to LDS, the neighbours' back ----------------------------
   double rl_y = 0.0, rl_p2 = 0.0, rl_p3 = 0.0;  // from the left wavefront: its Y(q)[col 3], Y'(q-1)[cols 2, 3]
   double rr_y = 0.0, rr_p0 = 0.0, rr_p1 = 0.0;  // from the right wavefront: its Y(q)[col 0], Y'(q-1)[cols 0, 1]
@@ -225,7 +277,7 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, DN>& st, 
         mi[j] = c;
         hi[j] = n;
       }
-      const r2l_d2* f = fifo + (size_t)(y & 3) * 4 * 64 + lane;
+      const r2l_d2* f = fifo + (size_t)((y + 2 * FR) % FR) * 4 * 64 + lane;
       float x[3][4];
       R2L_PRAGMA_UNROLL
       for (int c = 0; c < 4; ++c) {
@@ -299,7 +351,7 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, DN>& st, 
     const double* h2 = st.hb[(K + 3) % (DN == 0 ? 6 : 3)];
     const double* h3 = st.hb[(K + 4) % (DN == 0 ? 6 : 3)];
     const double* h4 = st.hb[(K + 5) % (DN == 0 ? 6 : 3)];
-    const r2l_d2* f = fifo + (size_t)(y & 3) * 4 * 64 + lane;
+    const r2l_d2* f = fifo + (size_t)((y + 2 * FR) % FR) * 4 * 64 + lane;
     float x[3][4];
     R2L_PRAGMA_UNROLL
     for (int c = 0; c < 4; ++c) {
@@ -326,14 +378,14 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, DN>& st, 
   }
 }
 
-template <int RAWK, int DEB, int DN>
+template <int RAWK, int DEB, int SH, int DN>
 R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, int nblk, float* lds_f) {
   (void)nblk;
   const R2LStaticArgs& a = ca.s;
   const int NW = ca.nw;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double* ex = (double*)lds_f;
-  r2l_d2* fifo = (r2l_d2*)(ex + 2 * NW * R2L_CHAIN_EX) + (size_t)wave * (R2L_CHAIN_FIFO_DOUBLES / 2);
+  r2l_d2* fifo = (r2l_d2*)(ex + 2 * NW * R2L_CHAIN_EX) + (size_t)wave * (R2L_CHAIN_FIFO_DOUBLES(SH) / 2);
   const int band = bid % ca.nband, b = bid / ca.nband;
   const int y0 = band * ca.band_h;
   const int y1 = (y0 + ca.band_h < a.H) ? y0 + ca.band_h : a.H;
@@ -344,20 +396,20 @@ R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, i
   const size_t plane = (size_t)a.H * a.W;
   const size_t img = (size_t)b * plane;
   float* outb = a.out + (size_t)b * 3 * plane;
-  R2LChainState<DEB, DN> st;
+  R2LChainState<DEB, SH, DN> st;
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < (DN == 0 ? 6 : 3); ++i)
     R2L_PRAGMA_UNROLL
   for (int c = 0; c < (DN == 0 ? 4 : 6); ++c) st.hb[i][c] = 0.0;  // rows outside the image are never written: they stay finite
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < (SH ? 9 : 3); ++i)
     R2L_PRAGMA_UNROLL
   for (int c = 0; c < 4; ++c) st.yr[i][c] = 0.0;
   st.yl = st.yrr = 0.0;
   // Output row y = q - LAG.  First luma row computed: q0 <= y0 - LAG (Gaussian: Hb(y0-2) needs Y'(y0-2) needs
-  // Y(y0-3); median: Y'(y0-1) needs Y(y0-2)), rounded down to a multiple of 6 so that q mod 6 is the unroll
-  // position; last: y1 + LAG - 1
-  constexpr int LAG = DN == 0 ? 3 : 2;
+  // Y(y0-3); median: Y'(y0-1) needs Y(y0-2); unsharp_masking: 3 rows more on either side), rounded down to a multiple
+  // of 6 so that q mod 6 is the unroll position; last: y1 + LAG - 1
+  constexpr int LAG = (DN == 0 ? 3 : 2) + (SH ? 3 : 0);
   constexpr int LA = DEB ? 2 : 1;  // raw rows the demosaic looks ahead
   constexpr int NR = DEB ? 6 : 3;
   int q0 = y0 - LAG;
@@ -383,7 +435,7 @@ R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, i
     r2l_stream_convert_row<RAWK, LANES>(a, pf[K % PF], le, re, st.rw[(K + LA) % NR]);                             \
     if (q + PF < q1)                                                                                              \
       r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q + LA + PF, a.H), x0, le, re, pf[K % PF]);         \
-    r2l_chain_step<DEB, DN, K>(a, st, q, y0, y1, le, re, NW, wave, lane, ex, fifo, outb, plane, x0, store_ok);   \
+    r2l_chain_step<DEB, SH, DN, K>(a, st, q, y0, y1, le, re, NW, wave, lane, ex, fifo, outb, plane, x0, store_ok); \
   }
     R2L_CHAIN_STEP(0)
     R2L_CHAIN_STEP(1)

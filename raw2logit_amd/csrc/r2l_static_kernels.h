@@ -48,6 +48,8 @@ struct R2LStaticArgs {
   double M2[9];     // rgb_from_yuv = inv(yuv_from_rgb)
   double ksharp[9];
   double gk[5];  // gaussian taps, sigma 0.5, radius 2
+  double uk[5];  // unsharp_masking: half of the 9-tap Gaussian (sigma 1): uk[0] = centre tap ... uk[4] = offset +-4
+  double amount;  // unsharp_masking
   float inv_gamma;
 };
 
@@ -106,6 +108,12 @@ static inline void r2l_static_setup(R2LStaticArgs& a, const R2LRaw& raw, float* 
     for (int i = 0; i < 5; ++i) a.gk[i] = w[i] / s;
   } else {
     for (int i = 0; i < 5; ++i) a.gk[i] = (i == 2) ? 1.0 : 0.0;
+  }
+  {  // scipy _gaussian_kernel1d(sigma = 1, radius = int(4 * 1 + 0.5) = 4), normalised (skimage unsharp_mask, radius 1)
+    double w[9], sum = 0;
+    for (int k = -4; k <= 4; ++k) sum += (w[k + 4] = exp(-0.5 * k * k));
+    for (int k = 0; k <= 4; ++k) a.uk[k] = w[4 + k] / sum;
+    a.amount = 1.0;
   }
   a.inv_gamma = (float)(1.0 / gamma);
 }

@@ -320,9 +320,9 @@ def test_bench_e2e_workloads(dev):
                                    (1, 4, 8), (1, 200, 256)], ids=str)
 def test_static_luma_chain_streaming_kernel(shape, dev):
     """the row-streaming luma-chain kernel (r2l_static_chain.h) on frames 1, 2, 4 and 8 wavefronts wide, several
-    bands high, partially filled last wavefront: every chain it serves (bilinear / Malvar2004 x [sharpening_filter] x
-    [gaussian_denoising | median_denoising]), float32 / 16-bit / float64 frames, against the oracle (the reference's own
-    arithmetic on scipy)"""
+    bands high, partially filled last wavefront: every chain it serves (bilinear / Malvar2004 x [sharpening_filter |
+    unsharp_masking] x [gaussian_denoising | median_denoising]; unsharp_masking on frames wider than 1024 runs as plane
+    passes), float32 / 16-bit / float64 frames, against the oracle (the reference's own arithmetic on scipy)"""
     from raw2logit_amd import functional as F_
     B, H, W = shape
     u = np.random.default_rng(W + H).integers(0, 4096, (B, H, W)).astype(np.uint16)
@@ -331,7 +331,8 @@ def test_static_luma_chain_streaming_kernel(shape, dev):
     for deb in ('bilinear', 'malvar2004'):
         for sh, dn in (('sharpening_filter', 'gaussian_denoising'), ('sharpening_filter', 'none'),
                        ('none', 'gaussian_denoising'), ('sharpening_filter', 'median_denoising'),
-                       ('none', 'median_denoising')):
+                       ('none', 'median_denoising'), ('unsharp_masking', 'none'),
+                       ('unsharp_masking', 'gaussian_denoising'), ('unsharp_masking', 'median_denoising')):
             ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
             out = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
             err = np.abs(out.cpu().numpy() - ref)
