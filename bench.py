@@ -95,6 +95,8 @@ def parse():
     ap.add_argument('--debayer', choices=('bilinear', 'malvar2004'), default='bilinear')
     ap.add_argument('--sharpening', default='none', help="static workload: 'none' | 'sharpening_filter' | 'unsharp_masking'")
     ap.add_argument('--denoising', default='none', help="static workload: 'none' | 'gaussian_denoising' | 'median_denoising'")
+    ap.add_argument('--normalize', action='store_true',
+                    help='static workload: with the T.Normalize(mean, std) epilogue of train.py:157-171')
     ap.add_argument('--no-static-c3', action='store_true',
                     help='skip the static_c3 sub-records (BASELINE config 3) appended to the headline line')
     ap.add_argument('--raw-u16', action='store_true',
@@ -354,9 +356,10 @@ def main_static(args):
     u = torch.randint(0, 4096, (B, S, S), device=dev, generator=gen, dtype=torch.int32)
     raw = u.to(torch.uint16) if args.raw_u16 else u.to(torch.float32) / 4095.0
     chain = (args.debayer, args.sharpening, args.denoising)
+    norm = [0.35, 0.36, 0.35, 0.12, 0.11, 0.12] if args.normalize else None      # train.py:157-158 (Drone)
 
     def step():
-        return F_.static_pipeline(raw, cameras.DRONE, *chain, bits=12)
+        return F_.static_pipeline(raw, cameras.DRONE, *chain, bits=12, mean_std=norm)
 
     dt = clock.time_steps(step, args.steps, args.warmup)
     px = world * B * S * S
@@ -380,7 +383,8 @@ def main_static(args):
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                'config': {'workload': ('static short chain' if short else 'static chain ' + '+'.join(chain[1:])) +
                                       f' ({args.debayer}), {B}x{S}x{S} 12-bit RGGB frames per GPU'
-                                      + (' as uint16 containers' if args.raw_u16 else '') + ', Drone camera parameters',
+                                      + (' as uint16 containers' if args.raw_u16 else '') + ', Drone camera parameters'
+                                      + (', T.Normalize epilogue' if args.normalize else ''),
                           'global_batch': world * B, 'frame': [S, S],
                           'parallelism': f'batch shard x{world}, no collective' if world > 1 else 'single GPU'},
                'roofline': roofline, 'kernels': k}

@@ -196,10 +196,11 @@ int r2l_isp_step_bwd(const void *raw, int raw_u16, float denom, const float *add
  * (:194-200)] -> clip[0,1] (:138) -> x**(1/gamma) (:241-244).  Linear part in float64 like the reference (black level: see below),
  * output (B,3,H,W) float32 (RawProcessingPipeline.__call__, :55-67).  camera_host: double[16] =
  * black_level[4], white_balance[3], colour_matrix[9] (host memory).
- * The short chain (no sharpening, no denoising: BASELINE config 3) and bilinear + sharpening_filter +
- * gaussian_denoising (the defaults of train.py:96-101) are single launches; the other combinations run as
- * float64 luma-plane passes and need r2l_static_workspace_bytes() of device memory (0 for the fused ones;
- * workspace may then be NULL) and W % 4 == 0.                                                          */
+ * On frames with W % 4 == 0 up to 2048 wide (1024 behind unsharp_masking) every combination is ONE launch
+ * (row-streaming kernels); otherwise the short chain and the train.py defaults (bilinear + sharpening_filter
+ * + gaussian_denoising, train.py:96-101) run as tile kernels and the other combinations as float64
+ * luma-plane passes, which need r2l_static_workspace_bytes() of device memory (0 for the single-launch
+ * ones; workspace may then be NULL) and W % 4 == 0.                                                     */
 size_t r2l_static_workspace_bytes(int B, int H, int W, int debayer, int sharpening, int denoising);
 int r2l_static_fwd(const float *raw, float *out, int B, int H, int W, const double *camera_host,
                    int debayer, int sharpening, int denoising, double gamma, void *workspace,
@@ -210,8 +211,7 @@ int r2l_static_fwd(const float *raw, float *out, int B, int H, int W, const doub
  * datasets' float32 division) therefore rounds the black level to float32 and subtracts in float32 before
  * widening -- near-black pixels differ by up to 1e-4 after the gamma from a float64 subtraction.  A float64
  * ndarray (a DNG: uint16 raw_image_visible / (2**bits - 1) is float64) keeps float64 arithmetic throughout:
- * r2l_static_fwd_f64 reads float64 frames (8 B/px; W % 4 == 0; every chain but the short one runs as
- * luma-plane passes and needs r2l_static_workspace_bytes_f64()).                                         */
+ * r2l_static_fwd_f64 reads float64 frames (8 B/px; W % 4 == 0; workspace: r2l_static_workspace_bytes_f64()). */
 size_t r2l_static_workspace_bytes_f64(int B, int H, int W, int debayer, int sharpening, int denoising);
 int r2l_static_fwd_f64(const double *raw, float *out, int B, int H, int W, const double *camera_host,
                        int debayer, int sharpening, int denoising, double gamma, void *workspace,
@@ -239,6 +239,15 @@ int r2l_raw2rgb_fwd_u16(const unsigned short *raw, float denom, const float *bla
 int r2l_static_fwd_u16(const unsigned short *raw, float denom, float *out, int B, int H, int W,
                        const double *camera_host, int debayer, int sharpening, int denoising, double gamma,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* The static pipeline with the T.Normalize(mean, std) that train.py:157-171 composes behind RawProcessingPipeline
+ * fused into the kernels' stores: out = (processing(raw) - mean[c]) / std[c], float32 subtraction and division
+ * like torchvision's.  mean_std_host: float[6] = mean[3], std[3] in host memory, or NULL (then identical to the
+ * entry points above).  frames: which container `raw` points to (denom is read for R2L_FRAMES_U16 only);
+ * workspace as r2l_static_workspace_bytes() / _f64().                                                       */
+enum { R2L_FRAMES_F32 = 0, R2L_FRAMES_U16 = 1, R2L_FRAMES_F64 = 2 };
+int r2l_static_fwd_norm(const void *raw, int frames, float denom, float *out, int B, int H, int W,
+                        const double *camera_host, int debayer, int sharpening, int denoising, double gamma,
+                        const float *mean_std_host, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- staged execution (track_stages=True, pipeline_torch.py:197-221): one entry point per materialised
  * stage, each with its VJP, so that autograd can hold every stage tensor (retain_grad) and d/d raw exists.

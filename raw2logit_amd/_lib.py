@@ -114,6 +114,11 @@ _SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_void_p]),
+    'r2l_static_fwd_norm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                           ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.c_void_p]),
     'r2l_static_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,

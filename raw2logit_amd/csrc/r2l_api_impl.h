@@ -850,9 +850,12 @@ static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W, int d
 
 static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int W, const double* camera_host,
                                int debayer, int sharpening, int denoising, double gamma, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, void* stream, const float* mean_std_host = nullptr) {
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (int e = r2l_check_raw(raw, W, "r2l_static_fwd")) return e;
+  if (mean_std_host)
+    for (int k = 0; k < 3; ++k)
+      if (!(mean_std_host[3 + k] != 0.f)) return r2l_fail(-1, "r2l_static_fwd_norm: std must be non-zero");
   if (!out || !camera_host) return r2l_fail(-1, "r2l_static_fwd: null pointer");
   if (debayer != R2L_DEBAYER_BILINEAR && debayer != R2L_DEBAYER_MALVAR2004)
     return r2l_fail(-1, "r2l_static_fwd: unknown debayer");
@@ -862,7 +865,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     return r2l_fail(-4, "r2l_static_fwd: denoising must be none, gaussian_denoising or median_denoising");
   if (!(gamma > 0)) return r2l_fail(-1, "r2l_static_fwd: gamma must be > 0");
   R2LStaticArgs a;
-  r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma);
+  r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, mean_std_host);
   const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
 #ifndef R2L_EMUL
   if (r2l_static_is_chain(W, debayer, sharpening, denoising)) {
@@ -1067,6 +1070,21 @@ int r2l_static_fwd_u16(const unsigned short* raw, float denom, float* out, int B
                        void* workspace, size_t workspace_bytes, void* stream) {
   return r2l_static_fwd_impl(r2l_raw_u16(raw, denom), out, B, H, W, camera_host, debayer, sharpening, denoising,
                              gamma, workspace, workspace_bytes, stream);
+}
+int r2l_static_fwd_norm(const void* raw, int frames, float denom, float* out, int B, int H, int W,
+                        const double* camera_host, int debayer, int sharpening, int denoising, double gamma,
+                        const float* mean_std_host, void* workspace, size_t workspace_bytes, void* stream) {
+  R2LRaw rw;
+  if (frames == R2L_FRAMES_F32)
+    rw = r2l_raw_f32((const float*)raw);
+  else if (frames == R2L_FRAMES_U16)
+    rw = r2l_raw_u16((const unsigned short*)raw, denom);
+  else if (frames == R2L_FRAMES_F64)
+    rw = r2l_raw_f64((const double*)raw);
+  else
+    return r2l_fail(-1, "r2l_static_fwd_norm: frames must be R2L_FRAMES_F32, _U16 or _F64");
+  return r2l_static_fwd_impl(rw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, workspace,
+                             workspace_bytes, stream, mean_std_host);
 }
 
 // ---- staged (track_stages=True) entry points -------------------------------------------------------

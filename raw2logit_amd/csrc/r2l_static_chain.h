@@ -292,6 +292,7 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, SH, DN>& 
           x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
         }
       }
+      r2l_static_normalize<4>(a, x);
       if (store_ok) {
         const size_t off = (size_t)y * a_.W + x0;
         R2L_PRAGMA_UNROLL
@@ -363,6 +364,7 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, SH, DN>& 
         x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
       }
     }
+    r2l_static_normalize<4>(a, x);
     if (store_ok) {
       const size_t off = (size_t)y * a_.W + x0;
       R2L_PRAGMA_UNROLL

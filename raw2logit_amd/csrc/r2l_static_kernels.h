@@ -33,7 +33,7 @@
 #endif
 
 typedef R2LGeom<64, 64> GStatic;
-#define R2L_STATIC_LDS_FLOATS (2 * GStatic::PAD + 5 * GStatic::PLANE + 128)
+#define R2L_STATIC_LDS_FLOATS (2 * GStatic::PAD + 5 * GStatic::PLANE + 160)  // (+ the argument block)
 #define R2L_STATIC_SHORT_LDS_FLOATS (2 * GStatic::PAD + GStatic::PLANE)
 
 struct R2LStaticArgs {
@@ -51,6 +51,9 @@ struct R2LStaticArgs {
   double uk[5];  // unsharp_masking: half of the 9-tap Gaussian (sigma 1): uk[0] = centre tap ... uk[4] = offset +-4
   double amount;  // unsharp_masking
   float inv_gamma;
+  int normalize;            // epilogue (x - nmean[c]) / nstd[c]: the T.Normalize(mean, std) of train.py:157-171 (2: see r2l_static_normalize)
+  float nmean[3], nstd[3];
+  float nrcp[3];            // RN(1 / nstd[c])
 };
 
 static inline void r2l_inv3(const double* m, double* o) {
@@ -70,7 +73,16 @@ static inline void r2l_inv3(const double* m, double* o) {
 
 static inline void r2l_static_setup(R2LStaticArgs& a, const R2LRaw& raw, float* out, int B, int H, int W,
                                     const double* cam, int debayer, int sharpening, int denoising,
-                                    double gamma) {
+                                    double gamma, const float* mean_std = nullptr) {
+  a.normalize = mean_std != nullptr;
+  for (int k = 0; k < 3; ++k) {
+    a.nmean[k] = mean_std ? mean_std[k] : 0.f;
+    a.nstd[k] = mean_std ? mean_std[3 + k] : 1.f;
+    a.nrcp[k] = 1.0f / a.nstd[k];
+    unsigned bits;
+    memcpy(&bits, &a.nstd[k], 4);
+    if (mean_std && (bits & 0x7fffffu) == 0x7fffffu) a.normalize = 2;
+  }
   // skimage.color yuv_from_rgb (scikit-image 0.18.1); the reference's own copy is
   // pipeline_torch.py:21-23
   static const double M1[9] = {0.299,       0.587,       0.114,       -0.14714119, -0.28886916,
@@ -477,6 +489,34 @@ R2L_HD float r2l_clip_gamma(double rgb, float inv_gamma) {
   return r2l_exp2(r2l_log2(xf) * inv_gamma);
 }
 
+// The optional T.Normalize epilogue on the NC pixels x 3 channels a lane is about to store -- torchvision's
+// tensor.sub_(mean).div_(std) in float32 (train.py:157-171) -- under ONE uniform branch behind the gamma code
+// (a test per value would cut the pixel loops into basic blocks; measured +10 % on the luma chains).
+// The quotient is the correctly rounded one in 3 instructions instead of the ~10 of a division: with r = RN(1/s),
+// q0 = RN(t r), the remainder t - q0 s is exact in one fma and RN(q0 + rem r) is RN(t / s) (Markstein's theorem; it
+// excludes divisors whose significand is all ones: normalize = 2 divides; tests/test_oracle_golden.py checks the
+// sequence on 3 * 10^6 quotients per std).
+template <int NC, class A>
+R2L_HD void r2l_static_normalize(const A& a, float x[3][NC]) {
+  if (a.normalize == 2) {
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k)
+      R2L_PRAGMA_UNROLL
+    for (int c = 0; c < NC; ++c) x[k][c] = (x[k][c] - a.nmean[k]) / a.nstd[k];
+  } else if (a.normalize) {
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      const float m = a.nmean[k], s = a.nstd[k], r = a.nrcp[k];
+      R2L_PRAGMA_UNROLL
+      for (int c = 0; c < NC; ++c) {
+        const float t = x[k][c] - m;
+        const float q0 = t * r;
+        x[k][c] = fmaf(fmaf(-q0, s, t), r, q0);
+      }
+    }
+  }
+}
+
 // ---- pixel stage ---------------------------------------------------------------------------------
 template <class G, bool BORDER, bool FULL>
 R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, const R2LStaticArgs& a,
@@ -549,6 +589,7 @@ R2L_HD void r2l_static_pixels_impl(int mt, const float* V, const double* YP, con
       R2L_PRAGMA_UNROLL
       for (int k = 0; k < 3; ++k) x[k][c] = r2l_clip_gamma(rgb[k], a.inv_gamma);
     }
+    r2l_static_normalize<NC>(a, x);
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < 3; ++k) {
       float* o = a.out + ((size_t)t.b * 3 + k) * plane + (size_t)gy * a.W + gx0;
@@ -593,7 +634,7 @@ R2L_HD void r2l_static_pixels(int tid, const float* V, const double* YP, const R
 // a constant).  The argument block is therefore copied to LDS once per workgroup, and every phase re-reads from
 // there what it uses (broadcast ds_reads into registers for the length of the phase; reading it from the kernarg
 // segment again per phase costs a global-memory round trip at the head of every phase).
-#define R2L_STATIC_ARGS_FLOATS 128
+#define R2L_STATIC_ARGS_FLOATS 160
 static_assert(sizeof(R2LStaticArgs) <= 4 * R2L_STATIC_ARGS_FLOATS, "argument block copy in LDS");
 #ifdef R2L_EMUL
 #define R2L_STATIC_ARGS(a, lds_args) (a)

@@ -204,6 +204,7 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
     const double rgb = fma(a.wbccm[k * 3], d[c][0], fma(a.wbccm[k * 3 + 1], d[c][1], a.wbccm[k * 3 + 2] * d[c][2]));
     x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
   }
+  r2l_static_normalize<4>(a, x);
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
     r2l_f4 st;
@@ -241,6 +242,7 @@ R2L_HD void r2l_stream_luma_in_row(const R2LStaticArgs& a, const double d[4][3],
       x[k][c] = r2l_clip_gamma(rgb, a.inv_gamma);
     }
   }
+  r2l_static_normalize<4>(a, x);
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
     r2l_f4 st;

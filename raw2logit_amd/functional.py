@@ -299,8 +299,11 @@ _DENOISE = {'gaussian_denoising': 1, 'median_denoising': 2}
 
 
 def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
-                    denoising='gaussian_denoising', gamma=2.2, bits=16):
+                    denoising='gaussian_denoising', gamma=2.2, bits=16, mean_std=None):
     """(B,H,W) raw on the GPU -> (B,3,H,W) float32, numpy semantics of the reference.
+
+    mean_std: six host floats (mean[3], std[3]) -- the T.Normalize(mean, std) that train.py:157-171 composes
+    behind RawProcessingPipeline, applied inside the kernels' stores (float32 subtraction and division).
 
     The black level is removed in the arithmetic of the frames' dtype, as the reference's in-place
     remove_blacklv does (pipeline_numpy.py:152-158): float32 frames -- what its datasets deliver
@@ -337,7 +340,12 @@ def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='shar
     nws = (lib.r2l_static_workspace_bytes_f64 if f64 else lib.r2l_static_workspace_bytes)(B, H, W, *codes)
     ws = torch.empty(nws, dtype=torch.uint8, device=raw.device) if nws else None      # 0: single-launch chains
     tail = (ptr(out), B, H, W, cam, *codes, float(gamma), ptr(ws), nws, stream)
-    if f64:
+    if mean_std is not None:
+        ms = (ctypes.c_float * 6)(*[float(v) for v in mean_std])
+        frames = 2 if f64 else (0 if denom is None else 1)
+        lib.check(lib.r2l_static_fwd_norm(ptr(raw), frames, float(denom or 1.0), ptr(out), B, H, W, cam, *codes,
+                                          float(gamma), ms, ptr(ws), nws, stream), 'r2l_static_fwd_norm')
+    elif f64:
         lib.check(lib.r2l_static_fwd_f64(ptr(raw), *tail), 'r2l_static_fwd_f64')
     elif denom is None:
         lib.check(lib.r2l_static_fwd(ptr(raw), *tail), 'r2l_static_fwd')

@@ -74,7 +74,7 @@ class StaticProcessing(nn.Module):
     """Batched static pipeline as a ``processor`` module: (B,H,W) raw on the GPU -> (B,3,H,W).
 
     Equals RawProcessingPipeline applied to every frame followed by the optional T.Normalize(mean, std)
-    of train.py:157-171.  No trainable parameters, no gradient.  Frames may be float32 in [0,1] or the
+    of train.py:157-171 (fused into the pipeline's kernels: r2l_static_fwd_norm).  No trainable parameters, no gradient.  Frames may be float32 in [0,1] or the
     sensor's 16-bit containers (uint16 / int16 tensors, divided by 2**raw_bits - 1 inside the kernel)."""
 
     raw_bits = 16
@@ -101,8 +101,19 @@ class StaticProcessing(nn.Module):
         self.stages = {}
         self.buffer = {}
         rgb = F_.static_pipeline(raw, self.camera_parameters, self.debayer, self.sharpening,
-                                 self.denoising, self.gamma, bits=self.raw_bits)
-        if self.mean_std is not None:
-            rgb = F_.normalize(rgb, self.mean_std)
+                                 self.denoising, self.gamma, bits=self.raw_bits, mean_std=self._mean_std_host())
         self.buffer['processed_rgb'] = rgb
         return rgb
+
+    def _mean_std_host(self):
+        """the six floats of the mean_std buffer on the host (the kernels take them as launch arguments), read
+        back once per value of the buffer"""
+        ms = self.mean_std
+        if ms is None:
+            return None
+        key = (ms.data_ptr(), ms._version)
+        cached = self.__dict__.get('_ms_host')
+        if cached is None or cached[0] != key:
+            cached = (key, [float(v) for v in ms.detach().cpu().tolist()])
+            self.__dict__['_ms_host'] = cached
+        return cached[1]

@@ -291,6 +291,44 @@ def check_static_combinations(device):
                     assert torch.equal(out16, out), (deb, sh, dn)
 
 
+def check_static_normalize(device):
+    """the T.Normalize(mean, std) epilogue of the static kernels (r2l_static_fwd_norm; train.py:157-171) equals
+    torchvision's arithmetic -- float32 (x - mean) / std -- on the un-normalised output, bit for bit: row-streaming
+    short chains, the fused luma chains, the tile kernels (W % 4 != 0) and float64 / 16-bit frames"""
+    mean, std = [0.35, 0.36, 0.35], [0.12, 0.11, 0.12]            # train.py:157-158 (Drone)
+    m = torch.tensor(mean).view(1, 3, 1, 1)
+    sd = torch.tensor(std).view(1, 3, 1, 1)
+    for (B, H, W) in ((2, 40, 72), (1, 18, 262), (1, 34, 264)):
+        u = np.random.default_rng(H).integers(0, 4096, (B, H, W)).astype(np.uint16)
+        rawf = torch.from_numpy(u.astype(np.float32) / np.float32(4095)).to(device)
+        for deb, sh, dn in (('bilinear', 'none', 'none'), ('malvar2004', 'none', 'none'),
+                            ('bilinear', 'sharpening_filter', 'gaussian_denoising'),
+                            ('malvar2004', 'unsharp_masking', 'median_denoising')):
+            if W % 4 and (deb, sh, dn) == ('malvar2004', 'unsharp_masking', 'median_denoising'):
+                continue                                          # plane passes need W % 4 == 0
+            plain = F_.static_pipeline(rawf, orc.DRONE_CAMERA_PARAMS, deb, sh, dn).cpu()
+            fused = F_.static_pipeline(rawf, orc.DRONE_CAMERA_PARAMS, deb, sh, dn, mean_std=mean + std).cpu()
+            assert torch.equal(fused, (plain - m) / sd), (deb, sh, dn, (B, H, W))
+            if W % 4 == 0:
+                f16 = F_.static_pipeline(torch.from_numpy(u).to(device), orc.DRONE_CAMERA_PARAMS, deb, sh, dn, bits=12,
+                                         mean_std=mean + std).cpu()
+                assert torch.equal(f16, fused), (deb, sh, dn, '16-bit containers')
+                p64 = F_.static_pipeline(rawf.double(), orc.DRONE_CAMERA_PARAMS, deb, sh, dn).cpu()
+                f64 = F_.static_pipeline(rawf.double(), orc.DRONE_CAMERA_PARAMS, deb, sh, dn, mean_std=mean + std).cpu()
+                assert torch.equal(f64, (p64 - m) / sd), (deb, sh, dn, 'float64 frames')
+    # a std whose significand is all ones takes the kernels' true-division path
+    odd = [float(np.nextafter(np.float32(0.25), np.float32(0))), 0.11, float(np.nextafter(np.float32(0.5), np.float32(0)))]
+    plain = F_.static_pipeline(rawf, orc.DRONE_CAMERA_PARAMS).cpu()
+    fused = F_.static_pipeline(rawf, orc.DRONE_CAMERA_PARAMS, mean_std=mean + odd).cpu()
+    assert torch.equal(fused, (plain - m) / torch.tensor(odd).view(1, 3, 1, 1))
+    try:
+        F_.static_pipeline(rawf, orc.DRONE_CAMERA_PARAMS, mean_std=mean + [0.1, 0.0, 0.1])
+    except Exception as e:                                        # noqa: BLE001
+        assert 'std' in str(e)
+    else:
+        raise AssertionError('a zero std must be refused')
+
+
 def check_ragged_and_properties(device, B=2, H=70, W=134):
     """size-independent properties of the fused path: (i) the batch dimension is independent,
     (ii) eval-mode BatchNorm is an affine map of the no-BatchNorm output, (iii) stats-only + apply ==

@@ -65,6 +65,10 @@ def test_static_chain_combinations(emulation):
     pc.check_static_combinations('cpu')
 
 
+def test_static_normalize_epilogue(emulation):
+    pc.check_static_normalize('cpu')
+
+
 def test_adversarial_aux_losses(golden, emulation):
     pc.check_aux_losses(golden, 'cpu')
 

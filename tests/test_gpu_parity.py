@@ -152,6 +152,10 @@ def test_static_chain_combinations(dev):
     pc.check_static_combinations(dev)
 
 
+def test_static_normalize_epilogue(dev):
+    pc.check_static_normalize(dev)
+
+
 def test_adversarial_aux_losses(golden, dev):
     pc.check_aux_losses(golden, dev)
 

@@ -168,3 +168,22 @@ def test_philox_restatement_against_the_published_known_answers():
     z = orc.philox_normal(1 << 20, 1234).astype(np.float64)
     assert abs(z.mean()) < 4e-3 and abs(z.std() - 1) < 4e-3 and abs((z ** 4).mean() - 3) < 5e-2
     assert np.array_equal(orc.philox_normal(10, 5, 3)[:6], orc.philox_normal(6, 5, 3))
+
+
+def test_normalize_division_sequence_is_correctly_rounded():
+    """r2l_static_out (csrc/r2l_static_kernels.h) divides by std as q0 = RN(t r), RN(q0 + (t - q0 s) r) with
+    r = RN(1/s): restated here in numpy (the remainder is exact in float64), 3 * 10^6 quotients per std of the
+    reference's Normalize constants (train.py:157-162, :185-187) and random ones, against float32 division"""
+    rng = np.random.default_rng(0)
+    stds = [0.12, 0.11, 0.08, 0.05, 0.097, 0.0423, 0.008] + list(rng.uniform(0.01, 2.0, 5))
+    n = 1_000_000
+    for s in stds:
+        s = np.float32(s)
+        r = np.float32(1) / s
+        t = np.concatenate([rng.uniform(-1, 1, n).astype(np.float32),
+                            rng.uniform(0, 1, n).astype(np.float32) - np.float32(0.35),
+                            (10.0 ** rng.uniform(-9, 0, n)).astype(np.float32)])
+        q0 = (t * r).astype(np.float32)
+        rem = (t.astype(np.float64) - q0.astype(np.float64) * np.float64(s)).astype(np.float32)
+        q1 = (q0.astype(np.float64) + rem.astype(np.float64) * np.float64(r)).astype(np.float32)
+        assert np.array_equal(q1, (t / s).astype(np.float32)), float(s)
