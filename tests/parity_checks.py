@@ -81,17 +81,19 @@ def _sample(a, full):
 
 
 LOW_BAND_TOL = 7.5e-5
+WELL_CONDITIONED = 3e-3          # pre-gamma value above which the 1e-5 bar itself applies (slope of x^(1/2.2) there: 11)
 DEFAULT_GRAD_RTOL = 1.5e-3      # of max|grad| (round 1: 3e-3; achieved <= 20 % of that on every golden case)
 
 
 def out_tolerance(cache, has_bn, base=1e-5):
     """1e-5 wherever the power law is well conditioned.  The reference clips at
     1e-5 before x^(1/gamma) (pipeline_torch.py:206-209): the slope there is up to 241, so float32
-    round-off of ~2e-7-3e-7 in the linear part is worth up to 7.5e-5 after the gamma for pre-gamma values
-    below 1e-3 (round 1 allowed 1e-4 there; the worst achieved error on the GPU is 5.8e-5 -- the streaming
-    forward on 514x512 frames with perturbed, dense weights -- 4.8e-5 elsewhere; profiles/r02_p_parity_gpu.tsv);
+    round-off of 2e-7 .. 5e-7 in the linear part (perturbed, dense weights sit at the upper end) is worth up to
+    7.5e-5 after the gamma near the clip floor and still 1e-5 at a pre-gamma value of 1e-3 (slope 20): the 1e-5
+    bar applies above 3e-3, 7.5e-5 below (round 1: 1e-4 below 1e-3; worst achieved on the GPU 5.8e-5 -- the
+    streaming forward on 514x512 frames with perturbed weights; profiles/r02_p_parity_gpu.tsv).
     BatchNorm multiplies everything by 1/std."""
-    tol = np.where(cache['rgb'] > 1e-3, base, LOW_BAND_TOL)
+    tol = np.where(cache['rgb'] > WELL_CONDITIONED, base, LOW_BAND_TOL)
     if has_bn:
         tol = tol * np.maximum(1.0, cache['istd'].reshape(1, 3, 1, 1))
     return tol
@@ -128,12 +130,12 @@ def check_param_case(case, golden, device):
     err = np.abs(out - o_out)
     worst = np.unravel_index((err / tol).argmax(), err.shape)
     report(f'param/{case["name"]}/out vs float64 oracle', err[worst], tol[worst])
-    well = cache['rgb'] > 1e-3          # where x ** (1/gamma) is well conditioned: the 1e-5 bar itself
+    well = cache['rgb'] > WELL_CONDITIONED  # where x ** (1/gamma) is well conditioned: the 1e-5 bar itself
     scale = (max(1.0, float(np.max(cache['istd']))) if case['bn'] else 1.0)
     if well.any():
-        report(f'param/{case["name"]}/out vs float64 oracle (pre-gamma > 1e-3)', err[well].max(), 1e-5 * scale)
+        report(f'param/{case["name"]}/out vs float64 oracle (pre-gamma > 3e-3)', err[well].max(), 1e-5 * scale)
     if (~well).any():
-        report(f'param/{case["name"]}/out vs float64 oracle (pre-gamma <= 1e-3)', err[~well].max(), LOW_BAND_TOL * scale)
+        report(f'param/{case["name"]}/out vs float64 oracle (pre-gamma <= 3e-3)', err[~well].max(), LOW_BAND_TOL * scale)
     assert np.all(err <= tol), (case['name'], 'out vs oracle', err.max(), np.unravel_index(err.argmax(), err.shape))
     assert m.buffer['processed_rgb'] is y
     if not case['track']:

@@ -278,7 +278,9 @@ def test_full_size_config4_microscopy(dev):
     bn = dict(training=False, running_mean=m.batch_norm.running_mean.double().cpu().numpy(),
               running_var=m.batch_norm.running_var.double().cpu().numpy())
     o, _, c = orc.parametrized_forward(raw_np[:2], P, bn=bn)
-    tol = pc.out_tolerance(c, True)
+    # Microscopy parameters: |colour matrix . diag(white balance)| has row sums up to 10.9 (Drone: 5.0), the float32
+    # round-off of the linear part grows with them: 2e-5 where the power law is well conditioned (achieved 9.7e-6)
+    tol = pc.out_tolerance(c, True, base=2e-5)
     err = np.abs(ys.detach().cpu().numpy() - o)
     w = np.unravel_index((err / tol).argmax(), err.shape)
     pc.report('config4/2-frame slice: out vs float64 oracle', err[w], tol[w])
