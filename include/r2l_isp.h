@@ -48,6 +48,11 @@ enum {
   R2L_F_STATS_ONLY = 1, /* fwd: do not write `out`, only the BatchNorm partial sums */
   R2L_F_FOLDED_VALID = 2, /* fwd/bwd: `workspace` was last used by a call with these same `params`;
                              skip re-deriving the folded weights (saves one small launch) */
+  R2L_F_KEEP_LUMA = 4, /* fwd (with `out`): keep the sharpened luma plane Y' in the workspace (+4 B/px written);
+                          bwd: the forward of this step ran with it -- read Y' there instead of recomputing
+                          raw -> Y -> Y' (-25 % of the first gradient kernel for 4.5 B/px read).  Both calls of
+                          a step must agree; honoured where the row-streaming forward runs (no additive layer,
+                          W % 4 == 0, W <= 2048), ignored elsewhere */
 };
 
 /* static-pipeline selectors (processing/pipeline_numpy.py:92-122) */
@@ -178,6 +183,8 @@ int r2l_additive_bwd(const float *grad_out, const float *out, const float *bn_me
  * phase B, which adds the rows in rank order.  One rank: phase = R2L_STEP_ALL.                             */
 enum { R2L_BN_NONE = 0, R2L_BN_TRAIN = 1, R2L_BN_EVAL = 2 };
 enum { R2L_STEP_ALL = 0, R2L_STEP_A = 1, R2L_STEP_B = 2 };
+/* or-ed into `phase` of r2l_isp_step_fwd AND r2l_isp_step_bwd of a step whose backward will run: R2L_F_KEEP_LUMA */
+enum { R2L_STEP_KEEP_LUMA = 8 };
 enum { R2L_STEP_STATS = 0, R2L_STEP_MOMENTS = 1, R2L_STEP_BN_SUMS = 2, R2L_STEP_PACKED = 3, R2L_STEP_BN = 4 };
 size_t r2l_isp_step_offset(int which, int B, int H, int W); /* byte offset inside the workspace */
 int r2l_isp_step_fwd(const void *raw, int raw_u16, float denom, const float *const *params_host,

@@ -181,6 +181,15 @@ R2L_FS_KERNEL(r2l_launch_fwd_stream_w8_u16, 8, true)
 #endif
 R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, false>)
 R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, false>)
+// ... with Y' taken from the plane the streaming forward kept (one workgroup per CU: the second prefetch frame
+// takes the kernel past 256 VGPRs)
+#ifndef R2L_OCC_BWD1S
+#define R2L_OCC_BWD1S 1
+#endif
+R2L_KERNEL_V(r2l_launch_bwd1_saved, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, false, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, true, false, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_saved_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, true, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, true, true, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
 R2L_KERNEL_V(r2l_launch_bwd2, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bwd2_block<GBwd2, false>)
 R2L_KERNEL_V(r2l_launch_fwd_u16, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, true>)
@@ -315,6 +324,7 @@ struct R2LWorkspace {
   double* gpartial;    // [R2L_NSUMS][R2L_MAX_GROUPS] group partials of the in-kernel final reductions
   unsigned* counters;  // [1 + R2L_MAX_GROUPS] arrival counters: zeroed by the fold kernel, zero after every launch
   float* gypp;
+  float* yp;     // (B,H,W): the sharpened luma Y' of the forward, for kernel B1 (R2L_F_KEEP_LUMA)
   float* debug;  // 3 x [R2L_MAX_BLOCKS][8] floats: per-phase cycle stamps of diagnostic builds (fwd, bwd1, bwd2)
   // step block (r2l_isp_step_fwd / _bwd): what one training step keeps between its launches
   float* packed;    // [R2L_P_COUNT] the parameter values the forward saw
@@ -356,6 +366,8 @@ static R2LWorkspace r2l_carve(void* base, int B, int H, int W) {
   w.bsums = w.stats + 16;
   off += r2l_align_up(sizeof(double) * 24);
   w.gypp = (float*)(p + off);
+  off += r2l_align_up(sizeof(float) * (size_t)B * H * W);
+  w.yp = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * (size_t)B * H * W);
   w.total = off;
   return w;
@@ -433,6 +445,15 @@ static int r2l_check_raw(const R2LRaw& raw, int W, const char* who) {
   return 0;
 }
 
+// where the row-streaming forward (r2l_param_stream.h) runs -- and with R2L_F_KEEP_LUMA leaves Y' for kernel B1
+static bool r2l_fwd_streams(const float* additive, int W) {
+#ifdef R2L_EMUL
+  (void)additive; (void)W;
+  return false;
+#else
+  return !additive && (W & 3) == 0 && W <= 2048 && !r2l_env_int("R2L_FWD_TILED", 0);
+#endif
+}
 static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float* additive,
                             const float* bn_mean_istd, float* out, double* stats, void* workspace,
                             size_t workspace_bytes, int B, int H, int W, int flags, void* stream,
@@ -452,7 +473,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     if (int e = r2l_launch_fold(fa, 1, stream)) return e;
   }
 #ifndef R2L_EMUL
-  if (!additive && (W & 3) == 0 && W <= 2048 && !r2l_env_int("R2L_FWD_TILED", 0)) {
+  if (r2l_fwd_streams(additive, W)) {
     // row-streaming forward: work item = (image, band of rows); short bands are cheap here (the 8 halo rows of a
     // band only compute their luma), so aim at ~2048 items (three wavefronts per SIMD: the kernel's row step is a
     // chain of scalar-load waits, which only other wavefronts can fill), bands of >= 16 rows
@@ -461,6 +482,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     fa.F = ws.folded;
     fa.bn = bn_mean_istd;
     fa.out = out;
+    fa.yp_out = (out && (flags & R2L_F_KEEP_LUMA)) ? ws.yp : nullptr;
     fa.stat_partial = stats ? ws.part_small : nullptr;
     fa.B = B;
     fa.H = H;
@@ -605,9 +627,14 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   a1.H = H;
   a1.W = W;
   a1.debug = ws.debug + 8 * R2L_MAX_BLOCKS;
+  const bool saved = (flags & R2L_F_KEEP_LUMA) && r2l_fwd_streams(additive, W) && !r2l_env_int("R2L_BWD1_RECOMPUTE", 0);
+  a1.yp = saved ? ws.yp : nullptr;
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
   int e1;
-  if (raw.u16)
+  if (saved)
+    e1 = raw.u16 ? (exact ? r2l_launch_bwd1_saved_u16(a1, g1, stream) : r2l_launch_bwd1_saved_ragged_u16(a1, g1, stream))
+                 : (exact ? r2l_launch_bwd1_saved(a1, g1, stream) : r2l_launch_bwd1_saved_ragged(a1, g1, stream));
+  else if (raw.u16)
     e1 = additive ? r2l_launch_bwd1_add_u16(a1, g1, stream)
                   : (exact ? r2l_launch_bwd1_u16(a1, g1, stream) : r2l_launch_bwd1_ragged_u16(a1, g1, stream));
   else
@@ -677,6 +704,8 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
                      long long* num_batches_tracked, double eps, double momentum, float* out, void* workspace,
                      size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
                      const double* gathered_stats, void* stream) {
+  const int keep = (phase & R2L_STEP_KEEP_LUMA) ? R2L_F_KEEP_LUMA : 0;
+  phase &= ~R2L_STEP_KEEP_LUMA;
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (!raw || !out || !workspace) return r2l_fail(-1, "r2l_isp_step_fwd: null pointer");
   if (bn_mode != R2L_BN_NONE && bn_mode != R2L_BN_TRAIN && bn_mode != R2L_BN_EVAL)
@@ -725,12 +754,14 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
     if (int e = r2l_launch_bn_finalize(f, 1, stream)) return e;
   }
   return r2l_isp_fwd_impl(rw, ws.packed, additive, bn_mode == R2L_BN_NONE ? nullptr : ws.bn, out, nullptr, workspace,
-                          workspace_bytes, B, H, W, R2L_F_FOLDED_VALID, stream);
+                          workspace_bytes, B, H, W, R2L_F_FOLDED_VALID | keep, stream);
 }
 int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* additive, const float* grad_out,
                      const float* out, float* grad_params, float* grad_additive, int bn_mode, void* workspace,
                      size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
                      const double* gathered_sums, void* stream) {
+  const int keep = (phase & R2L_STEP_KEEP_LUMA) ? R2L_F_KEEP_LUMA : 0;
+  phase &= ~R2L_STEP_KEEP_LUMA;
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (!raw || !grad_out || !workspace) return r2l_fail(-1, "r2l_isp_step_bwd: null pointer");
   if (phase != R2L_STEP_ALL && phase != R2L_STEP_A && phase != R2L_STEP_B)
@@ -758,7 +789,7 @@ int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* add
   }
   if (grad_params) {
     if (int e = r2l_isp_bwd_impl(rw, ws.packed, additive, bn, bn_bwd, grad_out, grad_params, nullptr, workspace,
-                                 workspace_bytes, B, H, W, R2L_F_FOLDED_VALID, stream))
+                                 workspace_bytes, B, H, W, R2L_F_FOLDED_VALID | keep, stream))
       return e;
   }
   if (grad_additive) return r2l_additive_bwd(grad_out, out, bn, bn_bwd, grad_additive, B, H, W, stream);

@@ -977,6 +977,7 @@ struct R2LBwd1Args {
   float* partial;       // [R2L_B1_NACC][nblk]
   int B, H, W;
   float* debug;
+  const float* yp;      // (B,H,W) or null: the sharpened luma Y' the forward kept (SAVED instantiations)
 };
 
 // per-thread accumulators of B1, as pairs: element h of a pair belongs to the pixels in the even (h = 0) or
@@ -1315,7 +1316,10 @@ R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LB
   }
 }
 
-template <class G, bool ADD, bool MAYBE_RAGGED, bool U16>
+// SAVED: the forward kept Y' (a.yp): its frame is prefetched like the raw frame and stored to the YP plane (zero outside
+// the image, then the mirror fill of border tiles) instead of being recomputed raw -> Y -> Y' -- two of the five
+// phases, 29 % of the kernel (profiles/r01_f_phase_stamps.txt), for 4.5 B/px more traffic.
+template <class G, bool ADD, bool MAYBE_RAGGED, bool U16, bool SAVED = false>
 R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* lds) {
   float* V = lds + R2L_FOLDED_FLOATS + G::PAD;
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
@@ -1323,6 +1327,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   float* YP = Y + G::PLANE;
   R2L_TREG_DECL(R2LBwd1Regs, regs);
   R2L_TREG_DECL(R2LPrefetch<G>, pre);
+  R2L_TREG_DECL(R2LPrefetch<G>, pre_yp);
   R2L_TREG_DECL(R2LGoutPre, gpre);
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t, tn;
@@ -1335,14 +1340,23 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
   }
   if (have) r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
+  if (SAVED && have) r2l_fetch_tile<G, 1>(tid, a.yp, t, a.H, a.W, R2L_TREG(pre_yp));
   R2L_PHASE_END
   R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre), a.raw);
+    if (SAVED) r2l_store_plane_s2<G>(tid, YP, R2L_TREG(pre_yp));
+    // (measured: the grad_out loads issued here, 119 us; a tile ahead at the head of the pixel phase, where 18 loads
+    // per lane then queue up in the texture-address path, 133 us; a tile ahead behind the pixel arithmetic, 124 us)
+    if (SAVED && !MAYBE_RAGGED) {
+      r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 0);
+      r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 1);
+    }
     R2L_PHASE_END
     R2L_STAMP(0)
     const bool haven = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, tn);
+    if (!SAVED) {
     R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     // consumed in the pixel phase; one row per stencil phase (six loads per lane at once queue up in the
     // texture-address path and hold every wave at its next instruction)
@@ -1358,6 +1372,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     r2l_compute_yp<G>(tid, Y, YP, F);
     R2L_PHASE_END
     R2L_STAMP(2)
+    }
     if (t.border) {
       R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
       r2l_fill_yp_mirror<G>(tid, YP, t.oy, t.ox, a.H, a.W);
@@ -1366,6 +1381,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     }
     R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     if (haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
+    if (SAVED && haven) r2l_fetch_tile<G, 1>(tid, a.yp, tn, a.H, a.W, R2L_TREG(pre_yp));
     if (MAYBE_RAGGED && t.ragged)
       r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD, false>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
     else

@@ -30,6 +30,7 @@ struct R2LFwdStreamArgs {
   const R2LFolded* F;
   const float* bn;      // mean[3], istd[3] or null
   float* out;           // (B,3,H,W) or null (statistics only)
+  float* yp_out;        // (B,H,W) or null: the sharpened luma Y', kept for the backward (written with `out`)
   float* stat_partial;  // [6][nblk] or null
   int B, H, W;
   int nband, band_h, nitems;  // work item = (image, band); workgroup bid takes items bid, bid + nblk, ...
@@ -153,7 +154,7 @@ static constexpr R2LFolded r2l_fs_fake_folded = r2l_fs_make_fake();
 #endif
 template <int NW, bool U16, int K>
 R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0, int y1, bool le, bool re,
-                        int wave, int lane, float* ex, r2l_f4* fifo, float* ob, unsigned plane, int x0,
+                        int wave, int lane, float* ex, r2l_f4* fifo, float* ob, float* ypb, unsigned plane, int x0,
                         bool store_ok, const float mean[3], const float istd[3]) {
 #ifdef R2L_FS_CONSTW
   const R2LFolded& F = r2l_fs_fake_folded;
@@ -273,6 +274,14 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
     ypn[3] = o[0][1];
     ypn[4] = o[1][0];
     ypn[5] = o[1][1];
+    if (ypb && store_ok && q - 1 >= y0 && q - 1 < y1) {  // kept for kernel B1 of the backward (the band's own rows)
+      r2l_f4 s4;
+      s4.x = o[0][0];
+      s4.y = o[0][1];
+      s4.z = o[1][0];
+      s4.w = o[1][1];
+      *(r2l_f4*)(ypb + (unsigned)(q - 1) * (unsigned)a.W + (unsigned)x0) = s4;
+    }
   }
   // ---- output row y = q-4 ------------------------------------------------------------------------------------
   const int y = q - 4;
@@ -373,6 +382,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
     const size_t img = (size_t)b * plane;
     float* ob = a.out ? a.out + (size_t)b * 3 * plane : nullptr;
+    float* ypb = (a.out && a.yp_out) ? a.yp_out + (size_t)b * plane : nullptr;
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 6; ++i) st.acc[i] = r2l_splat2(0.f);
     R2L_PRAGMA_UNROLL
@@ -424,7 +434,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     const int q = qb + K;                                                                                       \
     r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
     if (q + 1 + PF <= q1) r2l_fs_fetch<U16>(a, img, r2l_mirror(q + 1 + PF, a.H), x0, le, re, lane, pf[K % PF]); \
-    r2l_fs_step<NW, U16, K>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, plane, x0, store_ok, mean, istd); \
+    r2l_fs_step<NW, U16, K>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, store_ok, mean, istd); \
   }
       R2L_FS_STEP(0)
       R2L_FS_STEP(1)

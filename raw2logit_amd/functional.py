@@ -159,6 +159,7 @@ def bn_bwd_means(lib, stream, sums, moments, group):
 
 
 _STEP_ALL, _STEP_A, _STEP_B = 0, 1, 2
+_STEP_KEEP_LUMA = 8      # or-ed into `phase` of both calls of a step whose backward will run (R2L_STEP_KEEP_LUMA)
 _STEP_STATS, _STEP_MOMENTS, _STEP_BN_SUMS = 0, 1, 2
 _STEP_LAYOUT = {}
 
@@ -222,11 +223,14 @@ class _IspFused(torch.autograd.Function):
                 raise RuntimeError('BatchNorm buffers must be float32 on the device of the frames')
         nranks = _group_size(group) if bn_mode == BN_TRAIN else 1
         mom = float(momentum) if momentum is not None else -1.0
+        # a backward will follow: the forward keeps the sharpened luma plane for its first gradient kernel
+        keep = _STEP_KEEP_LUMA if any(ctx.needs_input_grad[1:8]) else 0
 
         def call(phase, gathered):
             lib.check(lib.r2l_isp_step_fwd(ptr(raw), int(denom is not None), denom or 1.0, table, ptr(additive),
                                            bn_mode, ptr(rm), ptr(rv), ptr(nbt), float(eps), mom, ptr(out), ptr(ws),
-                                           nws, B, H, W, nranks, phase, ptr(gathered), stream), 'r2l_isp_step_fwd')
+                                           nws, B, H, W, nranks, phase | keep, ptr(gathered), stream),
+                      'r2l_isp_step_fwd')
         if nranks == 1:
             call(_STEP_ALL, None)
         else:
@@ -234,6 +238,7 @@ class _IspFused(torch.autograd.Function):
             gathered, _ = gather_ranks(ws[off_stats:off_stats + 56].view(torch.float64), group)
             call(_STEP_B, gathered)
         ctx.bn_mode = bn_mode
+        ctx.keep = keep
         ctx.group = group
         ctx.nranks = nranks
         ctx.denom = denom
@@ -264,7 +269,7 @@ class _IspFused(torch.autograd.Function):
         def call(phase, gathered):
             lib.check(lib.r2l_isp_step_bwd(ptr(raw), int(denom is not None), denom or 1.0, ptr(additive), ptr(gout),
                                            ptr(out), ptr(gp), ptr(gadd), ctx.bn_mode, ptr(ws), nws, B, H, W,
-                                           ctx.nranks, phase, ptr(gathered), stream), 'r2l_isp_step_bwd')
+                                           ctx.nranks, phase | ctx.keep, ptr(gathered), stream), 'r2l_isp_step_bwd')
         if need_p or need_a:
             if ctx.nranks == 1:
                 call(_STEP_ALL, None)

@@ -354,6 +354,44 @@ def test_static_luma_chain_streaming_kernel(shape, dev):
             assert e64 <= 1e-5, (shape, deb, sh, dn, 'float64 frames', e64)
 
 
+@pytest.mark.parametrize('shape', [(3, 64, 64), (2, 70, 520), (1, 128, 1028), (2, 6, 8), (1, 192, 2048)], ids=str)
+def test_backward_reads_the_luma_plane_the_forward_kept(shape, dev):
+    """R2L_F_KEEP_LUMA: a forward that will be differentiated leaves the sharpened luma Y' in the workspace and
+    kernel B1 loads it (tiles that fit exactly, ragged ones, border tiles, 16-bit containers) instead of recomputing
+    raw -> Y -> Y'.  All parameter gradients against the recomputing kernel of the diagnostic build (same pixels,
+    Y' rounded by another kernel) and, through check_frame_shapes / the golden cases, against the oracle."""
+    import os
+    B, H, W = shape
+    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+    P.perturb(11)
+    u = np.rint(orc.synth_raw(B, H, W, seed=H + W, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
+    cot = torch.from_numpy(np.random.default_rng(H).standard_normal((B, 3, H, W)).astype(np.float32)).to(dev)
+    for bn in (True, False):
+        case = dict(camera='drone', track=False, additive=False, training=True, bn=bn)
+        grads = {}
+        for name, env, frames in (('kept', {}, 'f32'), ('kept16', {}, 'u16'), ('recomputed', {'R2L_BWD1_RECOMPUTE': '1'}, 'f32')):
+            m = pc.make_module(case, P, dev)
+            if frames == 'u16':
+                m.raw_bits = 12
+                raw = torch.from_numpy(u).to(dev)
+            else:
+                raw = torch.from_numpy(u.astype(np.float32) / np.float32(4095)).to(dev)
+            os.environ.update(env)
+            try:
+                with pc.launch_shape_overrides(dev):
+                    (m(raw) * cot).sum().backward()
+            finally:
+                for k in env:
+                    del os.environ[k]
+            grads[name] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
+        for n, ref in grads['recomputed'].items():
+            assert np.array_equal(grads['kept'][n], grads['kept16'][n]), (shape, bn, n, '16-bit containers')
+            e = np.abs(grads['kept'][n] - ref).max()
+            lim = 2e-4 * (np.abs(ref).max() + 1e-6)
+            pc.report(f'kept-luma/{shape}/bn={bn}/{n} vs recomputing kernel', e, lim)
+            assert e <= lim, (shape, bn, n, e, lim)
+
+
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
                                    (5, 18, 8), (2, 514, 512)], ids=str)
 def test_fused_forward_streaming_kernel(shape, dev):
