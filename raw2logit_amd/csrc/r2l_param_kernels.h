@@ -1348,7 +1348,8 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre), a.raw);
     if (SAVED) r2l_store_plane_s2<G>(tid, YP, R2L_TREG(pre_yp));
     // (measured: the grad_out loads issued here, 119 us; a tile ahead at the head of the pixel phase, where 18 loads
-    // per lane then queue up in the texture-address path, 133 us; a tile ahead behind the pixel arithmetic, 124 us)
+    // per lane then queue up in the texture-address path, 133 us; a tile ahead behind the pixel arithmetic, 124 us;
+    // a tile ahead from this store phase, held across the pixel phase, 136 us)
     if (SAVED && !MAYBE_RAGGED) {
       r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 0);
       r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 1);

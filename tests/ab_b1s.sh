@@ -1,15 +1,15 @@
 #!/bin/bash
-cd /root/repo
+# kernel B1 with the kept luma plane: variants (tests/_build/ab/<name>.so, built by tests/build_ab.sh with -DR2L_TEST_HOOKS)
+cd "$(dirname "$0")/.."
 run() { python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
 import sys, json
 o = json.loads(sys.stdin.readline()); k = o['kernels']
 print('%-40s ms/step %.4f ' % ('$1', o['ms_per_step']) + ' '.join('%s=%.1f' % (a.replace('r2l_launch_', '').replace('_kernel', ''), b['avg_us']) for a, b in sorted(k.items())))
 "; }
-export R2L_LIB_PATH=tests/_build/ab/b1s_occ1.so
-run "saved occ1 grid256"
-R2L_BWD1_RECOMPUTE=1 run "recompute grid256"
-export R2L_LIB_PATH=tests/_build/ab/b1s_occ2.so
-run "saved occ2 grid256"
-R2L_GRID_BWD1=512 run "saved occ2 grid512"
-R2L_GRID_BWD1=384 run "saved occ2 grid384"
-R2L_GRID_BWD1=512 R2L_BWD1_RECOMPUTE=1 run "recompute grid512"
+for r in 1 2; do
+for n in "$@"; do
+  export R2L_LIB_PATH=tests/_build/ab/$n.so
+  run "$n"
+done
+R2L_BWD1_RECOMPUTE=1 run "$1 recomputing"
+done
