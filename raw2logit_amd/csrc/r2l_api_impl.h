@@ -1319,4 +1319,11 @@ int r2l_l2_bwd(const float* x, const float* y, const float* grad_sum, float* gra
   return r2l_launch_l2(a, (int)g, stream);
 }
 
+#ifdef R2L_TEST_HOOKS
+// diagnostic builds: where the per-phase cycle stamps of -DR2L_EXP_STAMPS builds land in the workspace (tests/stamps.py)
+size_t r2l_test_debug_offset(int B, int H, int W) {
+  const R2LWorkspace ws = r2l_carve((void*)0, B, H, W);
+  return (size_t)((char*)ws.debug - (char*)0);
+}
+#endif
 }  // extern "C"

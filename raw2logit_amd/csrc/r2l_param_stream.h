@@ -274,14 +274,6 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
     ypn[3] = o[0][1];
     ypn[4] = o[1][0];
     ypn[5] = o[1][1];
-    if (ypb && store_ok && q - 1 >= y0 && q - 1 < y1) {  // kept for kernel B1 of the backward (the band's own rows)
-      r2l_f4 s4;
-      s4.x = o[0][0];
-      s4.y = o[0][1];
-      s4.z = o[1][0];
-      s4.w = o[1][1];
-      *(r2l_f4*)(ypb + (unsigned)(q - 1) * (unsigned)a.W + (unsigned)x0) = s4;
-    }
   }
   // ---- output row y = q-4 ------------------------------------------------------------------------------------
   const int y = q - 4;
@@ -337,6 +329,20 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
         s4.w = x[1][1];
         *(r2l_f4*)(ob + (unsigned)k * plane + off0) = s4;
       }
+    }
+    // Y'(y), kept for kernel B1 of the backward: the middle row of the blur's window, stored last (the step's
+    // registers are free here; next to the sharpen, or in front of the colour code, the kernel spills)
+    if (ypb && store_ok) {
+#ifndef R2L_EMUL
+      asm volatile("" ::: "memory");
+#endif
+      const float* ypy = st.yp[(K + 2) % 6];
+      r2l_f4 s4;
+      s4.x = ypy[2];
+      s4.y = ypy[3];
+      s4.z = ypy[4];
+      s4.w = ypy[5];
+      *(r2l_f4*)(ypb + off0) = s4;
     }
   }
   // rows of Y' that lie outside the image only ever meet zero weights, but must stay finite

@@ -19,13 +19,15 @@ gp = torch.empty(132, device=dev)
 bn = torch.tensor([0.4, 0.4, 0.4, 5., 5., 5.], device=dev)
 bnb = torch.tensor([0.01, 0.01, 0.01, 0.02, 0.02, 0.02], device=dev)
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+KEEP = 4 if os.environ.get('R2L_STAMPS_KEEP_LUMA') else 0     # R2L_F_KEEP_LUMA: kernel B1 reads Y' from the workspace
 for _ in range(3):
-    lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(P), None, ptr(bn), ptr(out), None, ptr(ws), n, B, H, W, 0, s), 'fwd')
-    lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(P), None, ptr(bn), ptr(bnb), ptr(gout), ptr(gp), None, ptr(ws), n, B, H, W, 0, s), 'bwd')
+    lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(P), None, ptr(bn), ptr(out), None, ptr(ws), n, B, H, W, KEEP, s), 'fwd')
+    lib.check(lib.r2l_isp_bwd(ptr(raw), ptr(P), None, ptr(bn), ptr(bnb), ptr(gout), ptr(gp), None, ptr(ws), n, B, H, W, 2 | KEEP, s), 'bwd')
 torch.cuda.synchronize()
-al = lambda x: (x + 255) & ~255
-off = al(4 * 267) + al(106 * 1024 * 4) + al(49 * 1024 * 4) + al(8 * 1024 * 4) + al(155 * 8) + al(155 * 64 * 8) + al(4 * 65)   # r2l_carve()
-dbg = ws[off:off + 3 * 8 * 1024 * 4].view(torch.float32).view(3, 1024, 8).double().cpu()
+MAXB = 2048                                  # R2L_MAX_BLOCKS
+lib.cdll.r2l_test_debug_offset.restype = ctypes.c_size_t
+off = lib.cdll.r2l_test_debug_offset(B, H, W)
+dbg = ws[off:off + 3 * 8 * MAXB * 4].view(torch.float32).view(3, MAXB, 8).double().cpu()
 names = {0: ['store', 'Y', 'YP', 'fill', 'pixels'], 1: ['store', 'Y', 'YP', 'fill', 'pixels'],
          2: ['store', 'adjblur', 'Y+fold', 'pixels', 'blockred', 'tree', 'unfold']}
 def report(k, kn, dbg):
@@ -37,10 +39,12 @@ if os.environ.get('R2L_STAMPS_STATS'):      # the statistics-only forward pass i
     for _ in range(3):
         lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(P), None, None, None, ptr(st7), ptr(ws), n, B, H, W, 1, s), 'fwd stats')
     torch.cuda.synchronize()
-    dbg = ws[off:off + 3 * 8 * 1024 * 4].view(torch.float32).view(3, 1024, 8).double().cpu()
+    dbg = ws[off:off + 3 * 8 * MAXB * 4].view(torch.float32).view(3, MAXB, 8).double().cpu()
 for k, kn in enumerate(['fwd', 'bwd1', 'bwd2']):
     d = dbg[k]
     nb = int((d.sum(1) > 0).sum())
+    if nb == 0:          # (the row-streaming forward carries no stamps)
+        continue
     d = d[:nb]
     rt = d[:, 7].mean().item()          # s_memrealtime ticks (100 MHz) over the same span
     d = d[:, :7]
