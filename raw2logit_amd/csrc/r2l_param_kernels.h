@@ -1382,11 +1382,14 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     }
     R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     if (haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
-    if (SAVED && haven) r2l_fetch_tile<G, 1>(tid, a.yp, tn, a.H, a.W, R2L_TREG(pre_yp));
     if (MAYBE_RAGGED && t.ragged)
       r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD, false>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
     else
       r2l_bwd1_pixels<G, false, ADD, !MAYBE_RAGGED>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
+#ifndef R2L_EMUL
+    asm volatile("" ::: "memory");
+#endif
+    if (SAVED && haven) r2l_fetch_tile<G, 1>(tid, a.yp, tn, a.H, a.W, R2L_TREG(pre_yp));
     R2L_PHASE_END
     R2L_STAMP(4)
     t = tn;
