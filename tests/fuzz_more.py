@@ -44,6 +44,8 @@ def fuzz_static():
         W += 2            # the plane passes need W % 4 == 0 (documented; the call raises otherwise)
     if deb == 'malvar2004' and (H < 6 or W < 6):
         H, W = max(H, 6), max(W, 8)
+    if rng.integers(0, 5) == 0:      # 2, 4 or 8 wavefronts side by side in the row-streaming chain kernels
+        W, H = int(rng.choice([260, 516, 772, 1024, 1028, 1540, 2048])), 2 * int(rng.integers(2, 40))
     u = rng.integers(0, 4096, (B, H, W)).astype(np.uint16)
     if rng.integers(0, 2):
         u[:, : H // 2] = rng.integers(240, 270, (B, H // 2, W))
@@ -57,6 +59,16 @@ def fuzz_static():
         dd = np.abs(out16.astype(np.float64) - out)
         assert np.array_equal(out16, out), ('static u16', (B, H, W), deb, sh, dn, 'max diff', float(dd.max()), 'pixels', int((dd > 0).sum()),
                                             'camera', 'drone' if cam is orc.DRONE_CAMERA_PARAMS else 'microscopy', np.argwhere(dd > 0)[:4].tolist())
+    if W % 4 == 0 and rng.integers(0, 3) == 0:      # float64 frames, and the T.Normalize epilogue on float32 ones
+        ref64 = orc.static_batch(raw_np.astype(np.float64), cam, deb, sh, dn)
+        out64 = F_.static_pipeline(torch.from_numpy(raw_np.astype(np.float64)).to(dev), cam, deb, sh, dn).cpu().numpy()
+        e64 = np.abs(out64 - ref64).max()
+        assert e64 <= 1e-5, ('static f64', (B, H, W), deb, sh, dn, e64)
+        ms = [float(v) for v in rng.uniform(0.2, 0.9, 3)] + [float(v) for v in rng.uniform(0.05, 0.3, 3)]
+        outn = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), cam, deb, sh, dn, mean_std=ms).cpu()
+        refn = (torch.from_numpy(out) - torch.tensor(ms[:3]).view(1, 3, 1, 1)) / torch.tensor(ms[3:]).view(1, 3, 1, 1)
+        assert torch.equal(outn, refn), ('static normalize', (B, H, W), deb, sh, dn)
+        e = max(e, e64)
     return e / 1e-5
 
 
