@@ -119,6 +119,36 @@ def test_full_size_static_config3_slice(dev):
     assert np.abs(outm[:1].cpu().numpy() - refm).max() <= 1e-5
 
 
+def test_full_size_static_config3_batch(dev):
+    """BASELINE config 3 at its full size (256 x 1024 x 1024, 12-bit frames drawn on the device): the short chain, the
+    train.py default chain and the Malvar2004 + median chain.  Size-independent properties: the first, a middle and
+    the last frame against the oracle (whole frames), batch independence (a frame processed alone gives the same
+    bits), and every output inside [0, 1] and finite."""
+    from raw2logit_amd import functional as F_
+    B, H, W = 256, 1024, 1024
+    g = torch.Generator(device=dev).manual_seed(3)
+    u = torch.randint(0, 4096, (B, H, W), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
+    # (tensor / tensor: ATen divides a float tensor by a Python scalar as a multiplication by its reciprocal, which is
+    # not the correctly rounded quotient the datasets' numpy division and the 16-bit entry points produce)
+    raw = u.to(torch.float32) / torch.full((), 4095.0, device=dev)
+    picks = (0, 131, 255)
+    host = {k: raw[k].cpu().numpy()[None] for k in picks}
+    for chain in (('bilinear', 'none', 'none'), ('bilinear', 'sharpening_filter', 'gaussian_denoising'),
+                  ('malvar2004', 'sharpening_filter', 'median_denoising')):
+        out = F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, *chain)
+        assert bool(torch.isfinite(out).all()) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0, chain
+        for k in picks:
+            ref = orc.static_batch(host[k], orc.DRONE_CAMERA_PARAMS, *chain)
+            e = np.abs(out[k:k + 1].cpu().numpy() - ref).max()
+            pc.report(f'config3 full size/{"+".join(chain)}/frame {k} vs oracle', e, 1e-5)
+            assert e <= 1e-5, (chain, k, e)
+        alone = F_.static_pipeline(raw[131:132], orc.DRONE_CAMERA_PARAMS, *chain)
+        assert torch.equal(alone, out[131:132]), chain
+        out16 = F_.static_pipeline(u[:4], orc.DRONE_CAMERA_PARAMS, *chain, bits=12)
+        assert torch.equal(out16, out[:4]), (chain, '16-bit containers')
+        del out
+
+
 def test_harness_logits_and_adam_step(golden, dev):
     pc.check_harness(golden, dev)
 
