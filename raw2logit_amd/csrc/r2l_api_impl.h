@@ -233,9 +233,14 @@ R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
 #ifndef R2L_CHAIN_OCC
 #define R2L_CHAIN_OCC 2
 #endif
+// behind unsharp_masking the 28 KB chroma ring per strip leaves one wavefront per SIMD on 1024-wide frames anyway:
+// 512 registers instead of spills
+#ifndef R2L_CHAIN_OCC_SH
+#define R2L_CHAIN_OCC_SH 1
+#endif
 // (the workgroup size and the LDS size follow the frame width at launch time: 64 threads and 16.1 KB per strip)
 #define R2L_CHAIN_KERNEL(name, RAWK, DEB, SH, DN)                                                             \
-  __global__ __launch_bounds__((SH) ? 256 : 512, R2L_CHAIN_OCC) void name##_kernel(const R2LStaticChainArgs a) { \
+  __global__ __launch_bounds__((SH) ? 256 : 512, (SH) ? R2L_CHAIN_OCC_SH : R2L_CHAIN_OCC) void name##_kernel(const R2LStaticChainArgs a) { \
     extern __shared__ __attribute__((aligned(16))) float r2l_chain_lds[];                                     \
     r2l_static_chain_block<RAWK, DEB, SH, DN>(a, (int)blockIdx.x, (int)gridDim.x, r2l_chain_lds);             \
   }                                                                                                           \
