@@ -209,6 +209,9 @@ R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L
 #ifndef R2L_STREAM_OCC_BILINEAR
 #define R2L_STREAM_OCC_BILINEAR 3
 #endif
+#ifndef R2L_STREAM_OCC_MALVAR
+#define R2L_STREAM_OCC_MALVAR 3
+#endif
 #define R2L_STREAM_KERNEL(name, DEB, RAWK, LUMA, OCC)                                                    \
   R2L_BLOCKFN void name##_block(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {          \
     r2l_static_stream_block<DEB, RAWK, LUMA>(sa, bid, nblk, lds);                                        \
@@ -216,15 +219,15 @@ R2L_KERNEL(r2l_launch_static_full, R2LStaticArgs, r2l_static_block<GStatic>, R2L
   R2L_KERNEL_NT(name, R2LStaticStreamArgs, name##_block, R2L_STREAM_NT, OCC)
 // demosaic x frame container (float32 | 16-bit | float64) x {whole short chain, luma-plane passes}
 R2L_STREAM_KERNEL(r2l_launch_static_stream_bilinear, 0, R2L_RAW_F32, false, R2L_STREAM_OCC_BILINEAR)
-R2L_STREAM_KERNEL(r2l_launch_static_stream_malvar, 1, R2L_RAW_F32, false, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_stream_malvar, 1, R2L_RAW_F32, false, R2L_STREAM_OCC_MALVAR)
 R2L_STREAM_KERNEL(r2l_launch_static_stream_bilinear_u16, 0, R2L_RAW_U16, false, R2L_STREAM_OCC_BILINEAR)
-R2L_STREAM_KERNEL(r2l_launch_static_stream_malvar_u16, 1, R2L_RAW_U16, false, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_stream_malvar_u16, 1, R2L_RAW_U16, false, R2L_STREAM_OCC_MALVAR)
 R2L_STREAM_KERNEL(r2l_launch_static_stream_bilinear_f64, 0, R2L_RAW_F64, false, 3)
 R2L_STREAM_KERNEL(r2l_launch_static_stream_malvar_f64, 1, R2L_RAW_F64, false, 2)
 R2L_STREAM_KERNEL(r2l_launch_static_luma_bilinear, 0, R2L_RAW_F32, true, R2L_STREAM_OCC_BILINEAR)
-R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar, 1, R2L_RAW_F32, true, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar, 1, R2L_RAW_F32, true, R2L_STREAM_OCC_MALVAR)
 R2L_STREAM_KERNEL(r2l_launch_static_luma_bilinear_u16, 0, R2L_RAW_U16, true, R2L_STREAM_OCC_BILINEAR)
-R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_u16, 1, R2L_RAW_U16, true, 3)
+R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_u16, 1, R2L_RAW_U16, true, R2L_STREAM_OCC_MALVAR)
 R2L_STREAM_KERNEL(r2l_launch_static_luma_bilinear_f64, 0, R2L_RAW_F64, true, 3)
 R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_f64, 1, R2L_RAW_F64, true, 2)
 R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)

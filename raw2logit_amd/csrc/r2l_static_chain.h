@@ -133,8 +133,8 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, SH, DN>& 
       // Malvar2004 convolves the UNMASKED mosaic (mirrored rows / columns are plain values) and selects by the
       // output pixel's site: rows q-2 .. q+2 of the ring of 6
       constexpr int R = DEB ? 6 : 3;
-      r2l_stream_malvar_row<PY>(st.rw[(K + 4) % R], st.rw[(K + 5) % R], st.rw[K % R], st.rw[(K + 1) % R],
-                                st.rw[(K + 2) % R], d);
+      r2l_stream_malvar_row_shared<PY>(st.rw[(K + 4) % R], st.rw[(K + 5) % R], st.rw[K % R], st.rw[(K + 1) % R],
+                                       st.rw[(K + 2) % R], d);
     }
     r2l_d2 uv[4];
     R2L_PRAGMA_UNROLL

@@ -349,6 +349,44 @@ R2L_HD void r2l_stream_malvar_row(const double* w0, const double* w1, const doub
   }
 }
 
+// Malvar2004 for the 4 pixels of a lane (w0 .. w4 = window rows y-2 .. y+2, 8 values each: columns x0-2 .. x0+5).
+// The four 5x5 kernels (r2l_malvar_* in r2l_static_kernels.h) are sums of a few symmetric groups of taps; the
+// vertical pair sums of a column serve every pixel whose window holds that column, so they are formed once per
+// column instead of once per pixel and kernel: ~60 float64 operations per row and lane instead of ~128.
+// (Summation order differs from the per-pixel form by float64 round-off only.)  Used by the luma-chain kernels
+// (r2l_static_chain.h: -2..3 %); in the short chain's kernel its 20 more live registers cost the third wavefront per
+// SIMD or spill (875 -> 1070-1165 us), so that one keeps the per-pixel form above.
+template <int PY>
+R2L_HD void r2l_stream_malvar_row_shared(const double* w0, const double* w1, const double* w2, const double* w3,
+                                  const double* w4, double d[4][3]) {
+  double v1[8], v2[8];  // rows y-1 + y+1 (columns 1 .. 6 used), rows y-2 + y+2 (columns 2 .. 5 used)
+  R2L_PRAGMA_UNROLL
+  for (int j = 1; j < 7; ++j) v1[j] = w1[j] + w3[j];
+  R2L_PRAGMA_UNROLL
+  for (int j = 2; j < 6; ++j) v2[j] = w0[j] + w4[j];
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) {
+    const int m = c + 2;  // window column of the pixel
+    const double ctr = w2[m];
+    const double h1 = w2[m - 1] + w2[m + 1], h2 = w2[m - 2] + w2[m + 2];
+    const double dg = v1[m - 1] + v1[m + 1];  // the four diagonal neighbours
+    const double far = v2[m] + h2;
+    if ((c & 1) == PY) {  // R site (PY 0, even column) or B site (PY 1, odd column): G and the opposite colour
+      const double g = (fma(2.0, v1[m] + h1, 4.0 * ctr) - far) * 0.125;
+      const double o = fma(-1.5, far, fma(2.0, dg, 6.0 * ctr)) * 0.125;
+      d[c][PY ? 2 : 0] = ctr;
+      d[c][1] = g;
+      d[c][PY ? 0 : 2] = o;
+    } else {  // G site: the colour of its row from the horizontal kernel, the other from the vertical one
+      const double hz = (fma(0.5, v2[m], fma(4.0, h1, 5.0 * ctr)) - dg - h2) * 0.125;
+      const double vt = (fma(0.5, h2, fma(4.0, v1[m], 5.0 * ctr)) - dg - v2[m]) * 0.125;
+      d[c][1] = ctr;
+      d[c][PY ? 2 : 0] = hz;   // red row (PY 0): R left / right; blue row: B left / right
+      d[c][PY ? 0 : 2] = vt;
+    }
+  }
+}
+
 #ifndef R2L_STREAM_PF_BILINEAR
 #define R2L_STREAM_PF_BILINEAR 5
 #endif
