@@ -58,7 +58,7 @@ enum {
 /* static-pipeline selectors (processing/pipeline_numpy.py:92-122) */
 enum { R2L_DEBAYER_BILINEAR = 0, R2L_DEBAYER_MALVAR2004 = 1 };
 enum { R2L_SHARPEN_NONE = 0, R2L_SHARPEN_FILTER = 1, R2L_SHARPEN_UNSHARP = 2 };
-enum { R2L_DENOISE_NONE = 0, R2L_DENOISE_GAUSSIAN = 1, R2L_DENOISE_MEDIAN = 2 };
+enum { R2L_DENOISE_NONE = 0, R2L_DENOISE_GAUSSIAN = 1, R2L_DENOISE_MEDIAN = 2, R2L_DENOISE_FFT = 3 };
 
 int r2l_abi_version(void);
 const char *r2l_last_error(void);
@@ -203,7 +203,11 @@ int r2l_isp_step_bwd(const void *raw, int raw_u16, float denom, const float *add
  * (:194-200)] -> clip[0,1] (:138) -> x**(1/gamma) (:241-244).  Linear part in float64 like the reference (black level: see below),
  * output (B,3,H,W) float32 (RawProcessingPipeline.__call__, :55-67).  camera_host: double[16] =
  * black_level[4], white_balance[3], colour_matrix[9] (host memory).
- * On frames with W % 4 == 0 up to 2048 wide (1024 behind unsharp_masking) every combination is ONE launch
+ * R2L_DENOISE_FFT = fft_denoising (:212-238 as :121-122 calls it: keep_fraction 0.3, columns only) -- per image row
+ * and colour channel an ideal low-pass along the columns of the sharpened RGB image: luma-plane passes + rocFFT
+ * (real-to-complex, Hermitian-symmetrised mask, complex-to-real) + a clip / gamma pass; W % 4 == 0; workspace
+ * from r2l_static_workspace_bytes().
+ * On frames with W % 4 == 0 up to 2048 wide (1024 behind unsharp_masking) every other combination is ONE launch
  * (row-streaming kernels); otherwise the short chain and the train.py defaults (bilinear + sharpening_filter
  * + gaussian_denoising, train.py:96-101) run as tile kernels and the other combinations as float64
  * luma-plane passes, which need r2l_static_workspace_bytes() of device memory (0 for the single-launch

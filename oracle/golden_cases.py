@@ -124,6 +124,13 @@ STATIC_CASES = [
     dict(name='u16_drone_default_scene_12bit', seed=23, shape=(1, 32, 48), kind='scene', camera='drone',
          dtype='float32', bits=12, debayer='bilinear', sharpening='sharpening_filter',
          denoising='gaussian_denoising'),
+    # fft_denoising (pipeline_numpy.py:212-238; train.py:100-101 offers it): the reference's own function, pinned
+    dict(name='f32_drone_fft', seed=27, shape=(2, 24, 40), kind='scene', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='fft_denoising'),
+    dict(name='f32_drone_malvar_unsharp_fft_dark', seed=28, shape=(1, 32, 36), kind='dark', camera='drone',
+         dtype='float32', debayer='malvar2004', sharpening='unsharp_masking', denoising='fft_denoising'),
+    dict(name='f64_micro_fft_uniform', seed=29, shape=(1, 16, 64), kind='uniform', camera='microscopy',
+         dtype='float64', debayer='bilinear', sharpening='none', denoising='fft_denoising'),
 ]
 
 

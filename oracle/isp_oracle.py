@@ -20,6 +20,7 @@ What is restated (all citations relative to /root/reference):
     sharpening_filter          :180-191
     gaussian_denoising         :203-209
     median_denoising           :194-200
+    fft_denoising              :212-238
     unsharp_masking            :170-177
     adjust_gamma               :241-244
 
@@ -624,6 +625,18 @@ def median_denoising(img, size=3):
     return yuv2rgb(img)
 
 
+def fft_denoising(img, keep_fraction=0.3):
+    """pipeline_numpy.py:212-238 as processing() calls it (:121-122: row_cut=False, column_cut=True).
+    scipy.fftpack.fft2 transforms the LAST two axes of the (H,W,3) array, i.e. (W, channel); zeroing the
+    slice [:, int(c*keep):int(c*(1-keep))] (c = W) along axis 1 for every channel frequency and inverting leaves
+    the channel transform undone: per image row and colour channel a 1-D ideal low-pass along the columns,
+    real part kept.  Restated on axis 1 only (equal to the 2-D form up to float64 round-off)."""
+    r, c, _ = img.shape
+    f = np.fft.fft(img, axis=1)
+    f[:, int(c * keep_fraction):int(c * (1 - keep_fraction))] = 0
+    return np.fft.ifft(f, axis=1).real
+
+
 def gaussian_kernel1d(sigma=0.5, truncate=4.0):
     """the taps scipy.ndimage.gaussian_filter uses: radius=int(truncate*sigma+0.5)."""
     r = int(truncate * float(sigma) + 0.5)
@@ -652,6 +665,8 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
         img = median_denoising(img)
     if denoising == "gaussian_denoising":
         img = gaussian_denoising(img)
+    if denoising == "fft_denoising":
+        img = fft_denoising(img, keep_fraction=0.3)
     img = np.clip(img, 0, 1)
     img = img ** (1.0 / gamma)
     return img

@@ -192,7 +192,7 @@ def hipcc_command(out_path=LIB_PATH, extra=()):
     # -fno-slp-vectorize: packed f32 is written out by hand where it pays (r2l_p2 pairs of adjacent pixels); the
     # SLP vectoriser's own pairing adds register shuffles and ~100 live VGPRs to the backward kernels
     return ['hipcc', '-O3', '-std=c++17', '-fno-slp-vectorize', '--offload-arch=gfx950', '-shared', '-fPIC',
-            *extra, os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path]
+            *extra, os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path, '-lrocfft']      # rocFFT: fft_denoising only
 
 
 def build_device_library(verbose=True, out_path=LIB_PATH, extra=()):

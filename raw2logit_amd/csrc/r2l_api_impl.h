@@ -7,7 +7,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "r2l_simple_kernels.h"
@@ -231,6 +234,8 @@ R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_u16, 1, R2L_RAW_U16, true, R2L_S
 R2L_STREAM_KERNEL(r2l_launch_static_luma_bilinear_f64, 0, R2L_RAW_F64, true, 3)
 R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_f64, 1, R2L_RAW_F64, true, 2)
 R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
+R2L_KERNEL(r2l_launch_spec_mask, R2LSpecMaskArgs, r2l_spec_mask_block, 4)
+R2L_KERNEL(r2l_launch_static_finish, R2LStaticFinishArgs, r2l_static_finish_block, 4)
 #ifndef R2L_EMUL
 // row-streaming luma chains (r2l_static_chain.h): NW wavefronts side by side cover frames up to 256 * NW columns
 #ifndef R2L_CHAIN_OCC
@@ -857,11 +862,12 @@ static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoisin
   if (r2l_env_int("R2L_STATIC_TILED", 0)) return false;
   (void)debayer;  // every demosaic, sharpening and denoising the library knows -- but for the chain without a luma stage
   // (behind unsharp_masking the chroma waits 7 rows for its luma: 28 KB of LDS per 256-column strip, 4 strips at most)
-  return (W & 3) == 0 && W <= (sharpening == R2L_SHARPEN_UNSHARP ? 1024 : 2048) &&
+  return (W & 3) == 0 && W <= (sharpening == R2L_SHARPEN_UNSHARP ? 1024 : 2048) && denoising != R2L_DENOISE_FFT &&
          !(sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE);
 #endif
 }
 static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoising, bool f64_frames = false) {
+  if (denoising == R2L_DENOISE_FFT) return false;
   if (sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE) return true;
   if (r2l_static_is_chain(W, debayer, sharpening, denoising)) return true;
   if (f64_frames) return false;  // the tile kernel of the default chain stages float32 frames in LDS
@@ -887,6 +893,72 @@ static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W, int d
   (void)B;
 }
 
+// ---- fft_denoising: the two transforms.  Device build: rocFFT plans (real <-> Hermitian, float64, rows of length W),
+// cached per (W, rows); the work buffer comes out of the caller's workspace like everything else.
+struct R2LFftPlans {
+#ifndef R2L_EMUL
+  rocfft_plan fwd = nullptr, inv = nullptr;
+#endif
+  size_t work_bytes = 0;
+};
+#ifndef R2L_EMUL
+static int r2l_fft_plans(int W, size_t rows, R2LFftPlans& out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, size_t>, R2LFftPlans> cache;
+  static bool setup = false;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!setup) {
+    if (rocfft_setup() != rocfft_status_success) return r2l_fail(-10, "rocfft_setup failed");
+    setup = true;
+  }
+  auto it = cache.find({W, rows});
+  if (it == cache.end()) {
+    R2LFftPlans p;
+    const size_t len = (size_t)W;
+    if (rocfft_plan_create(&p.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                           rocfft_precision_double, 1, &len, rows, nullptr) != rocfft_status_success ||
+        rocfft_plan_create(&p.inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                           rocfft_precision_double, 1, &len, rows, nullptr) != rocfft_status_success)
+      return r2l_fail(-10, "rocfft_plan_create failed");
+    size_t w0 = 0, w1 = 0;
+    rocfft_plan_get_work_buffer_size(p.fwd, &w0);
+    rocfft_plan_get_work_buffer_size(p.inv, &w1);
+    p.work_bytes = w0 > w1 ? w0 : w1;
+    it = cache.emplace(std::make_pair(W, rows), p).first;
+  }
+  out = it->second;
+  return 0;
+}
+static int r2l_fft_exec(rocfft_plan plan, void* in, void* outp, void* work, size_t work_bytes, void* stream) {
+  rocfft_execution_info info = nullptr;
+  if (rocfft_execution_info_create(&info) != rocfft_status_success) return r2l_fail(-10, "rocfft_execution_info_create failed");
+  rocfft_status st = rocfft_execution_info_set_stream(info, stream);
+  if (st == rocfft_status_success && work_bytes) st = rocfft_execution_info_set_work_buffer(info, work, work_bytes);
+  void* ins[1] = {in};
+  void* outs[1] = {outp};
+  if (st == rocfft_status_success) st = rocfft_execute(plan, ins, outs, info);
+  rocfft_execution_info_destroy(info);
+  return st == rocfft_status_success ? 0 : r2l_fail(-10, "rocfft_execute failed");
+}
+#endif
+// workspace of the fft_denoising chain behind the two luma planes: linear RGB planes, spectrum, rocFFT work buffer
+struct R2LFftLayout {
+  size_t rgb_off, spec_off, work_off, total, rows;
+  R2LFftPlans plans;
+};
+static int r2l_fft_layout(int B, int H, int W, R2LFftLayout& L) {
+  const size_t px = (size_t)B * H * W;
+  L.rows = (size_t)3 * B * H;
+  L.rgb_off = r2l_align_up(2 * sizeof(double) * px);
+  L.spec_off = L.rgb_off + r2l_align_up(3 * sizeof(double) * px);
+  L.work_off = L.spec_off + r2l_align_up(2 * sizeof(double) * L.rows * (size_t)(W / 2 + 1));
+#ifndef R2L_EMUL
+  if (int e = r2l_fft_plans(W, L.rows, L.plans)) return e;
+#endif
+  L.total = L.work_off + r2l_align_up(L.plans.work_bytes);
+  return 0;
+}
+
 static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int W, const double* camera_host,
                                int debayer, int sharpening, int denoising, double gamma, void* workspace,
                                size_t workspace_bytes, void* stream, const float* mean_std_host = nullptr) {
@@ -900,8 +972,9 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     return r2l_fail(-1, "r2l_static_fwd: unknown debayer");
   if (sharpening != R2L_SHARPEN_NONE && sharpening != R2L_SHARPEN_FILTER && sharpening != R2L_SHARPEN_UNSHARP)
     return r2l_fail(-1, "r2l_static_fwd: unknown sharpening");
-  if (denoising != R2L_DENOISE_NONE && denoising != R2L_DENOISE_GAUSSIAN && denoising != R2L_DENOISE_MEDIAN)
-    return r2l_fail(-4, "r2l_static_fwd: denoising must be none, gaussian_denoising or median_denoising");
+  if (denoising != R2L_DENOISE_NONE && denoising != R2L_DENOISE_GAUSSIAN && denoising != R2L_DENOISE_MEDIAN &&
+      denoising != R2L_DENOISE_FFT)
+    return r2l_fail(-4, "r2l_static_fwd: denoising must be none, gaussian_denoising, median_denoising or fft_denoising");
   if (!(gamma > 0)) return r2l_fail(-1, "r2l_static_fwd: gamma must be > 0");
   R2LStaticArgs a;
   r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, mean_std_host);
@@ -941,7 +1014,11 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     // luma-plane passes: raw -> Y | sharpen | denoise | raw + Y'' -> RGB
     if (W & 3) return r2l_fail(-4, "r2l_static_fwd: this chain runs as plane passes, which need W % 4 == 0");
     const size_t plane_bytes = sizeof(double) * (size_t)B * H * W;
-    if (!workspace || workspace_bytes < 2 * plane_bytes)
+    const bool fft = denoising == R2L_DENOISE_FFT;
+    R2LFftLayout L;
+    if (fft)
+      if (int e = r2l_fft_layout(B, H, W, L)) return e;
+    if (!workspace || workspace_bytes < (fft ? L.total : 2 * plane_bytes))
       return r2l_fail(-2, "r2l_static_fwd: workspace too small (r2l_static_workspace_bytes)");
     double* p0 = (double*)workspace;
     double* p1 = p0 + (size_t)B * H * W;
@@ -965,6 +1042,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     };
     sa.luma_out = p0;
     sa.luma_in = nullptr;
+    sa.lin_out = nullptr;
     if (int e = stream_pass(sa)) return e;
     double* cur = p0;
     double* other = p1;
@@ -991,7 +1069,29 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     }
     sa.luma_out = nullptr;
     sa.luma_in = cur;
-    return stream_pass(sa);
+    if (!fft) return stream_pass(sa);
+    // fft_denoising: sharpened RGB as float64 planes -> low-pass along the columns -> clip, gamma
+    double* rgb = (double*)((char*)workspace + L.rgb_off);
+    double* spec = (double*)((char*)workspace + L.spec_off);
+    sa.lin_out = rgb;
+    if (int e = stream_pass(sa)) return e;
+    const int cut0 = (int)(W * 0.3), cut1 = (int)(W * (1 - 0.3));  // int(c * keep_fraction), int(c * (1 - keep_fraction))
+#ifdef R2L_EMUL
+    (void)spec;
+    r2l_fft_lowpass_rows_host(rgb, L.rows, W, cut0, cut1);
+#else
+    void* work = (char*)workspace + L.work_off;
+    if (int e = r2l_fft_exec(L.plans.fwd, rgb, spec, work, L.plans.work_bytes, stream)) return e;
+    R2LSpecMaskArgs ma{spec, L.rows, W, cut0, cut1};
+    size_t gm = (L.rows * (size_t)(W / 2 + 1) + R2L_NT - 1) / R2L_NT;
+    if (gm > 16384) gm = 16384;
+    if (int e = r2l_launch_spec_mask(ma, (int)gm, stream)) return e;
+    if (int e = r2l_fft_exec(L.plans.inv, spec, rgb, work, L.plans.work_bytes, stream)) return e;
+#endif
+    R2LStaticFinishArgs fa{a, rgb};
+    size_t gf = ((size_t)B * H * W / 4 + R2L_NT - 1) / R2L_NT;
+    if (gf > 16384) gf = 16384;
+    return r2l_launch_static_finish(fa, (int)gf, stream);
   }
   if (a.full) {
     const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_STATIC_FULL", 256));
@@ -1084,13 +1184,20 @@ int r2l_raw2rgb_fwd_u16(const unsigned short* raw, float denom, const float* bla
   return r2l_raw2rgb_fwd_impl(r2l_raw_u16(raw, denom), black_level, out, B, H, W, reduce_size, out_channels,
                               stream);
 }
-size_t r2l_static_workspace_bytes(int B, int H, int W, int debayer, int sharpening, int denoising) {
-  if (B < 1 || H < 1 || W < 1 || r2l_static_is_fused(W, debayer, sharpening, denoising)) return 0;
+static size_t r2l_static_ws(int B, int H, int W, int debayer, int sharpening, int denoising, bool f64) {
+  if (B < 1 || H < 1 || W < 1 || r2l_static_is_fused(W, debayer, sharpening, denoising, f64)) return 0;
+  if (denoising == R2L_DENOISE_FFT) {
+    R2LFftLayout L;
+    if (r2l_fft_layout(B, H, W, L)) return 0;
+    return L.total;
+  }
   return 2 * sizeof(double) * (size_t)B * H * W;
 }
+size_t r2l_static_workspace_bytes(int B, int H, int W, int debayer, int sharpening, int denoising) {
+  return r2l_static_ws(B, H, W, debayer, sharpening, denoising, false);
+}
 size_t r2l_static_workspace_bytes_f64(int B, int H, int W, int debayer, int sharpening, int denoising) {
-  if (B < 1 || H < 1 || W < 1 || r2l_static_is_fused(W, debayer, sharpening, denoising, true)) return 0;
-  return 2 * sizeof(double) * (size_t)B * H * W;
+  return r2l_static_ws(B, H, W, debayer, sharpening, denoising, true);
 }
 int r2l_static_fwd_f64(const double* raw, float* out, int B, int H, int W, const double* camera_host,
                        int debayer, int sharpening, int denoising, double gamma, void* workspace,

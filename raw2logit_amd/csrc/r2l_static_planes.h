@@ -161,6 +161,96 @@ R2L_BLOCKFN void r2l_plane_filter_block(const R2LPlaneArgs& a, int bid, int nblk
   R2L_PHASE_END
 }
 
+// ---- fft_denoising (pipeline_numpy.py:212-238 as processing() calls it, :121-122): per image row and colour channel
+// the spectrum along the columns is zeroed for k in [int(W * keep), int(W * (1 - keep))) and the REAL PART of the
+// inverse transform is kept.  The input is real, so its spectrum F is Hermitian and Re(ifft(m F)) = ifft(h F) with
+// the symmetrised mask h_k = (m_k + m_{W-k}) / 2 (values 0, 1/2, 1): a real-to-complex transform, this mask on the
+// W/2 + 1 stored bins (with the 1/W of the unnormalised inverse), a complex-to-real transform.
+struct R2LSpecMaskArgs {
+  double* spec;  // [rows][W/2 + 1] interleaved complex
+  size_t rows;
+  int W, cut0, cut1;  // bins cut0 <= k < cut1 are zeroed
+};
+R2L_HD double r2l_fft_mask(int k, int W, int cut0, int cut1) {
+  const int kk = (W - k) % W;
+  const double m0 = (k >= cut0 && k < cut1) ? 0.0 : 1.0, m1 = (kk >= cut0 && kk < cut1) ? 0.0 : 1.0;
+  return 0.5 * (m0 + m1);
+}
+R2L_BLOCKFN void r2l_spec_mask_block(const R2LSpecMaskArgs& a, int bid, int nblk, float* lds) {
+  (void)lds;
+  const int nb = a.W / 2 + 1;
+  const size_t n = a.rows * (size_t)nb;
+  R2L_PHASE_BEGIN
+  for (size_t i = (size_t)bid * R2L_NT + tid; i < n; i += (size_t)nblk * R2L_NT) {
+    const int k = (int)(i % (size_t)nb);
+    const double h = r2l_fft_mask(k, a.W, a.cut0, a.cut1) / (double)a.W;
+    a.spec[2 * i] *= h;
+    a.spec[2 * i + 1] *= h;
+  }
+  R2L_PHASE_END
+}
+// float64 planes (B,3,H,W) -> clip, gamma (+ the T.Normalize epilogue) -> float32 output; 4 pixels per lane
+struct R2LStaticFinishArgs {
+  R2LStaticArgs s;
+  const double* lin;
+};
+R2L_BLOCKFN void r2l_static_finish_block(const R2LStaticFinishArgs& fa, int bid, int nblk, float* lds) {
+  (void)lds;
+  const R2LStaticArgs& a = fa.s;
+  const size_t hw4 = (size_t)a.H * a.W / 4, n = (size_t)a.B * hw4;  // W % 4 == 0
+  R2L_PHASE_BEGIN
+  for (size_t i = (size_t)bid * R2L_NT + tid; i < n; i += (size_t)nblk * R2L_NT) {
+    const size_t b = i / hw4, off = (i - b * hw4) * 4;
+    float x[3][4];
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k)
+      R2L_PRAGMA_UNROLL
+    for (int c = 0; c < 4; ++c)
+      x[k][c] = r2l_clip_gamma(fa.lin[((size_t)b * 3 + k) * hw4 * 4 + off + c], a.inv_gamma);
+    r2l_static_normalize<4>(a, x);
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      r2l_f4 st;
+      st.x = x[k][0];
+      st.y = x[k][1];
+      st.z = x[k][2];
+      st.w = x[k][3];
+      *(r2l_f4*)(a.out + ((size_t)b * 3 + k) * hw4 * 4 + off) = st;
+    }
+  }
+  R2L_PHASE_END
+}
+#ifdef R2L_EMUL
+// host emulation of the two transforms + mask (the device build calls rocFFT): plain O(W^2) DFT per row
+static inline void r2l_fft_lowpass_rows_host(double* rows, size_t nrows, int W, int cut0, int cut1) {
+  std::vector<double> re(W), im(W), out(W);
+  const double w0 = 2.0 * 3.14159265358979323846 / (double)W;
+  for (size_t r = 0; r < nrows; ++r) {
+    double* x = rows + r * (size_t)W;
+    for (int k = 0; k < W; ++k) {
+      double sr = 0.0, si = 0.0;
+      for (int j = 0; j < W; ++j) {
+        const double ang = w0 * (double)(((long long)k * j) % W);
+        sr += x[j] * cos(ang);
+        si -= x[j] * sin(ang);
+      }
+      const bool cut = k >= cut0 && k < cut1;
+      re[k] = cut ? 0.0 : sr;
+      im[k] = cut ? 0.0 : si;
+    }
+    for (int j = 0; j < W; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < W; ++k) {
+        const double ang = w0 * (double)(((long long)k * j) % W);
+        s += re[k] * cos(ang) - im[k] * sin(ang);
+      }
+      out[j] = s / (double)W;
+    }
+    for (int j = 0; j < W; ++j) x[j] = out[j];
+  }
+}
+#endif
+
 #ifndef R2L_EMUL
 #pragma clang fp contract(fast)  // end of the static chains (see r2l_static_kernels.h)
 #endif

@@ -21,6 +21,9 @@ struct R2LStaticStreamArgs {
   // chroma from the raw frame, takes the filtered luma from the plane and finishes (YUV->RGB, clip, gamma)
   double* luma_out;
   const double* luma_in;
+  // fft_denoising works on the sharpened RGB image before clip and gamma: with lin_out the last pass stores that
+  // image as float64 planes (B,3,H,W) instead of finishing
+  double* lin_out;
 };
 
 // raw values of columns x0-2 .. x0+5 of source row `ys` (symmetric extension at the image edges); with 16-bit
@@ -254,6 +257,20 @@ R2L_HD void r2l_stream_luma_in_row(const R2LStaticArgs& a, const double d[4][3],
   }
 }
 
+// the same up to yuv2rgb, stored as float64 planes (the input of fft_denoising)
+R2L_HD void r2l_stream_lin_out_row(const R2LStaticArgs& a, const double d[4][3], const double* yplane, double* linb,
+                                   size_t plane, size_t off) {
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 4; ++c) {
+    const double yy = yplane[off + c];
+    const double u = fma(a.T[3], d[c][0], fma(a.T[4], d[c][1], a.T[5] * d[c][2]));
+    const double v = fma(a.T[6], d[c][0], fma(a.T[7], d[c][1], a.T[8] * d[c][2]));
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k)
+      linb[(size_t)k * plane + off + c] = fma(a.M2[k * 3], yy, fma(a.M2[k * 3 + 1], u, a.M2[k * 3 + 2] * v));
+  }
+}
+
 // bilinear row: w0/w1/w2 = window rows y-1, y, y+1 (8 values each); tpy = their source row parities
 R2L_HD void r2l_stream_bilinear_row(const double* w0, const double* w1, const double* w2, const int tpy[3],
                                     bool le, bool re, double d[4][3]) {
@@ -461,6 +478,8 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
         }
         if (LUMA && sa.luma_out)
           r2l_stream_luma_out_row(a, d, sa.luma_out, img + (size_t)y * a.W + x0);
+        else if (LUMA && sa.lin_out)
+          r2l_stream_lin_out_row(a, d, sa.luma_in + img, sa.lin_out + 3 * img, plane, (size_t)y * a.W + x0);
         else if (LUMA)
           r2l_stream_luma_in_row(a, d, sa.luma_in + img, outb, plane, (size_t)y * a.W + x0);
         else

@@ -300,7 +300,7 @@ def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
 # --------------------------------------------------------------------------------------------------
 _DEBAYER = {'bilinear': 0, 'malvar2004': 1}
 _SHARPEN = {'sharpening_filter': 1, 'unsharp_masking': 2}
-_DENOISE = {'gaussian_denoising': 1, 'median_denoising': 2}
+_DENOISE = {'gaussian_denoising': 1, 'median_denoising': 2, 'fft_denoising': 3}
 
 
 def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
@@ -318,7 +318,7 @@ def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='shar
 
     Like the reference's if-chains (pipeline_numpy.py:110-122) a sharpening / denoising string that
     names no algorithm means "skip that stage"; algorithms the reference has but this library does not
-    build (menon2007, unsharp_masking, median/fft/... denoising) raise instead of silently differing."""
+    build (menon2007, tv_chambolle / tv_bregman / bilateral denoising) raise instead of silently differing."""
     assert raw.ndim == 3, f"needs dims (B, H, W), got {raw.shape}"
     f64 = raw.dtype == torch.float64
     if f64:

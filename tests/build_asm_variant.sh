@@ -14,5 +14,5 @@ $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $W/dev.s -o $
 $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $W/dev.out $W/dev.o
 $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$W/dev.out -output=$W/dev.hipfb
 hipcc $FLAGS --cuda-host-only -fPIC -Xclang -fcuda-include-gpubinary -Xclang $W/dev.hipfb -c raw2logit_amd/csrc/r2l_api.hip -o $W/host.o 2>/dev/null
-hipcc -shared $W/host.o -o tests/_build/ab/$1.so
+hipcc -shared $W/host.o -o tests/_build/ab/$1.so -lrocfft
 ls -la tests/_build/ab/$1.so

@@ -37,7 +37,7 @@ def fuzz_static():
     B, H, W = rand_shape(wmul=int(rng.choice([2, 4])))
     deb = ['bilinear', 'malvar2004'][int(rng.integers(0, 2))]
     sh = ['none', 'sharpening_filter', 'unsharp_masking'][int(rng.integers(0, 3))]
-    dn = ['none', 'gaussian_denoising', 'median_denoising'][int(rng.integers(0, 3))]
+    dn = ['none', 'gaussian_denoising', 'median_denoising', 'fft_denoising'][int(rng.integers(0, 4))]
     cam = [orc.DRONE_CAMERA_PARAMS, orc.MICROSCOPY_CAMERA_PARAMS][int(rng.integers(0, 2))]
     fused = (sh == 'none' and dn == 'none') or (deb == 'bilinear' and sh == 'sharpening_filter' and dn == 'gaussian_denoising')
     if not fused and W % 4:

@@ -284,7 +284,7 @@ def check_static_combinations(device):
         raw = torch.from_numpy(raw_np).to(device)
         for deb in ('bilinear', 'malvar2004'):
             for sh in ('none', 'sharpening_filter', 'unsharp_masking'):
-                for dn in ('none', 'gaussian_denoising', 'median_denoising'):
+                for dn in ('none', 'gaussian_denoising', 'median_denoising', 'fft_denoising'):
                     ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
                     out = F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
                     err = np.abs(out.cpu().numpy() - ref).max()
@@ -678,7 +678,7 @@ def check_error_behaviour(device):
     with pytest.raises(NotImplementedError):
         F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, debayer='menon2007')
     with pytest.raises(NotImplementedError):
-        F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, denoising='fft_denoising')
+        F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, denoising='tv_chambolle')
     with pytest.raises(NotImplementedError):
         losses.SSIM(window_size=7)
     with pytest.raises(ValueError):
