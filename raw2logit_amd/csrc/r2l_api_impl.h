@@ -189,9 +189,9 @@ R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_b
 #ifndef R2L_OCC_BWD1S
 #define R2L_OCC_BWD1S 1
 #endif
-R2L_KERNEL_V(r2l_launch_bwd1_saved, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, false, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_saved, R2LBwd1Args, R2L_LDS3(GBwd1) + GBwd1::PAD + R2L_B1_FRAME_FLOATS, R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, false, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, true, false, true>)
-R2L_KERNEL_V(r2l_launch_bwd1_saved_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, true, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_saved_u16, R2LBwd1Args, R2L_LDS3(GBwd1) + GBwd1::PAD + R2L_B1_FRAME_FLOATS, R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, true, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, true, true, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
 R2L_KERNEL_V(r2l_launch_bwd2, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bwd2_block<GBwd2, false>)
@@ -247,6 +247,7 @@ R2L_KERNEL(r2l_launch_static_finish, R2LStaticFinishArgs, r2l_static_finish_bloc
 #define R2L_CHAIN_OCC_SH 1
 #endif
 // (the workgroup size and the LDS size follow the frame width at launch time: 64 threads and 16.1 KB per strip)
+#define R2L_MAX_DEVICES 64
 #define R2L_CHAIN_KERNEL(name, RAWK, DEB, SH, DN)                                                             \
   __global__ __launch_bounds__((SH) ? 256 : 512, (SH) ? R2L_CHAIN_OCC_SH : R2L_CHAIN_OCC) void name##_kernel(const R2LStaticChainArgs a) { \
     extern __shared__ __attribute__((aligned(16))) float r2l_chain_lds[];                                     \
@@ -254,12 +255,20 @@ R2L_KERNEL(r2l_launch_static_finish, R2LStaticFinishArgs, r2l_static_finish_bloc
   }                                                                                                           \
   static int name(const R2LStaticChainArgs& a, int grid, void* stream) {                                      \
     const size_t lds_bytes = sizeof(double) * R2L_CHAIN_LDS_DOUBLES(a.nw, SH);                                \
-    static size_t lds_ok = 48 * 1024;                                                                         \
-    if (lds_bytes > lds_ok) {                                                                                 \
-      const hipError_t ea = hipFuncSetAttribute((const void*)name##_kernel,                                   \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-      if (ea != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(ea));            \
-      lds_ok = lds_bytes;                                                                                     \
+    {                                                                                                         \
+      /* the attribute is per device: remember what each device of this process was granted */               \
+      static std::mutex mu_;                                                                                  \
+      static size_t lds_ok[R2L_MAX_DEVICES];                                                                  \
+      int dev_ = 0;                                                                                           \
+      (void)hipGetDevice(&dev_);                                                                              \
+      std::lock_guard<std::mutex> g_(mu_);                                                                    \
+      size_t& ok_ = lds_ok[(unsigned)dev_ % R2L_MAX_DEVICES];                                                 \
+      if (lds_bytes > (ok_ ? ok_ : (size_t)48 * 1024)) {                                                      \
+        const hipError_t ea = hipFuncSetAttribute((const void*)name##_kernel,                                 \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);\
+        if (ea != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(ea));          \
+        ok_ = lds_bytes;                                                                                      \
+      }                                                                                                       \
     }                                                                                                         \
     R2LTimedLaunch t_;                                                                                        \
     const bool timed_ = r2l_timing_on;                                                                        \
@@ -674,6 +683,13 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC, g1};
   a2.params = params;
   a2.grad_params = grad_params;
+  // two workgroups per CU: the older one (dispatched first) gets more issue slots -- and one tile more every 4 rounds
+  // (r2l_walk_init); only when the launch really is two resident workgroups per CU with several tiles each
+#ifndef R2L_B2_ASYM
+#define R2L_B2_ASYM 4
+#endif
+  a2.asym = (R2L_OCC_BWD2 >= 4 && g2 == 512 && ntiles2 >= 4 * g2) ? r2l_env_int("R2L_B2_ASYM", R2L_B2_ASYM) : 0;
+  if (a2.asym == 1) a2.asym = 0;
   if (int e = raw.u16 ? r2l_launch_bwd2_u16(a2, g2, stream) : r2l_launch_bwd2(a2, g2, stream)) return e;
   if (in_kernel) return 0;
   R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0, nullptr};
@@ -904,15 +920,19 @@ struct R2LFftPlans {
 #ifndef R2L_EMUL
 static int r2l_fft_plans(int W, size_t rows, R2LFftPlans& out) {
   static std::mutex mu;
-  static std::map<std::pair<int, size_t>, R2LFftPlans> cache;
+  static std::map<std::pair<int, std::pair<int, size_t>>, R2LFftPlans> cache;  // (device, (W, rows))
   static bool setup = false;
   std::lock_guard<std::mutex> lk(mu);
   if (!setup) {
     if (rocfft_setup() != rocfft_status_success) return r2l_fail(-10, "rocfft_setup failed");
     setup = true;
   }
-  auto it = cache.find({W, rows});
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const std::pair<int, std::pair<int, size_t>> key{dev, {W, rows}};
+  auto it = cache.find(key);
   if (it == cache.end()) {
+    // (plans live as long as the process: a caller on another thread may be executing one, so none is destroyed here)
     R2LFftPlans p;
     const size_t len = (size_t)W;
     if (rocfft_plan_create(&p.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
@@ -924,7 +944,7 @@ static int r2l_fft_plans(int W, size_t rows, R2LFftPlans& out) {
     rocfft_plan_get_work_buffer_size(p.fwd, &w0);
     rocfft_plan_get_work_buffer_size(p.inv, &w1);
     p.work_bytes = w0 > w1 ? w0 : w1;
-    it = cache.emplace(std::make_pair(W, rows), p).first;
+    it = cache.emplace(key, p).first;
   }
   out = it->second;
   return 0;
@@ -1440,5 +1460,30 @@ size_t r2l_test_debug_offset(int B, int H, int W) {
   const R2LWorkspace ws = r2l_carve((void*)0, B, H, W);
   return (size_t)((char*)ws.debug - (char*)0);
 }
+#ifdef R2L_EMUL
+// the tile walk of the persistent kernels, replayed on the host: owner[tile] = workgroup id that visits it (or -1), and
+// the number of visits per tile in visits[tile]; returns the largest number of tiles any workgroup takes
+int r2l_test_walk(int B, int H, int W, int nblk, int asym, int* owner, int* visits) {
+  const int ntx = (W + 63) / 64, nty = (H + 63) / 64, ntiles = B * ntx * nty;
+  for (int i = 0; i < ntiles; ++i) {
+    owner[i] = -1;
+    visits[i] = 0;
+  }
+  int most = 0;
+  for (int bid = 0; bid < nblk; ++bid) {
+    R2LTileWalk w = r2l_walk_init(B, H, W, 64, 64, bid, nblk, asym);
+    R2LTile t;
+    int n = 0;
+    while (r2l_walk_next(w, H, W, 64, 64, t)) {
+      const int tile = (t.b * nty + t.oy / 64) * ntx + t.ox / 64;
+      owner[tile] = bid;
+      visits[tile] += 1;
+      n += 1;
+    }
+    most = n > most ? n : most;
+  }
+  return most;
+}
+#endif
 #endif
 }  // extern "C"

@@ -207,6 +207,42 @@ R2L_HD r2l_f4 r2l_lds_f4(const float* p) {
 }
 #endif
 
+// Asynchronous global -> LDS copy of 16 bytes per lane (gfx950 `global_load_lds_dwordx4`): no destination registers, the
+// data lands in LDS while the wave computes.  The hardware writes lane l of the wavefront at (wave-uniform LDS base) +
+// 16 l: a lane-linear staging area, 1 KiB per wave-instruction; the source is (wave-uniform base pointer) + (per-lane byte
+// offset), i.e. one scalar register pair and ONE vector register per copy.
+// Written as an asm statement on purpose: hipcc keeps no account of it, so no `s_waitcnt vmcnt` is inserted in front of
+// the NEXT LDS read (through __builtin_amdgcn_global_load_lds every later ds_read waits for the copy -- its whole memory
+// latency, in the middle of the phase that was supposed to hide it).  The consumer therefore waits itself:
+// r2l_glds_wait(), then a barrier if other lanes read the data.  (Vector-memory operations complete in issue order, so the
+// compiler's own counted waits for ITS loads stay correct: an untracked operation in between only makes them wait for
+// more, never for less.)  Default cache policy: a nontemporal copy of a plane another kernel of the step re-writes made
+// that kernel slower (profiles/r03_b1_staging_modes.txt).
+#ifdef R2L_EMUL
+R2L_HD void r2l_glds16(const float* base, unsigned lane_byte_off, float* lane_slot) {
+  *(r2l_f4*)lane_slot = *(const r2l_f4*)((const char*)base + lane_byte_off);
+}
+R2L_HD void r2l_glds_wait() {}
+#else
+#ifndef R2L_GLDS_POLICY
+#define R2L_GLDS_POLICY ""  // " nt": A/B builds
+#endif
+R2L_HD void r2l_glds16(const float* base, unsigned lane_byte_off, float* lane_slot) {
+  // wave-uniform LDS base = the slot of lane 0, whether or not lane 0 takes part (v_readfirstlane reads the first ACTIVE lane)
+  const unsigned lbase = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) float*)lane_slot - 16u * (unsigned)R2L_LANE_ID);
+  const unsigned long long gb = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)gb), hi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));
+  const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" R2L_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_byte_off), "s"(sb), "s"(lbase)
+               : "memory");
+}
+R2L_HD void r2l_glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+
 #define R2L_LN2 0.69314718055994530942
 
 // Primitives of the in-kernel final reductions.  Partials travel between workgroups (possibly on different
@@ -528,6 +564,21 @@ R2L_HD double r2l_unfold_gT(const float* P, const double* S, int k, int j) {
     }
   return s;
 }
+// black_level[site] gets  - sum_{k, par, t : site(par, t) == site} A[k][par][t] * S_k[par]  (S_k[par] = sum of gK over
+// the pixels of parity par; the raw value at p + t has the black level of ITS site subtracted): the k-th part of it
+R2L_HD double r2l_unfold_bl_part(const double* S, const double* TG, int site, int k) {
+  const double* b1 = S;
+  const double* b2 = S + R2L_B1_NACC;
+  const double* SS = (k == 0) ? (b2 + R2L_B2_SY) : (k == 1 ? b1 + R2L_B1_SU : b1 + R2L_B1_SV);
+  double g = 0;
+  for (int par = 0; par < 4; ++par)
+    for (int t = 0; t < 9; ++t) {
+      const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
+      if ((((py + dy + 2) & 1) * 2 + ((px + dx + 2) & 1)) != site) continue;
+      g -= TG[18 + (k * 4 + par) * 9 + t] * SS[par];  // folded A[k][par][t], float64
+    }
+  return g;
+}
 // Unfold the reduced sums into the gradient of trainable parameter `o` (index into the packed block);
 // float64 throughout, one lane per parameter.  TG = T[9] (r2l_fold_T_one), gT[9] (r2l_unfold_gT) and the
 // folded stencils A[3][4][9] (r2l_fold_A_one), computed once per launch by 126 lanes.  P, S and TG are read in place (they sit in LDS): no lane-private
@@ -554,20 +605,8 @@ R2L_HD float r2l_unfold_one(const float* P, const double* S, int o, const double
     }
     return (float)g;
   }
-  if (o < R2L_P_WHITE_BALANCE) {  // black_level[site]
-    double g = 0;
-    for (int k = 0; k < 3; ++k) {
-      const double* SS = (k == 0) ? (b2 + R2L_B2_SY) : (k == 1 ? b1 + R2L_B1_SU : b1 + R2L_B1_SV);
-      for (int par = 0; par < 4; ++par)
-        for (int t = 0; t < 9; ++t) {
-          const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
-          const int site = ((py + dy + 2) & 1) * 2 + ((px + dx + 2) & 1);
-          if (site != o) continue;
-          g -= TG[18 + (k * 4 + par) * 9 + t] * SS[par];  // folded A[k][par][t], float64
-        }
-    }
-    return (float)g;
-  }
+  if (o < R2L_P_WHITE_BALANCE)  // black_level[site]: the three per-k partial sums (r2l_unfold_bl_part)
+    return (float)(TG[126 + o * 3] + TG[126 + o * 3 + 1] + TG[126 + o * 3 + 2]);
   // white balance / colour matrix: through gT
   if (o < R2L_P_CCM) {
     const int c = o - R2L_P_WHITE_BALANCE;

@@ -21,10 +21,23 @@
 #define R2L_STAMP(k) t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - t0_; t0_ = t1_;
 #define R2L_STAMP_FLUSH(dbg, bid) st_[7] = __builtin_amdgcn_s_memrealtime() - r0_; /* 100 MHz ticks: slot 7 */ \
   if (threadIdx.x == 0 && (dbg)) for (int k_ = 0; k_ < 8; ++k_) (dbg)[(size_t)(bid) * 8 + k_] = (float)st_[k_];
+// stage stamps inside kernel B1's pixel phase (slots 1, 2 -- unused when Y' comes from the forward: blur + chroma | pointwise)
+#define R2L_SUB_ARG , unsigned long long* sub_
+#define R2L_SUB_PASS , st_
+#define R2L_SUB_PASS_FWD , sub_
+#define R2L_SUB_PASS_NONE , (unsigned long long*)nullptr
+#define R2L_SUB_BEGIN unsigned long long s0_ = __builtin_amdgcn_s_memtime(), s1_;
+#define R2L_SUB(k) if (sub_) { s1_ = __builtin_amdgcn_s_memtime(); sub_[k] += s1_ - s0_; s0_ = s1_; }
 #else
 #define R2L_STAMP_DECL
 #define R2L_STAMP(k)
 #define R2L_STAMP_FLUSH(dbg, bid)
+#define R2L_SUB_ARG
+#define R2L_SUB_PASS
+#define R2L_SUB_PASS_FWD
+#define R2L_SUB_PASS_NONE
+#define R2L_SUB_BEGIN
+#define R2L_SUB(k)
 #endif
 
 template <int TW_, int TH_>
@@ -86,9 +99,16 @@ R2L_HD int r2l_div(int n, const R2LDiv& dv) { return (int)((r2l_mulhi(dv.m, (uns
 
 struct R2LTileWalk {
   int ntx, nty, ntiles, nper, group, w, k, jstep;
-  R2LDiv dx, dy, dj;
+  int asym;  // > 0: every asym-th round of the walk is a HALF round, served by the older half of the workgroups only
+  R2LDiv dx, dy, dj, dh;
 };
-R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, int nblk) {
+// asym: two workgroups share a CU and the hardware's issue arbitration favours the waves of the one dispatched first
+// (by age): with equal shares the older workgroup of kernel B2 finishes its tiles in ~140 kcycles, the younger one needs
+// ~178 and the launch lasts as long as the slowest (profiles/r02_l_bwd2_stream_experiment.txt).  Workgroups are
+// dispatched in id order, so ids below nblk / 2 are the older ones: they take one tile more every `asym` rounds (asym = 4,
+// 8 tiles per workgroup on average: 9 vs 7).  The tile -> workgroup map stays a pure function of (bid, nblk): sums do not
+// depend on the schedule.
+R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, int nblk, int asym = 0) {
   R2LTileWalk w;
   w.ntx = (W + TW - 1) / TW;
   w.nty = (H + TH - 1) / TH;
@@ -99,9 +119,11 @@ R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, i
   w.w = bid / ngroups;
   w.k = 0;
   w.jstep = nblk / ngroups;
+  w.asym = (asym > 1 && (w.jstep & 1) == 0 && w.jstep >= 2) ? asym : 0;
   w.dx = r2l_div_init(w.ntx);
   w.dy = r2l_div_init(w.nty);
   w.dj = r2l_div_init(w.jstep);
+  w.dh = r2l_div_init(w.jstep > 1 ? w.jstep / 2 : 1);
   return w;
 }
 // k-th tile of a workgroup: block k of `jstep` consecutive tiles, rotated by k tile rows + k tile columns
@@ -110,9 +132,25 @@ R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, i
 // that start in the first or last tile row would see nothing but border tiles (measured: slowest workgroup
 // 28 % above the mean).
 R2L_HD bool r2l_walk_next(R2LTileWalk& w, int H, int W, int TW, int TH, R2LTile& t) {
-  while (w.k * w.jstep < w.nper) {
+  for (;;) {
+    // first tile of round k: rounds before it hold jstep tiles each, but for the half rounds (every asym-th)
+    int base = w.k * w.jstep;
+    bool half = false;
+    if (w.asym) {
+      const int q = w.k / w.asym;
+      base -= q * (w.jstep / 2);
+      half = (w.k - q * w.asym) == w.asym - 1;
+    }
+    if (base >= w.nper) return false;
     const int rot = w.w + w.k * (w.ntx + 1);
-    const int j = w.k * w.jstep + (rot - r2l_div(rot, w.dj) * w.jstep);
+    int j;
+    if (half) {
+      const int hs = w.jstep / 2;
+      j = base + (rot - r2l_div(rot, w.dh) * hs);
+      if (w.w >= hs) j = w.nper;  // the younger half sits this round out
+    } else {
+      j = base + (rot - r2l_div(rot, w.dj) * w.jstep);
+    }
     w.k += 1;
     if (j >= w.nper) continue;
     const int tile = w.group * w.nper + j;
@@ -125,7 +163,6 @@ R2L_HD bool r2l_walk_next(R2LTileWalk& w, int H, int W, int TW, int TH, R2LTile&
     t.ragged = (t.oy + TH > H) || (t.ox + TW > W) || ((W & 3) != 0);
     return true;
   }
-  return false;
 }
 
 // ---- phase A: raw tile + halo -> V -------------------------------------------------------------
@@ -162,12 +199,17 @@ struct R2LPrefetch {
 // MODE 0: raw frame values with mirror coordinates outside the image (the V plane before black level)
 // MODE 1: plain plane, zero outside the image
 template <class G, bool BORDER, int MODE>
-R2L_HD void r2l_fetch_frame(int tid, const float* gb, int oy, int ox, int H, int W, R2LPrefetch<G>& pf) {
+R2L_HD void r2l_fetch_frame(int tid, const float* gb, int oy, int ox, int H, int W, R2LPrefetch<G>& pf,
+                            int only = -1 /* >= 0: that chunk of the lane alone (loads spread over a phase) */) {
   R2LChunkWalk<G> w;
   w.init(tid);
   const bool vec_ok = (W & 3) == 0;
   R2L_PRAGMA_UNROLL
   for (int it = 0; it < R2LPrefetch<G>::NIT; ++it) {
+    if (only >= 0 && it != only) {
+      w.next();
+      continue;
+    }
     r2l_f4 v;
     v.x = v.y = v.z = v.w = 0.f;
     if (w.fy < G::FH) {
@@ -206,24 +248,28 @@ R2L_HD void r2l_fetch_frame(int tid, const float* gb, int oy, int ox, int H, int
   }
 }
 template <class G, int MODE>
-R2L_HD void r2l_fetch_tile(int tid, const float* gb, const R2LTile& t, int H, int W, R2LPrefetch<G>& pf) {
+R2L_HD void r2l_fetch_tile(int tid, const float* gb, const R2LTile& t, int H, int W, R2LPrefetch<G>& pf, int only = -1) {
   const float* base = gb + (size_t)t.b * H * W;
   if (t.border)
-    r2l_fetch_frame<G, true, MODE>(tid, base, t.oy, t.ox, H, W, pf);
+    r2l_fetch_frame<G, true, MODE>(tid, base, t.oy, t.ox, H, W, pf, only);
   else
-    r2l_fetch_frame<G, false, MODE>(tid, base, t.oy, t.ox, H, W, pf);
+    r2l_fetch_frame<G, false, MODE>(tid, base, t.oy, t.ox, H, W, pf, only);
 }
 
 // 16-bit containers: the 4 values of a chunk travel as raw bits in .x/.y of the prefetch register (decoded
 // when they are written to LDS, so that the fetch stays a fire-and-forget load)
 template <class G, bool BORDER>
 R2L_HD void r2l_fetch_frame_u16(int tid, const unsigned short* gb, int oy, int ox, int H, int W,
-                                R2LPrefetch<G>& pf) {
+                                R2LPrefetch<G>& pf, int only = -1) {
   R2LChunkWalk<G> w;
   w.init(tid);
   const bool vec_ok = (W & 3) == 0;
   R2L_PRAGMA_UNROLL
   for (int it = 0; it < R2LPrefetch<G>::NIT; ++it) {
+    if (only >= 0 && it != only) {
+      w.next();
+      continue;
+    }
     r2l_f2 v;
     v.x = v.y = 0.f;
     if (w.fy < G::FH) {
@@ -251,15 +297,16 @@ R2L_HD void r2l_fetch_frame_u16(int tid, const unsigned short* gb, int oy, int o
 }
 // raw frame of tile t -> prefetch registers (either container type)
 template <class G, bool U16>
-R2L_HD void r2l_fetch_raw_tile(int tid, const R2LRaw& raw, const R2LTile& t, int H, int W, R2LPrefetch<G>& pf) {
+R2L_HD void r2l_fetch_raw_tile(int tid, const R2LRaw& raw, const R2LTile& t, int H, int W, R2LPrefetch<G>& pf,
+                               int only = -1) {
   if (U16) {
     const unsigned short* base = raw.u16 + (size_t)t.b * H * W;
     if (t.border)
-      r2l_fetch_frame_u16<G, true>(tid, base, t.oy, t.ox, H, W, pf);
+      r2l_fetch_frame_u16<G, true>(tid, base, t.oy, t.ox, H, W, pf, only);
     else
-      r2l_fetch_frame_u16<G, false>(tid, base, t.oy, t.ox, H, W, pf);
+      r2l_fetch_frame_u16<G, false>(tid, base, t.oy, t.ox, H, W, pf, only);
   } else {
-    r2l_fetch_tile<G, 0>(tid, raw.f32, t, H, W, pf);
+    r2l_fetch_tile<G, 0>(tid, raw.f32, t, H, W, pf, only);
   }
 }
 
@@ -540,13 +587,30 @@ R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* ld
   if (lu[0] + 1 != (unsigned)gsize) return false;
   R2L_PHASE_BEGIN
   if (tid == 0) tr.counters[1 + g] = 0;
-  for (int idx = tid; idx < NSLOTS * gsize; idx += NT) {
-    const int sl = idx / gsize, m = idx - sl * gsize;
+  // the coherent loads of a lane are issued as one batch (all in flight together) and parked in LDS afterwards: as
+  // `sf[idx] = load(...)` in a plain loop each of them was a round trip of its own, five in a row for kernel B2's 155
+  // slots -- on the critical path of the launch's last workgroup
+  {
+    constexpr int NB1 = (NSLOTS * R2L_TREE_GROUP + NT - 1) / NT;
+    float v1[NB1];
     const int n1 = tr.nblk1 > 0 ? tr.nblk1 : nblk;
-    if (sl < tr.split)
-      sf[idx] = (g0 + m < n1) ? r2l_load_coherent(tr.partial + (size_t)sl * n1 + g0 + m) : 0.f;
-    else
-      sf[idx] = r2l_load_coherent(tr.partial2 + (size_t)(sl - tr.split) * nblk + g0 + m);
+    R2L_PRAGMA_UNROLL
+    for (int it = 0; it < NB1; ++it) {
+      const int idx = tid + it * NT;
+      v1[it] = 0.f;
+      if (idx < NSLOTS * gsize) {
+        const int sl = idx / gsize, m = idx - sl * gsize;
+        if (sl < tr.split)
+          v1[it] = (g0 + m < n1) ? r2l_load_coherent(tr.partial + (size_t)sl * n1 + g0 + m) : 0.f;
+        else
+          v1[it] = r2l_load_coherent(tr.partial2 + (size_t)(sl - tr.split) * nblk + g0 + m);
+      }
+    }
+    R2L_PRAGMA_UNROLL
+    for (int it = 0; it < NB1; ++it) {
+      const int idx = tid + it * NT;
+      if (idx < NSLOTS * gsize) sf[idx] = v1[it];
+    }
   }
   R2L_PHASE_END
   R2L_PHASE_BEGIN
@@ -566,9 +630,22 @@ R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* ld
     const int cnt = (NSLOTS - s0 < chunk) ? NSLOTS - s0 : chunk;
     R2L_PHASE_BEGIN
     if (tid == 0) tr.counters[0] = 0;
-    for (int idx = tid; idx < cnt * ngroups; idx += NT) {
-      const int sl = idx / ngroups, q = idx - sl * ngroups;
-      scratch[idx] = r2l_load_coherent(tr.gpartial + (size_t)(s0 + sl) * R2L_MAX_GROUPS + q);
+    for (int base = 0; base < cnt * ngroups; base += 8 * NT) {  // batches of 8 loads in flight per lane (see above)
+      double v2[8];
+      R2L_PRAGMA_UNROLL
+      for (int it = 0; it < 8; ++it) {
+        const int idx = base + tid + it * NT;
+        v2[it] = 0.0;
+        if (idx < cnt * ngroups) {
+          const int sl = idx / ngroups, q = idx - sl * ngroups;
+          v2[it] = r2l_load_coherent(tr.gpartial + (size_t)(s0 + sl) * R2L_MAX_GROUPS + q);
+        }
+      }
+      R2L_PRAGMA_UNROLL
+      for (int it = 0; it < 8; ++it) {
+        const int idx = base + tid + it * NT;
+        if (idx < cnt * ngroups) scratch[idx] = v2[it];
+      }
     }
     R2L_PHASE_END
     R2L_PHASE_BEGIN
@@ -584,7 +661,7 @@ R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* ld
 
 // sums (float64 in LDS) -> the 132 parameter gradients; tg (R2L_UNFOLD_TG doubles) and pl (R2L_P_COUNT floats)
 // are LDS
-#define R2L_UNFOLD_TG 126
+#define R2L_UNFOLD_TG (126 + 12)  // T[9], gT[9], folded A[3][4][9], black-level partial sums [site][k]
 // (every phase walks its work items with a stride of NT threads, so workgroups smaller than R2L_NT can run it too)
 template <int NT = R2L_NT>
 R2L_BLOCKFN void r2l_unfold_phases(const float* params, const double* sums, double* tg, float* pl,
@@ -603,6 +680,11 @@ R2L_BLOCKFN void r2l_unfold_phases(const float* params, const double* sums, doub
       tg[18 + e] = r2l_fold_A_one(pl, e / 36, (e % 36) / 9, e % 9);
     }
   }
+  R2L_PHASE_END
+  // the black-level gradient sums 108 products per site: 12 lanes take one (site, k) each (36 candidates, fixed order)
+  // instead of 4 lanes walking all 108 -- this runs in the launch's last workgroup with the rest of the chip idle
+  R2L_PHASE_BEGIN
+  for (int t = tid; t < 12; t += NT) tg[126 + t] = r2l_unfold_bl_part(sums, tg, t / 3, t % 3);
   R2L_PHASE_END
   R2L_PHASE_BEGIN
   for (int t = tid; t < R2L_P_NTRAIN; t += NT) grad_params[t] = r2l_unfold_one(pl, sums, t, tg);
@@ -799,9 +881,6 @@ R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, in
         st.y = x[0][1];
         st.z = x[1][0];
         st.w = x[1][1];
-#ifdef R2L_EXP_NOSTORE
-        if (st.x == 123456.0f)
-#endif
         *(r2l_f4*)(ob + off) = st;  // (a nontemporal store here costs the apply pass 4 %)
       } else {
         R2L_PRAGMA_UNROLL
@@ -1030,6 +1109,65 @@ R2L_HD void r2l_bwd1_fetch_gout(int tid, const R2LBwd1Args& a, const R2LTile& t,
     gp.g[r][k] = r2l_load_f4_nt(gb + (unsigned)k * plane + pix0 + (unsigned)(2 * r) * (unsigned)a.W);
 }
 
+// The kept-luma frame of the NEXT tile through an LDS staging area instead of prefetch registers (hot instantiations:
+// frames that tile exactly, Y' kept by the forward): asynchronous global -> LDS copies (r2l_glds16, no destination
+// registers) issued from inside the current tile's pixel phase, one per lane behind a window row of the gradient
+// correlations, and converted to the Y' plane in the next store phase.  The staging area is a dense (FH x FW) image of
+// the frame: chunk c = it * R2L_NT + tid of the chunk walk is frame row c / (FW/4), columns 4 (c % (FW/4)) .. + 3, and
+// lands at float 4 c.  Straight-line on purpose -- no branch, no predicate: the copies sit between the window rows of
+// unrolled loops and every extra basic block there costs the register allocator dearly (89-134 spilled registers with an
+// `if` per copy, none without).  So chunks outside the image copy a clamped in-image chunk (replaced by zeros when the
+// plane is built), and the wavefronts past the end of the frame in the last round are pointed at a dump area behind it.
+// What this buys: 12 registers (kernel B1: 255 -> 245, no scratch, no spilled registers) and 2 us; what was measured on
+// the way (profiles/r03_b1_staging_modes.txt): grad_out and the raw frame staged the same way make the kernel and -- through
+// the chip's clocks -- every other kernel of the step slower, a nontemporal policy on these copies slows the forward.
+#define R2L_B1_FRAME_FLOATS (72 * 72 + 256)  // a 64 x 64 tile's frame + 1 KiB: dump area / overhang of the last round's wavefront
+#ifndef R2L_B1_GLDS
+#define R2L_B1_GLDS 1  // 0: A/B builds, the Y' frame prefetched into registers at the end of the pixel phase (round 2)
+#endif
+template <class G>
+R2L_HD void r2l_stage_frame(int tid, const float* gb, int oy, int ox, int H, int W, float* FSG, int only = -1) {
+  constexpr int NCH = G::FH * (G::FW / 4);
+  R2LChunkWalk<G> w;
+  w.init(tid);
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < R2LPrefetch<G>::NIT; ++it) {
+    if (only < 0 || only == it) {
+      int gy = oy - 4 + w.fy, gx0 = ox - 4 + 4 * w.cx;
+      gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+      gx0 = gx0 < 0 ? 0 : (gx0 > W - 4 ? W - 4 : gx0);
+      const int c = it * R2L_NT + tid;
+      // (wave-uniform: does this wavefront's first chunk exist?)
+      float* slot = (it * R2L_NT + (tid & ~63) < NCH) ? FSG + 4 * c : FSG + 4 * NCH + 4 * (tid & 63);
+      r2l_glds16(gb, 4u * ((unsigned)gy * (unsigned)W + (unsigned)gx0), slot);
+    }
+    w.next();
+  }
+}
+// staged Y' frame -> plane stored shifted by +2 columns (r2l_store_plane_s2 with the chunks read back from LDS; zero
+// outside the image)
+template <class G>
+R2L_HD void r2l_store_plane_s2_staged(int tid, float* Pl, const float* FSG, int oy, int ox, int H, int W) {
+  R2LChunkWalk<G> w;
+  w.init(tid);
+  R2L_PRAGMA_UNROLL
+  for (int it = 0; it < R2LPrefetch<G>::NIT; ++it) {
+    if (w.fy < G::FH) {
+      const r2l_f4 v = r2l_lds_f4(FSG + 4 * (it * R2L_NT + tid));
+      const int gy = oy - 4 + w.fy, gx0 = ox - 4 + 4 * w.cx;
+      const bool in = (unsigned)gy < (unsigned)H && gx0 >= 0 && gx0 + 3 < W;
+      float* d = Pl + w.fy * G::FS + 4 * w.cx + 2;
+      r2l_f2 lo, hi;
+      lo.x = in ? v.x : 0.f;
+      lo.y = in ? v.y : 0.f;
+      hi.x = in ? v.z : 0.f;
+      hi.y = in ? v.w : 0.f;
+      *(r2l_f2*)d = lo;
+      *(r2l_f2*)(d + 2) = hi;
+    }
+    w.next();
+  }
+}
 // one output row (4 pixels of this thread) of kernel B1; PY = row parity
 R2L_HD float r2l_pick(bool second, float a, float b) {
 #ifndef R2L_EMUL
@@ -1167,10 +1305,13 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
 // for every row (8 scalar-load waits per row, each a full `s_waitcnt lgkmcnt(0)` with one other wave per SIMD to
 // hide behind); stage-major, every group of weights is fetched once per two rows.  Hot instantiation only (tiles
 // inside the image, prefetched grad_out).
-template <class G, int PY, bool ADD>
-R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a, int tx, int frow0, unsigned off00,
-                           unsigned plane, const R2LGoutPre& gpre, float* gyb, const R2LBnConsts& bc,
-                           R2LBwd1Regs& regs) {
+// mid(slot): 16 slots behind the window rows of the two gradient correlations, where the block issues the next tile's
+// asynchronous copies one at a time (r2l_stage_frame).
+template <class G, int PY, bool ADD, class MID>
+R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a, int tid, int tx, int frow0,
+                           unsigned off00, unsigned plane, const R2LGoutPre& gpre, float* gyb,
+                           const R2LBnConsts& bc, R2LBwd1Regs& regs, MID&& mid R2L_SUB_ARG) {
+  R2L_SUB_BEGIN
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
   r2l_p2 ypp[2][2], u[2][2], v[2][2];
   R2L_PRAGMA_UNROLL
@@ -1187,6 +1328,7 @@ R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a
     r2l_chroma_row2<PY>(vw, F, u[r], v[r]);
   }
   R2L_SCHED_FENCE();
+  R2L_SUB(1)
   r2l_p2 gy2[2][2], gu[2][2], gv[2][2];  // d loss / d (Y'', U, V)
   r2l_p2 ggam = r2l_splat2(0.f);
   R2L_PRAGMA_UNROLL
@@ -1234,6 +1376,7 @@ R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a
     *(r2l_f4*)(gyb + off0) = st;
   }
   R2L_SCHED_FENCE();
+  R2L_SUB(2)
   regs.acc[R2L_L1_GGAM] = r2l_padd(regs.acc[R2L_L1_GGAM], ggam);
   R2L_PRAGMA_UNROLL
   for (int r = 0; r < 2; ++r) {  // d/d gaussian_blur.weight (windows read from LDS a second time, see r2l_bwd1_row)
@@ -1247,6 +1390,7 @@ R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a
       R2L_PRAGMA_UNROLL
       for (int p = 0; p < 2; ++p) sacc = r2l_pfma(gy2[r][p], r2l_mk2(yw[i][2 * p + j], yw[i][2 * p + j + 1]), sacc);
       regs.acc[R2L_L1_GBLUR + i * 5 + j] = sacc;
+      if (j == 4) mid(r * 5 + i);  // one of the next tile's loads behind every window row (10 slots here, 6 below)
     }
     R2L_SCHED_FENCE();
   }
@@ -1268,6 +1412,7 @@ R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a
       }
       regs.acc[R2L_L1_GAU + i * 3 + j] = su;
       regs.acc[R2L_L1_GAV + i * 3 + j] = sv;
+      if (j == 2) mid(10 + r * 3 + i);
     }
     regs.acc[R2L_L1_SU] = r2l_padd(regs.acc[R2L_L1_SU], r2l_padd(gu[r][0], gu[r][1]));
     regs.acc[R2L_L1_SV] = r2l_padd(regs.acc[R2L_L1_SV], r2l_padd(gv[r][0], gv[r][1]));
@@ -1275,9 +1420,9 @@ R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a
   }
 }
 
-template <class G, bool RAGGED, bool ADD, bool PRE>
+template <class G, bool RAGGED, bool ADD, bool PRE, class MID>
 R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LBwd1Args& a,
-                            const R2LTile& t, const R2LGoutPre& gp, R2LBwd1Regs& regs) {
+                            const R2LTile& t, const R2LGoutPre& gp, R2LBwd1Regs& regs, MID&& mid R2L_SUB_ARG) {
   int tx, row0, py;
   G::thread_tile(tid, tx, row0, py);
   const int gy0 = t.oy + row0, gx0 = t.ox + 4 * tx;
@@ -1297,12 +1442,14 @@ R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LB
 #ifndef R2L_B1_ROW_MAJOR
   if (!RAGGED && PRE) {
     if (py)
-      r2l_bwd1_rows2<G, 1, ADD>(V, YP, a, tx, row0 + 4, pix0, plane, gp, gyb, bc, regs);
+      r2l_bwd1_rows2<G, 1, ADD>(V, YP, a, tid, tx, row0 + 4, pix0, plane, gp, gyb, bc, regs, mid R2L_SUB_PASS_FWD);
     else
-      r2l_bwd1_rows2<G, 0, ADD>(V, YP, a, tx, row0 + 4, pix0, plane, gp, gyb, bc, regs);
+      r2l_bwd1_rows2<G, 0, ADD>(V, YP, a, tid, tx, row0 + 4, pix0, plane, gp, gyb, bc, regs, mid R2L_SUB_PASS_FWD);
     return;
   }
 #endif
+  R2L_PRAGMA_UNROLL
+  for (int sl = 0; sl < 16; ++sl) mid(sl);
   R2L_PRAGMA_NOUNROLL
   for (int rr = 0; rr < 4; rr += 2) {
     if (RAGGED && gy0 + rr >= a.H) break;
@@ -1329,6 +1476,11 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   R2L_TREG_DECL(R2LPrefetch<G>, pre);
   R2L_TREG_DECL(R2LPrefetch<G>, pre_yp);
   R2L_TREG_DECL(R2LGoutPre, gpre);
+  // hot instantiations: the next tile's Y' frame travels through an LDS staging area behind the three planes
+  // (r2l_stage_frame; these kernels are launched with R2L_B1_FRAME_FLOATS more LDS)
+  constexpr bool GLDS = SAVED && !MAYBE_RAGGED && !ADD && (R2L_B1_GLDS != 0);
+  static_assert(!GLDS || G::FH * G::FW + 256 == R2L_B1_FRAME_FLOATS, "staging area of a frame");
+  float* YS = GLDS ? YP + G::PLANE + G::PAD : nullptr;
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t, tn;
   bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
@@ -1340,16 +1492,24 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
   }
   if (have) r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
-  if (SAVED && have) r2l_fetch_tile<G, 1>(tid, a.yp, t, a.H, a.W, R2L_TREG(pre_yp));
+  if (SAVED && !GLDS && have) r2l_fetch_tile<G, 1>(tid, a.yp, t, a.H, a.W, R2L_TREG(pre_yp));
+  if (GLDS && have) {
+    r2l_stage_frame<G>(tid, a.yp + (size_t)t.b * a.H * a.W, t.oy, t.ox, a.H, a.W, YS);
+    r2l_glds_wait();  // this wave's copies have landed; behind the phase barrier every wave's have
+  }
   R2L_PHASE_END
   R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre), a.raw);
-    if (SAVED) r2l_store_plane_s2<G>(tid, YP, R2L_TREG(pre_yp));
+    if (GLDS)
+      r2l_store_plane_s2_staged<G>(tid, YP, YS, t.oy, t.ox, a.H, a.W);
+    else if (SAVED)
+      r2l_store_plane_s2<G>(tid, YP, R2L_TREG(pre_yp));
     // (measured: the grad_out loads issued here, 119 us; a tile ahead at the head of the pixel phase, where 18 loads
     // per lane then queue up in the texture-address path, 133 us; a tile ahead behind the pixel arithmetic, 124 us;
-    // a tile ahead from this store phase, held across the pixel phase, 136 us)
+    // a tile ahead from this store phase, held across the pixel phase, 136 us; a tile ahead through an LDS staging
+    // area like the Y' frame, 115 us -- but the step as a whole slower, profiles/r03_b1_staging_modes.txt)
     if (SAVED && !MAYBE_RAGGED) {
       r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 0);
       r2l_bwd1_fetch_gout<G>(tid, a, t, R2L_TREG(gpre), 1);
@@ -1382,14 +1542,28 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     }
     R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
     if (haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
-    if (MAYBE_RAGGED && t.ragged)
-      r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD, false>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
-    else
-      r2l_bwd1_pixels<G, false, ADD, !MAYBE_RAGGED>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs));
+    if (GLDS) {
+      // the next tile's Y' frame: one copy per lane behind each of the first window rows of the blur-weight correlation
+      // (as a burst all 8 wavefronts would reach them together and queue in the texture-address path).  After the last
+      // tile the copies run once more on the tile itself: cheaper than a branch per slot.
+      const R2LTile tq = haven ? tn : t;
+      auto mid = [&](int slot) {
+        if (slot < R2LPrefetch<G>::NIT)
+          r2l_stage_frame<G>(tid, a.yp + (size_t)tq.b * a.H * a.W, tq.oy, tq.ox, a.H, a.W, YS, slot);
+      };
+      r2l_bwd1_pixels<G, false, ADD, true>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs), mid R2L_SUB_PASS);
+      r2l_glds_wait();  // this wave's copies have landed; behind the phase barrier every wave's have
+    } else {
+      auto nomid = [](int) {};
+      if (MAYBE_RAGGED && t.ragged)
+        r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD, false>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs), nomid R2L_SUB_PASS);
+      else
+        r2l_bwd1_pixels<G, false, ADD, !MAYBE_RAGGED>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs), nomid R2L_SUB_PASS);
 #ifndef R2L_EMUL
-    asm volatile("" ::: "memory");
+      asm volatile("" ::: "memory");
 #endif
-    if (SAVED && haven) r2l_fetch_tile<G, 1>(tid, a.yp, tn, a.H, a.W, R2L_TREG(pre_yp));
+      if (SAVED && haven) r2l_fetch_tile<G, 1>(tid, a.yp, tn, a.H, a.W, R2L_TREG(pre_yp));
+    }
     R2L_PHASE_END
     R2L_STAMP(4)
     t = tn;
@@ -1412,6 +1586,7 @@ struct R2LBwd2Args {
   R2LTree tree;         // in-kernel final reduction of B1's and B2's partials + unfold -> grad_params
   const float* params;  // packed parameters (for the unfold)
   float* grad_params;   // [R2L_P_NTRAIN]
+  int asym;             // r2l_walk_init: uneven tile shares for the two workgroups of a CU (0 = even)
 };
 
 enum { R2L_L2_GSHARP = 0, R2L_L2_GAY = 9, R2L_L2_SY = 27, R2L_L2_NACC = 29 };
@@ -1660,7 +1835,7 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
   R2L_TREG_DECL(R2LBwd2Regs, regs);
   R2L_TREG_DECL(R2LPrefetch<G>, pre_v);
   R2L_TREG_DECL(R2LPrefetch<G>, pre_g);
-  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
+  R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk, a.asym);
   R2LTile t, tn;
   bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
   R2L_PHASE_BEGIN

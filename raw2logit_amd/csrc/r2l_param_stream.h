@@ -135,38 +135,12 @@ R2L_HD void r2l_fs_stencil_parity(const float* r0, const float* r1, const float*
   }
 }
 
-#ifdef R2L_FS_CONSTW  // timing experiment only: every weight a compile-time constant (no scalar loads), wrong results
-constexpr R2LFolded r2l_fs_make_fake() {
-  R2LFolded f{};
-  int n = 0;
-  auto v = [&n]() { n += 1; return 0.01f * (float)(n % 37 + 1); };
-  for (int i = 0; i < 4; ++i) f.bl[i] = v();
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 9; ++j) { f.AY[i][j] = v(); f.AU[i][j] = v(); f.AV[i][j] = v(); }
-  for (int i = 0; i < 9; ++i) { f.sharp[i] = v(); f.M2[i] = v(); }
-  for (int i = 0; i < 25; ++i) f.blur[i] = v();
-  f.inv_gamma = 0.45f;
-  f.gamma = 2.2f;
-  for (int i = 0; i < 2; ++i) for (int j = 0; j < 9; ++j) for (int k = 0; k < 2; ++k) { f.AY2[i][j][k] = v(); f.AU2[i][j][k] = v(); f.AV2[i][j][k] = v(); }
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 25; ++j) f.blur_edge[i][j] = v();
-  return f;
-}
-static constexpr R2LFolded r2l_fs_fake_folded = r2l_fs_make_fake();
-#endif
 template <int NW, bool U16, int K>
 R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0, int y1, bool le, bool re,
                         int wave, int lane, float* ex, r2l_f4* fifo, float* ob, float* ypb, unsigned plane, int x0,
                         bool store_ok, const float mean[3], const float istd[3]) {
-#ifdef R2L_FS_CONSTW
-  const R2LFolded& F = r2l_fs_fake_folded;
-  const R2LFolded& Fh = r2l_fs_fake_folded;
-#else
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
-#ifndef R2L_FS_NO_HOIST_BLUR
   R2LFoldedRef Fh = R2L_FOLDED_REF(a.F);  // not laundered: the 25 blur weights stay in scalar registers (-1 %)
-#else
-  R2LFoldedRef Fh = F;
-#endif
-#endif
   constexpr int PY = K & 1;
   const int H = a.H;
   const float* vu = st.v[(K + 2) % 3];  // V(q-1)
@@ -187,11 +161,7 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
   // ---- strip edges: Y(q) (1 column each side) and Y'(q-2) (2 columns each side) ------------------------------
   float* ypq2 = st.yp[(K + 4) % 6];  // Y'(q-2): own columns in [2..5], neighbours still missing
   float rl_y = 0.f, rl_p2 = 0.f, rl_p3 = 0.f, rr_y = 0.f, rr_p0 = 0.f, rr_p1 = 0.f;
-#ifdef R2L_FS_NOEXCHANGE  // timing experiment only: wrong results at the strip edges
-  constexpr bool EXCH = false;
-#else
   constexpr bool EXCH = NW > 1;
-#endif
   if (EXCH) {
     float* mine = ex + ((q & 1) * NW + wave) * R2L_FS_EX;
     if (lane == 0) {
@@ -288,12 +258,8 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
       for (int j = 0; j < 8; ++j) yw[i][j] = st.yp[(K + i) % 6][j];
       // the first / last two image rows take the weight sets with the mirror padding folded in
       const int set = (y < 2) ? y : (y - (H - 2)) + 2;
-#ifdef R2L_FS_CONSTW
-      const float* w25 = (y >= 2 && y < H - 2) ? &Fh.blur[0] : &F.blur_edge[0][0] + 25 * set;
-#else
       const __attribute__((address_space(4))) float* w25 =
           (y >= 2 && y < H - 2) ? &Fh.blur[0] : &F.blur_edge[0][0] + 25 * set;
-#endif
       r2l_blur_row2w(yw, w25, ypp);
     }
     const r2l_f4* f = fifo + ((K + 2) % R2L_FS_FIFO_ROWS) * 2 * 64 + lane;  // row q-4

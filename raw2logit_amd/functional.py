@@ -114,16 +114,121 @@ PARAM_LAYOUT = (('black_level', 0, 4), ('white_balance', 4, 3), ('colour_correct
                 ('gaussian_blur.weight', 107, 25))
 
 
-def gather_ranks(vec, group=None):
+class CommTimer:
+    """wall time of every ISP collective (bench.py's `comm_us`): device events on the current stream around each
+    exchange (host clock for CPU tensors).  Off unless a bench pass switches it on; costs one branch per collective."""
+    on = False
+    _open = []
+
+    @classmethod
+    def enable(cls, on):
+        cls.on = bool(on)
+        cls._open = []
+
+    @classmethod
+    def begin(cls, name, t):
+        if not cls.on:
+            return None
+        if t.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            return (name, e0, e1)
+        import time
+        return (name, time.perf_counter(), None)
+
+    @classmethod
+    def end(cls, tok):
+        if tok is None:
+            return
+        name, e0, e1 = tok
+        if e1 is None:
+            import time
+            cls._open.append((name, 1e6 * (time.perf_counter() - e0)))
+        else:
+            e1.record()
+            cls._open.append((name, e0, e1))
+
+    @classmethod
+    def report(cls):
+        """{name: {'calls': n, 'avg_us': t}} of everything recorded since enable(True)"""
+        acc = {}
+        for rec in cls._open:
+            if len(rec) == 3:
+                rec[2].synchronize()
+                us = 1e3 * rec[1].elapsed_time(rec[2])
+            else:
+                us = rec[1]
+            a = acc.setdefault(rec[0], [0, 0.0])
+            a[0] += 1
+            a[1] += us
+        cls._open = []
+        return {k: {'calls': n, 'avg_us': round(t / n, 1)} for k, (n, t) in acc.items()}
+
+
+def _host_staged(group, t):
+    """gloo moves host memory: device tensors of a gloo group (several ranks sharing one GPU -- the functional
+    multi-rank check on a one-GPU box) cross through a host copy.  RCCL ("nccl") takes device pointers as they are."""
+    return t.is_cuda and 'gloo' in str(dist.get_backend(group))
+
+
+def gather_ranks(vec, group=None, what='gather'):
     """this rank's small float64 vector -> (all ranks' vectors, rank-major in one flat tensor, nranks), over
     RCCL/xGMI.  The kernels that consume it add the rows in rank order, so every rank computes bit-identical
     results, equal to the single-GPU result for the global batch."""
     n = _group_size(group)
     if n == 1:
         return vec, 1
-    out = torch.empty(n * vec.numel(), dtype=vec.dtype, device=vec.device)   # rank-major, flat (gloo wants 1-D)
-    dist.all_gather_into_tensor(out, vec, group=group)
+    tok = CommTimer.begin(what, vec)
+    if _host_staged(group, vec):
+        h = vec.cpu()
+        oh = torch.empty(n * h.numel(), dtype=h.dtype)
+        dist.all_gather_into_tensor(oh, h, group=group)
+        out = oh.to(vec.device)
+    else:
+        out = torch.empty(n * vec.numel(), dtype=vec.dtype, device=vec.device)   # rank-major, flat (gloo wants 1-D)
+        dist.all_gather_into_tensor(out, vec, group=group)
+    CommTimer.end(tok)
     return out, n
+
+
+class GradAllReduce:
+    """data-parallel sum of the ISP's parameter gradients (132 floats; + 196 608 with an additive layer): ONE flat
+    all-reduce, issued asynchronously right after backward -- nothing needs the result before the optimiser (or the
+    next forward), so it overlaps with whatever the caller does in between (the task model's own DDP buckets).
+
+        h = GradAllReduce(params, group)     # after loss.backward()
+        ...
+        h.wait()                             # before optimiser.step(): p.grad now holds the sum over ranks
+    `average=True` divides by the number of ranks (DistributedDataParallel's convention)."""
+
+    def __init__(self, params, group=None, average=False):
+        self.params = [p for p in params if p.grad is not None]
+        self.n = _group_size(group)
+        self.work = self.flat = self.host = None
+        self.average = average
+        if self.n == 1 or not self.params:
+            return
+        self.tok = CommTimer.begin('grad all-reduce', self.params[0].grad)
+        self.flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+        if _host_staged(group, self.flat):
+            self.host = self.flat.cpu()
+            self.work = dist.all_reduce(self.host, group=group, async_op=True)
+        else:
+            self.work = dist.all_reduce(self.flat, group=group, async_op=True)
+
+    def wait(self):
+        if self.work is None:
+            return
+        self.work.wait()
+        if self.host is not None:
+            self.flat.copy_(self.host)
+        if self.average:
+            self.flat /= self.n
+        torch._foreach_copy_([p.grad for p in self.params],
+                             [c.view_as(p.grad) for c, p in
+                              zip(self.flat.split([p.numel() for p in self.params]), self.params)])
+        CommTimer.end(self.tok)
+        self.work = None
 
 
 def _bn_buffers(bn_module, dev):
@@ -152,7 +257,7 @@ def bn_finalize(lib, stream, stats, nranks, bn_module, eps, momentum):
 
 def bn_bwd_means(lib, stream, sums, moments, group):
     """several ranks: the BatchNorm backward sums cross ranks (all-gather, added in rank order in the kernel)"""
-    gathered, n = gather_ranks(sums, group)
+    gathered, n = gather_ranks(sums, group, 'bn-bwd sums all-gather')
     bn_bwd = torch.empty(6, dtype=torch.float32, device=sums.device)
     lib.check(lib.r2l_bn_bwd_means(ptr(gathered), n, ptr(moments[6:]), ptr(bn_bwd), stream), 'r2l_bn_bwd_means')
     return bn_bwd
@@ -186,12 +291,12 @@ class _IspFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, bl, wb, ccm, gamma, deb, sharp, blur, m1, m2, additive, bn_mode, bn_module, eps,
-                momentum, group, bits=16):
+                momentum, group, bits=16, grad_mode=True):
         raw, denom = _raw_arg(raw, bits)
         params = (bl, wb, ccm, gamma, deb, sharp, blur, m1, m2)
         sizes = (4, 3, 9, 1, 81, 9, 25, 9, 9)
         table = (ctypes.c_void_p * 9)()
-        keep = []
+        alive = []          # contiguous copies of strided parameters: referenced until the launches are enqueued
         f32, rdev = torch.float32, raw.device
         for i in range(9):
             p = params[i]
@@ -201,7 +306,7 @@ class _IspFused(torch.autograd.Function):
                                 f'like the reference; .double() / .half() modules are not supported')
             if not p.is_contiguous():
                 p = p.detach().contiguous()
-                keep.append(p)
+                alive.append(p)
             table[i] = p.data_ptr()
         B, H, W = raw.shape
         lib, stream = _lib.library_for(raw)
@@ -224,7 +329,8 @@ class _IspFused(torch.autograd.Function):
         nranks = _group_size(group) if bn_mode == BN_TRAIN else 1
         mom = float(momentum) if momentum is not None else -1.0
         # a backward will follow: the forward keeps the sharpened luma plane for its first gradient kernel
-        keep = _STEP_KEEP_LUMA if any(ctx.needs_input_grad[1:8]) else 0
+        # (needs_input_grad is also set under torch.no_grad(); grad_mode is the caller's torch.is_grad_enabled())
+        keep = _STEP_KEEP_LUMA if (grad_mode and any(ctx.needs_input_grad[1:8])) else 0
 
         def call(phase, gathered):
             lib.check(lib.r2l_isp_step_fwd(ptr(raw), int(denom is not None), denom or 1.0, table, ptr(additive),
@@ -235,8 +341,10 @@ class _IspFused(torch.autograd.Function):
             call(_STEP_ALL, None)
         else:
             call(_STEP_A, None)
-            gathered, _ = gather_ranks(ws[off_stats:off_stats + 56].view(torch.float64), group)
+            gathered, _ = gather_ranks(ws[off_stats:off_stats + 56].view(torch.float64), group,
+                                       'bn statistics all-gather')
             call(_STEP_B, gathered)
+        del alive
         ctx.bn_mode = bn_mode
         ctx.keep = keep
         ctx.group = group
@@ -275,14 +383,15 @@ class _IspFused(torch.autograd.Function):
                 call(_STEP_ALL, None)
             else:
                 call(_STEP_A, None)
-                gathered, _ = gather_ranks(ws[ctx.off_sums:ctx.off_sums + 48].view(torch.float64), ctx.group)
+                gathered, _ = gather_ranks(ws[ctx.off_sums:ctx.off_sums + 48].view(torch.float64), ctx.group,
+                                           'bn-bwd sums all-gather')
                 call(_STEP_B, gathered)
         grads = [None] * 7
         if need_p:
             for i, ((_, off, n), shape) in enumerate(zip(PARAM_LAYOUT, ctx.shapes)):
                 if ctx.needs_input_grad[1 + i]:
                     grads[i] = gp[off:off + n].view(shape)
-        return (None, *grads, None, None, gadd, None, None, None, None, None, None)
+        return (None, *grads, None, None, gadd, None, None, None, None, None, None, None)
 
 
 def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
@@ -292,7 +401,8 @@ def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
                            module.gamma_correct, module.debayer.weight, module.sharpening_filter.weight,
                            module.gaussian_blur.weight, module.M_RGB_2_YUV, module.M_YUV_2_RGB,
                            module.additive_layer, bn_mode, bn, bn.eps if bn is not None else 1e-5,
-                           bn.momentum if bn is not None else None, group, getattr(module, 'raw_bits', 16))
+                           bn.momentum if bn is not None else None, group, getattr(module, 'raw_bits', 16),
+                           torch.is_grad_enabled())
 
 
 # --------------------------------------------------------------------------------------------------

@@ -39,6 +39,8 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
         raise NotImplementedError('only median_kernel_size=3 (the reference default) is built')
     if (sharp_radius != 1.0 or sharp_amount != 1.0) and sharpening == 'unsharp_masking':
         raise NotImplementedError('only sharp_radius=1.0, sharp_amount=1.0 (the reference defaults) are built')
+    if fft_fraction != 0.3 and denoising == 'fft_denoising':
+        raise NotImplementedError('only fft_fraction=0.3 (the reference default) is built')
     if not (isinstance(img, np.ndarray) and img.dtype in (np.float32, np.float64)):
         raise TypeError('processing() takes a float32 or float64 ndarray (dataset.py:86-87 delivers float32)')
     raw = torch.from_numpy(np.ascontiguousarray(img))[None].to(_device())

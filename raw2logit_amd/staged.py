@@ -204,7 +204,7 @@ class _BatchNorm(torch.autograd.Function):
             _, sm = _point(lib, s, 7, x, x=x, out=False, sums=True)
             stats = torch.cat([sm.to(torch.float64),
                                torch.full((1,), float(B * H * W), dtype=torch.float64, device=dev)])
-            gathered, nranks = gather_ranks(stats, group)
+            gathered, nranks = gather_ranks(stats, group, 'bn statistics all-gather')
             bn, moments = bn_finalize(lib, s, gathered, nranks, bn_module, bn_module.eps, bn_module.momentum)
             ctx.moments = moments
         else:

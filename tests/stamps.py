@@ -47,13 +47,21 @@ for k, kn in enumerate(['fwd', 'bwd1', 'bwd2']):
         continue
     d = d[:nb]
     rt = d[:, 7].mean().item()          # s_memrealtime ticks (100 MHz) over the same span
-    d = d[:, :7]
+    d = d[:, :7].clone()
+    sub = None
+    if kn == 'bwd1' and KEEP:            # slots 1, 2 are stages INSIDE the pixel phase (slot 4) of the kept-luma kernel
+        sub = d[:, 1:3].clone()
+        d[:, 1:3] = 0
     tot = d.sum(1).mean().item()
     print(f'{kn}: {nb} workgroups, mean total {tot:,.0f} cycles over {rt/100:.1f} us: in-kernel clock {tot/rt*0.1:.2f} GHz')
     tt = d.sum(1)
     print(f'   per-workgroup total: min {tt.min().item():,.0f}  median {tt.median().item():,.0f}  p90 {tt.quantile(0.9).item():,.0f}  max {tt.max().item():,.0f}')
     for i, nm in enumerate(names[k]):
         print(f'   {nm:8s} mean {d[:, i].mean().item():10,.0f}  ({100*d[:, i].mean().item()/tot:4.1f} %)  max {d[:, i].max().item():10,.0f}')
+    if sub is not None:
+        a, b, c = sub[:, 0].mean().item(), sub[:, 1].mean().item(), (d[:, 4] - sub.sum(1)).mean().item()
+        print(f'   inside pixels: blur+chroma {a:,.0f}   grad_out + pointwise + next-tile loads {b:,.0f}   '
+              f'gradient correlations {c:,.0f}')
 if os.environ.get('R2L_STAMPS_DETAIL'):
     for k, kn in enumerate(['fwd', 'bwd1', 'bwd2']):
         d = dbg[k][:512, :7].sum(1)

@@ -83,3 +83,31 @@ def test_weak_augmentation(emulation):
 
 def test_error_behaviour(emulation):
     pc.check_error_behaviour('cpu')
+
+
+def test_tile_walk_covers_every_tile_once(emulation):
+    """the persistent kernels' tile walk (r2l_walk_init / r2l_walk_next), even shares and the uneven shares kernel B2 uses
+    when two workgroups share a CU (every asym-th round is served by the older half of the workgroups only): every
+    tile exactly once, whatever the grid; with asym = 4 on BASELINE config 2's shape the older workgroups take 9 tiles and
+    the younger ones 7"""
+    import ctypes
+    import numpy as np
+    lib = emulation.cdll
+    lib.r2l_test_walk.restype = ctypes.c_int
+    for (B, H, W) in ((64, 512, 512), (3, 200, 520), (1, 64, 64), (16, 1024, 1024), (128, 256, 256), (5, 70, 70)):
+        ntiles = B * ((H + 63) // 64) * ((W + 63) // 64)
+        for nblk in (512, 256, 24, 8, 7, 1):
+            for asym in (0, 2, 3, 4, 5):
+                owner = np.empty(ntiles, dtype=np.int32)
+                visits = np.empty(ntiles, dtype=np.int32)
+                most = lib.r2l_test_walk(B, H, W, nblk, asym, owner.ctypes.data_as(ctypes.c_void_p),
+                                         visits.ctypes.data_as(ctypes.c_void_p))
+                assert np.all(visits == 1), (B, H, W, nblk, asym, int((visits != 1).sum()))
+                assert owner.min() >= 0 and owner.max() < nblk
+                if (B, H, W, nblk) == (64, 512, 512, 512):
+                    counts = np.bincount(owner, minlength=nblk)
+                    if asym == 0:
+                        assert counts.min() == counts.max() == 8
+                    if asym == 4:
+                        assert set(counts[:256]) == {9} and set(counts[256:]) == {7}, (counts[:4], counts[-4:])
+                    assert most == counts.max()

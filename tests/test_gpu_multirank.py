@@ -1,0 +1,194 @@
+"""The N > 1 device path on real hardware.
+
+Two FRESH processes join a gloo group, share cuda:0 and take half of each batch through ParametrizedProcessing
+(tests/multirank_worker.py: fused and staged path, BatchNorm in train mode, float32 frames and 16-bit containers,
+frames 1 / 2 / 4 wavefronts wide for the row-streaming forward, a ragged width for the tile kernels, BASELINE
+config 5's per-GPU shard).  What must hold:
+
+  * the halves concatenated equal the single-process run of the whole batch on the same GPU (<= 2e-5 x max istd:
+    only the summation order of the statistics differs),
+  * the all-reduced gradient is bit-identical on both ranks and equals the single-process gradient to 2e-4 of its
+    scale (3e-3 on the staged path, whose reductions run per stage),
+  * running statistics and num_batches_tracked equal the single-process module's on every rank,
+  * a 2-frame slice equals the float64 oracle evaluated with the global batch's statistics.
+
+The reference has nothing to match here (train.py:361-368 hard-codes gpus=1): synchronised statistics are this
+library's way of reproducing ITS numbers at a global batch size, so the single-process run is the yardstick.
+With two GPUs the same test also runs over RCCL, one rank per GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import parity_checks as pc
+from oracle import isp_oracle as orc
+import multirank_worker as mw
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(world, out_dir, backend, cases=None, timeout=900):
+    env = dict(os.environ, R2L_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    if cases:
+        env['R2L_MULTIRANK_CASES'] = ','.join(cases)
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', 'multirank_worker.py'), str(r), str(world),
+                               str(port), out_dir], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f'rank {r} failed:\n{outs[r][-3000:]}'
+    return [np.load(os.path.join(out_dir, f'rank{r}.npz')) for r in range(world)]
+
+
+def _single_process(case, dev):
+    """the whole batch in this process on the same GPU: the yardstick"""
+    name, shape, frames, path, camera = case
+    raw_np, cot_np = mw.case_inputs(name, shape, frames)
+    m = mw.make_module(path, camera, dev)
+    raw, cot = torch.from_numpy(raw_np).to(dev), torch.from_numpy(cot_np).to(dev)
+    y = m(raw)
+    y.backward(cot)
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    for p in m.parameters():
+        p.grad = None
+    m(raw)
+    return m, y.detach().cpu().numpy(), g, raw_np, cot_np
+
+
+def _check(ranks, dev, tag):
+    world = len(ranks)
+    for case in mw.CASES:
+        name, shape, frames, path, camera = case
+        if f'{name}/y' not in ranks[0]:
+            continue
+        m, y, g, raw_np, cot_np = _single_process(case, dev)
+        y_sh = np.concatenate([r[f'{name}/y'] for r in ranks])
+        raw32 = raw_np if frames == 'f32' else (raw_np.view(np.uint16).astype(np.float32) / np.float32(4095))
+        # 1 / std of the batch (BatchNorm multiplies every round-off by it): from the module's first running_var update,
+        # running_var_1 = 0.9 + 0.1 * unbiased var; after two updates on the same batch 0.81 + 0.19 * unbiased var
+        var = (m.batch_norm.running_var.double().cpu().numpy() - 0.81) / 0.19
+        istd = float(1.0 / np.sqrt(max(var.min(), 0.0) + 1e-5))
+        e = np.abs(y_sh - y).max()
+        lim = 2e-5 * max(istd, 1.0)
+        pc.report(f'multirank[{tag}]/{name}: shards vs single process, out', e, lim)
+        assert e <= lim, (name, e, lim)
+        for r in range(1, world):
+            assert np.array_equal(ranks[0][f'{name}/g'], ranks[r][f'{name}/g']), (name, 'gradient differs between ranks')
+        rel = 3e-3 if path == 'staged' else 2e-4
+        scale = np.abs(g).max() + 1e-6
+        eg = np.abs(ranks[0][f'{name}/g'] - g).max()
+        pc.report(f'multirank[{tag}]/{name}: all-reduced gradient vs single process', eg, rel * scale)
+        assert eg <= rel * scale, (name, eg, rel * scale)
+        # the local gradients really are partial: their sum is the all-reduced one
+        gl = sum(r[f'{name}/g_local'].astype(np.float64) for r in ranks)
+        assert np.abs(gl - ranks[0][f'{name}/g']).max() <= 1e-5 * scale
+        for r in ranks:
+            np.testing.assert_allclose(r[f'{name}/rm'], m.batch_norm.running_mean.cpu().numpy(), rtol=2e-6, atol=1e-7)
+            np.testing.assert_allclose(r[f'{name}/rv'], m.batch_norm.running_var.cpu().numpy(), rtol=2e-6, atol=1e-7)
+            assert int(r[f'{name}/nbt']) == int(m.batch_norm.num_batches_tracked) == 2
+            assert bool(r[f'{name}/y2_equal'])
+        if shape[0] <= 8:
+            # the whole (small) batch against the float64 oracle with global statistics
+            P = mw.case_params(camera)
+            o64, _, c64 = orc.parametrized_forward(raw32, P.astype(np.float64),
+                                                   bn=dict(training=True, running_mean=np.zeros(3),
+                                                           running_var=np.ones(3)))
+            tol = pc.out_tolerance(c64, True, base=2e-5 if camera == 'microscopy' else 1e-5)
+            err = np.abs(y_sh - o64)
+            w = np.unravel_index((err / tol).argmax(), err.shape)
+            pc.report(f'multirank[{tag}]/{name}: shards vs float64 oracle (global statistics)', err[w], tol[w])
+            assert np.all(err <= tol), (name, err.max(), w)
+            # float32 conditioning of this case: how far the SAME algorithm in float32 (the oracle run in float32, i.e.
+            # what the reference's own arithmetic does) lands from its float64 run
+            _, _, c32 = orc.parametrized_forward(raw32, P.astype(np.float32),
+                                                 bn=dict(training=True, running_mean=np.zeros(3), running_var=np.ones(3)))
+            g32, _, _ = orc.parametrized_backward(P.astype(np.float32), c32, cot_np)
+            go, _, _ = orc.parametrized_backward(P.astype(np.float64), c64, cot_np)
+            lo, _, _ = orc.parametrized_backward(P.astype(np.float64), c64, cot_np, clip_shift=1e-6)
+            hi, _, _ = orc.parametrized_backward(P.astype(np.float64), c64, cot_np, clip_shift=-1e-6)
+            off = 0
+            for k, p in m.named_parameters():
+                n = p.numel()
+                og = np.asarray(go[k]).reshape(-1)
+                flip = max(np.abs(np.asarray(lo[k]).reshape(-1) - og).max(),
+                           np.abs(np.asarray(hi[k]).reshape(-1) - og).max())
+                cond = np.abs(np.asarray(g32[k], dtype=np.float64).reshape(-1) - og).max()
+                lim = (1e-2 if camera == 'microscopy' else 1.5e-3) * (np.abs(og).max() + 1e-6) + flip + 2 * cond
+                e = np.abs(ranks[0][f'{name}/g'][off:off + n] - og).max()
+                pc.report(f'multirank[{tag}]/{name}: all-reduced grad {k} vs float64 oracle', e, lim)
+                assert e <= lim, (name, k, e, lim)
+                off += n
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from raw2logit_amd import _lib
+    assert _lib.device_library().is_device
+    return 'cuda:0'
+
+
+def test_two_gloo_ranks_share_the_gpu(dev, tmp_path):
+    ranks = _spawn(2, str(tmp_path), 'gloo')
+    _check(ranks, dev, 'gloo x2 on one GPU')
+
+
+def test_three_ranks_uneven_shards(dev, tmp_path):
+    """three ranks: shards of different sizes (4 -> 1 + 1 + 2 frames, 6 -> 2 + 2 + 2), rank-ordered sums of three"""
+    ranks = _spawn(3, str(tmp_path), 'gloo', cases=('w1_f32', 'tiles_bands_f32', 'staged_f32'))
+    _check(ranks, dev, 'gloo x3 on one GPU')
+
+
+def test_two_rccl_ranks_one_per_gpu(dev, tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    ranks = _spawn(2, str(tmp_path), 'nccl')
+    _check(ranks, dev, 'rccl x2')
+
+
+def test_bench_two_gloo_ranks_on_the_device(dev):
+    """`bench.py --gpus 2` with R2L_BENCH_BACKEND=gloo: both ranks on this GPU -- the bench's multi-rank step (phase A / B
+    calls, asynchronous gradient all-reduce, comm_us) as a FUNCTIONAL line, labelled not-a-measurement"""
+    import json
+    e = dict(os.environ, R2L_BENCH_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                        '--batch', '32', '--size', '256', '--no-cpu-baseline', '--no-static-c3'], env=e,
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out, = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{')]
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 64
+    assert 'not a measurement' in out['data']
+    comm = out['comm_us']
+    assert set(comm) == {'bn statistics all-gather', 'bn-bwd sums all-gather', 'grad all-reduce'}
+    for v in comm.values():
+        assert v['calls'] == 5 and v['avg_us'] > 0
+    out_dir = os.path.join(REPO, 'gpurun_out')
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, 'bench_gloo2_functional.json'), 'w') as f:
+            json.dump(out, f)
