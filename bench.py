@@ -100,10 +100,21 @@ def parse():
                     help='static workload: with the T.Normalize(mean, std) epilogue of train.py:157-171')
     ap.add_argument('--no-static-c3', action='store_true',
                     help='skip the static_c3 sub-records (BASELINE config 3) appended to the headline line')
+    ap.add_argument('--quick', action='store_true',
+                    help='the headline workload only: no cpu_baseline leg, no static_c3 / small_shapes sub-records (A/B runs)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay forward and backward as HIP graphs (torch.cuda.make_graphed_callables): the step costs the '
+                         'host two graph launches instead of two C-ABI calls + autograd; matters below ~8 Mpix per step, '
+                         'where the host is the bound (single GPU)')
+    ap.add_argument('--no-small-shapes', action='store_true',
+                    help="skip the small_shapes sub-records (the datasets' 256x256 tiles: BASELINE configs 4 / 5 per GPU)")
     ap.add_argument('--raw-u16', action='store_true',
                     help='feed the 12-bit frames as uint16 containers (2 B/px ingest, normalised in-kernel; '
                          'SURVEY.md section 8f) instead of float32: a separate variant, not the headline config')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.quick:
+        args.no_cpu_baseline = args.no_static_c3 = args.no_small_shapes = True
+    return args
 
 
 def cpu_baseline_parametrized(size, seconds=8.0):
@@ -311,11 +322,14 @@ def kernel_times(lib, clock, step, steps, finish=None):
     """{kernel: {launches, avg_us}} of `steps` more steps, from the library's HIP events around every launch
     (recorded on the stream the kernels are launched on)"""
     lib.r2l_timing_enable(1)
+    clock.barrier()
+    t0 = time.perf_counter()
     for _ in range(steps):
         step()
     if finish:
         finish()
     clock.barrier()
+    kernel_times.wall_ms_per_step = 1e3 * (time.perf_counter() - t0) / max(steps, 1)
     buf = ctypes.create_string_buffer(1 << 16)
     lib.r2l_timing_report(buf, len(buf))
     lib.r2l_timing_enable(0)
@@ -364,6 +378,38 @@ def static_records(torch, lib, clock, dev):
                      'Mpix_per_s': round(B * S * S / (wall_ms * 1e-3) / 1e6, 1)})
         del raw
         torch.cuda.empty_cache()
+    return recs
+
+
+def small_shape_records(torch, lib, clock, dev, cameras, ParametrizedProcessing):
+    """the step at the reference's real tile size (dataset.py:92: 256 x 256): BASELINE config 5's share per GPU
+    (64 frames) and config 4's ISP share (128 frames) -- eager (two C-ABI calls through autograd) and replayed as HIP
+    graphs, plus the kernels' own time from the HIP-event pass."""
+    recs = []
+    for B, S in ((64, 256), (128, 256)):
+        gen = torch.Generator(dev).manual_seed(0)
+        raw = torch.randint(0, 4096, (B, S, S), device=dev, generator=gen, dtype=torch.int32).to(torch.float32) / 4095.0
+        cot = torch.randn((B, 3, S, S), device=dev, generator=gen)
+        rec = {'shape': [B, S, S]}
+        for mode in ('eager', 'graph'):
+            model = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True).to(dev).train()
+            params = list(model.parameters())
+            fwd = torch.cuda.make_graphed_callables(model, (raw,)) if mode == 'graph' else model
+
+            def step():
+                for p in params:
+                    p.grad = None
+                fwd(raw).backward(cot)
+            clock.preroll(step, None, 0.05)
+            dt = clock.time_steps(step, 50, 10)
+            rec['ms_per_step' + ('_graph' if mode == 'graph' else '')] = round(1e3 * dt / 50, 4)
+            if mode == 'eager':
+                k = kernel_times(lib, clock, step, 50)
+                rec['kernels_us_per_step'] = round(sum(v['launches'] * v['avg_us'] for v in k.values()) / 50, 1)
+                rec['kernels'] = {n.replace('r2l_launch_', '').replace('_kernel', ''): v['avg_us'] for n, v in k.items()}
+        rec['Mpix_per_s_graph'] = round(B * S * S / (rec['ms_per_step_graph'] * 1e-3) / 1e6, 1)
+        recs.append(rec)
+        del raw, cot
     return recs
 
 
@@ -543,6 +589,11 @@ def main():
     if world > 1:
         model.process_group = dist.group.WORLD
     params = list(model.parameters())
+    fwd = model
+    if args.graph:
+        if world > 1:
+            raise SystemExit('bench.py: --graph is a single-GPU option (the statistics exchange splits the step calls)')
+        fwd = torch.cuda.make_graphed_callables(model, (raw,))
 
     pending = []
 
@@ -554,7 +605,7 @@ def main():
         finish()
         for p in params:
             p.grad = None
-        y = model(raw)
+        y = fwd(raw)
         y.backward(cot)
         if world > 1:                                # data-parallel sum of the 132-float ISP gradient, asynchronous
             pending.append(F_.GradAllReduce(params, dist.group.WORLD))
@@ -597,7 +648,9 @@ def main():
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                         'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
 
-    static_c3 = None
+    static_c3 = small = None
+    if world == 1 and dev.type == 'cuda' and not args.no_small_shapes:
+        small = small_shape_records(torch, lib, clock, dev, cameras, ParametrizedProcessing)
     if world == 1 and dev.type == 'cuda' and not args.no_static_c3:
         del raw, cot
         torch.cuda.empty_cache()
@@ -626,6 +679,9 @@ def main():
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(px_per_step / world * 52.0 * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
             'kernels': kernels,
+            # the kernels' HIP events sit between the launches of the instrumented pass: each event pair costs the queue
+            # ~2 us, so that pass runs slower than the timed one -- its own wall clock is the one the kernel sum must fit in
+            'instrumented_ms_per_step': round(getattr(kernel_times, 'wall_ms_per_step', 0.0), 4) if kernels else None,
             'preroll': {'steps': preroll_steps, 'seconds': PREROLL_S,
                         'why': 'untimed; brings the GPU clocks up after the host-side cpu_baseline leg, before the W warm-up '
                                'steps and the K timed steps'},
@@ -634,6 +690,10 @@ def main():
             # wall time of each ISP collective per call (device events on the launch stream around the exchange, from the
             # instrumented pass): the two small all-gathers sit inside the step, the gradient all-reduce overlaps
             out['comm_us'] = comm_us
+        if args.graph:
+            out['config']['step'] += ' (forward and backward replayed as HIP graphs)'
+        if small is not None:
+            out['small_shapes'] = small
         if static_c3 is not None:
             out['static_c3'] = static_c3
         if cpu is not None:

@@ -171,6 +171,9 @@ R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GF
 #ifndef R2L_FS_OCC
 #define R2L_FS_OCC 3
 #endif
+#ifndef R2L_FS_MINBAND
+#define R2L_FS_MINBAND 16  // rows: shortest band of the row-streaming forward (7 halo rows of luma per band)
+#endif
 #define R2L_FS_KERNEL(name, NW, U16)                                                                    \
   R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC, r2l_fwd_stream_block<NW, U16>)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w1, 1, false)
@@ -514,7 +517,8 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     const long resident = 256L * (12 / nwv);
     long nband = r2l_env_int("R2L_FS_BAND", 0) ? (H + r2l_env_int("R2L_FS_BAND", 32) - 1) / r2l_env_int("R2L_FS_BAND", 32)
                                                : resident / B;
-    if (nband > H / 16) nband = H / 16;
+    const int minband = r2l_env_int("R2L_FS_MINBAND", R2L_FS_MINBAND);
+    if (nband > H / minband) nband = H / minband;
     if (nband < 1) nband = 1;
     fa.band_h = (int)((H + nband - 1) / nband);
     fa.band_h += fa.band_h & 1;

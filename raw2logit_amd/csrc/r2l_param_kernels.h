@@ -1825,6 +1825,7 @@ R2L_HD void r2l_bwd2_pixels(int tid, const float* V, const float* Y, const float
 #ifndef R2L_B2_PREFETCH
 #define R2L_B2_PREFETCH 0
 #endif
+
 template <class G, bool U16>
 R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* lds) {
   float* V = lds + R2L_FOLDED_FLOATS + G::PAD;

@@ -62,6 +62,9 @@ R2L_HD double r2l_wave_shl1_d(double x, double edge) {
 #define R2L_CHAIN_LDS_DOUBLES(NW, SH) (2 * (NW) * R2L_CHAIN_EX + (NW) * R2L_CHAIN_FIFO_DOUBLES(SH))
 
 // per-lane state of the luma chain
+// (a float32 raw window, widened on the fly as in the short chain's Malvar2004 kernel, does not pay here: the chroma ring
+// in LDS, not the registers, keeps these kernels at two wavefronts per SIMD, and the extra conversions cost 2 %:
+// profiles/r03_static_windows.txt)
 template <int DEB, int SH, int DN>
 struct R2LChainState {
   double rw[DEB ? 6 : 3][8];  // raw rows (slot = row mod 3 / mod 6): columns x0-2 .. x0+5, black level removed
@@ -118,10 +121,10 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, SH, DN>& 
   // ---- demosaic + colour of row q: Y(q) to the window, (U, V)(q) to the LDS ring ---------------------------
   {
     double d[4][3];
-    if (DEB == 0) {
-      const double* u = st.rw[(K + 2) % 3];    // raw row q-1
-      const double* m = st.rw[K % 3];          // raw row q
-      const double* l = st.rw[(K + 1) % 3];    // raw row q+1
+    if constexpr (DEB == 0) {
+      const auto* u = st.rw[(K + 2) % 3];    // raw row q-1
+      const auto* m = st.rw[K % 3];          // raw row q
+      const auto* l = st.rw[(K + 1) % 3];    // raw row q+1
       if (q > 0 && q < H - 1) {
         r2l_stream_bilinear_row_interior<PY>(u, m, l, le, re, d);
       } else {

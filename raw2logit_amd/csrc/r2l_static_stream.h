@@ -129,21 +129,23 @@ R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, size_t img0, int ys, in
 // subtraction happens in the arithmetic of the frames' dtype, like the reference's in-place remove_blacklv
 // (pipeline_numpy.py:152-158): float32 frames (and 16-bit containers, which the datasets normalise in float32,
 // dataset.py:86-87) subtract the float32-rounded black level in float32; float64 frames subtract in float64.
-template <int RAWK, bool LANES>
+// DT = double: the window holds float64 values; DT = float (float32 / 16-bit frames only): the window keeps the float32
+// values the subtraction produced and its users widen on the fly -- the same numbers, half the registers.
+template <int RAWK, bool LANES, class DT = double>
 R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStageT<RAWK>& st, bool le, bool re,
-                                   double dst[8]) {
+                                   DT dst[8]) {
   const int ys = st.ys;
   if constexpr (RAWK == R2L_RAW_F64) {
     const double be = (ys & 1) ? a.bl[2] : a.bl[0], bo = (ys & 1) ? a.bl[3] : a.bl[1];
     // source column parities: x0-2 even, x0-1 odd, ..., except the mirrored ones (1, 0 | W-1, W-2)
-    dst[0] = st.v[0] - (le ? bo : be);
-    dst[1] = st.v[1] - (le ? be : bo);
-    dst[2] = st.v[2] - be;
-    dst[3] = st.v[3] - bo;
-    dst[4] = st.v[4] - be;
-    dst[5] = st.v[5] - bo;
-    dst[6] = st.v[6] - (re ? bo : be);
-    dst[7] = st.v[7] - (re ? be : bo);
+    dst[0] = (DT)(st.v[0] - (le ? bo : be));
+    dst[1] = (DT)(st.v[1] - (le ? be : bo));
+    dst[2] = (DT)(st.v[2] - be);
+    dst[3] = (DT)(st.v[3] - bo);
+    dst[4] = (DT)(st.v[4] - be);
+    dst[5] = (DT)(st.v[5] - bo);
+    dst[6] = (DT)(st.v[6] - (re ? bo : be));
+    dst[7] = (DT)(st.v[7] - (re ? be : bo));
   } else {
   constexpr bool U16 = RAWK == R2L_RAW_U16;
   float v[8];
@@ -185,15 +187,28 @@ R2L_HD void r2l_stream_convert_row(const R2LStaticArgs& a, const R2LRowStageT<RA
     }
   }
   const float be = (ys & 1) ? a.blf[2] : a.blf[0], bo = (ys & 1) ? a.blf[3] : a.blf[1];
-  dst[0] = (double)(v[0] - (le ? bo : be));
-  dst[1] = (double)(v[1] - (le ? be : bo));
-  dst[2] = (double)(v[2] - be);
-  dst[3] = (double)(v[3] - bo);
-  dst[4] = (double)(v[4] - be);
-  dst[5] = (double)(v[5] - bo);
-  dst[6] = (double)(v[6] - (re ? bo : be));
-  dst[7] = (double)(v[7] - (re ? be : bo));
+  dst[0] = (DT)(v[0] - (le ? bo : be));
+  dst[1] = (DT)(v[1] - (le ? be : bo));
+  dst[2] = (DT)(v[2] - be);
+  dst[3] = (DT)(v[3] - bo);
+  dst[4] = (DT)(v[4] - be);
+  dst[5] = (DT)(v[5] - bo);
+  dst[6] = (DT)(v[6] - (re ? bo : be));
+  dst[7] = (DT)(v[7] - (re ? be : bo));
   }
+}
+
+// float32 window value -> float64, re-done at every use: left alone the compiler keeps the float64 copy of every window
+// value alive across the rows that use it -- the float64 window again
+R2L_HD double r2l_widen(double x) { return x; }
+R2L_HD double r2l_widen(float x) {
+#ifndef R2L_EMUL
+  double d;
+  asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(x));  // (volatile: identical statements are not merged)
+  return d;
+#else
+  return (double)x;
+#endif
 }
 
 // WB * CCM, clip, gamma and the three 16-byte stores of one output row (4 pixels of this lane)
@@ -272,16 +287,17 @@ R2L_HD void r2l_stream_lin_out_row(const R2LStaticArgs& a, const double d[4][3],
 }
 
 // bilinear row: w0/w1/w2 = window rows y-1, y, y+1 (8 values each); tpy = their source row parities
-R2L_HD void r2l_stream_bilinear_row(const double* w0, const double* w1, const double* w2, const int tpy[3],
+template <class WT>
+R2L_HD void r2l_stream_bilinear_row(const WT* w0, const WT* w1, const WT* w2, const int tpy[3],
                                     bool le, bool re, double d[4][3]) {
   R2L_PRAGMA_UNROLL
   for (int c = 0; c < 4; ++c) {
     double n[3][3];
     R2L_PRAGMA_UNROLL
     for (int j = 0; j < 3; ++j) {
-      n[0][j] = w0[1 + c + j];
-      n[1][j] = w1[1 + c + j];
-      n[2][j] = w2[1 + c + j];
+      n[0][j] = r2l_widen(w0[1 + c + j]);
+      n[1][j] = r2l_widen(w1[1 + c + j]);
+      n[2][j] = r2l_widen(w2[1 + c + j]);
     }
     int tpx[3] = {1 - (c & 1), c & 1, 1 - (c & 1)};
     // a tap mirrored back from outside the image keeps the site of the column it came from
@@ -301,12 +317,15 @@ R2L_HD void r2l_stream_bilinear_row(const double* w0, const double* w1, const do
 // (its values are zeroed), and the taps of that column (weights [1 2 1]/4 for R/B, [0 1 0]/4 for G) add to the
 // channels the edge column itself holds: the pixel's own channel gets +1/2 (R/B) or +1/4 (G) of the pixel, and
 // the channel of the rows above / below gets +1/4 of their sum when it is R or B.
-template <int PY>
-R2L_HD void r2l_stream_bilinear_row_interior(const double* u, const double* m, const double* l, bool le, bool re,
+template <int PY, class WT>
+R2L_HD void r2l_stream_bilinear_row_interior(const WT* u, const WT* m_, const WT* l, bool le, bool re,
                                              double d[4][3]) {
-  double vs[8], hs[4];
+  double vs[8], hs[4], m[8];
   R2L_PRAGMA_UNROLL
-  for (int j = 1; j < 7; ++j) vs[j] = u[j] + l[j];
+  for (int j = 1; j < 7; ++j) {
+    vs[j] = r2l_widen(u[j]) + r2l_widen(l[j]);
+    m[j] = r2l_widen(m_[j]);
+  }
   const double fl = le ? 1.0 : 0.0, fr = re ? 1.0 : 0.0;
   const double m1 = le ? 0.0 : m[1], m6 = re ? 0.0 : m[6];
   vs[1] = le ? 0.0 : vs[1];
@@ -373,19 +392,27 @@ R2L_HD void r2l_stream_malvar_row(const double* w0, const double* w1, const doub
 // (Summation order differs from the per-pixel form by float64 round-off only.)  Used by the luma-chain kernels
 // (r2l_static_chain.h: -2..3 %); in the short chain's kernel its 20 more live registers cost the third wavefront per
 // SIMD or spill (875 -> 1070-1165 us), so that one keeps the per-pixel form above.
-template <int PY>
-R2L_HD void r2l_stream_malvar_row_shared(const double* w0, const double* w1, const double* w2, const double* w3,
-                                  const double* w4, double d[4][3]) {
+// WT = float: a float32 window (float32 / 16-bit frames), widened here -- exactly, so the results are those of the float64
+// window bit for bit.  That is what lets the short chain's kernel use this form: its 5-row float64 window alone was 80 of
+// its 167 registers.
+template <int PY, class WT = double>
+R2L_HD void r2l_stream_malvar_row_shared(const WT* w0, const WT* w1, const WT* w2, const WT* w3,
+                                  const WT* w4, double d[4][3]) {
   double v1[8], v2[8];  // rows y-1 + y+1 (columns 1 .. 6 used), rows y-2 + y+2 (columns 2 .. 5 used)
+  double wm[8];         // the pixel's own row
+  // (r2l_widen: the conversion is re-done per output row; left alone the compiler keeps the float64 copy of every window
+  // value alive across the rows that use it -- the float64 window again)
   R2L_PRAGMA_UNROLL
-  for (int j = 1; j < 7; ++j) v1[j] = w1[j] + w3[j];
+  for (int j = 0; j < 8; ++j) wm[j] = r2l_widen(w2[j]);
   R2L_PRAGMA_UNROLL
-  for (int j = 2; j < 6; ++j) v2[j] = w0[j] + w4[j];
+  for (int j = 1; j < 7; ++j) v1[j] = r2l_widen(w1[j]) + r2l_widen(w3[j]);
+  R2L_PRAGMA_UNROLL
+  for (int j = 2; j < 6; ++j) v2[j] = r2l_widen(w0[j]) + r2l_widen(w4[j]);
   R2L_PRAGMA_UNROLL
   for (int c = 0; c < 4; ++c) {
     const int m = c + 2;  // window column of the pixel
-    const double ctr = w2[m];
-    const double h1 = w2[m - 1] + w2[m + 1], h2 = w2[m - 2] + w2[m + 2];
+    const double ctr = wm[m];
+    const double h1 = wm[m - 1] + wm[m + 1], h2 = wm[m - 2] + wm[m + 2];
     const double dg = v1[m - 1] + v1[m + 1];  // the four diagonal neighbours
     const double far = v2[m] + h2;
     if ((c & 1) == PY) {  // R site (PY 0, even column) or B site (PY 1, odd column): G and the opposite colour
@@ -404,6 +431,28 @@ R2L_HD void r2l_stream_malvar_row_shared(const double* w0, const double* w1, con
   }
 }
 
+#ifndef R2L_STREAM_MALVAR_F32WIN
+#define R2L_STREAM_MALVAR_F32WIN 1  // 0: A/B builds, float64 window + per-pixel kernels (round 2)
+#endif
+template <bool F32>
+struct R2LWinType {
+  typedef double type;
+};
+template <>
+struct R2LWinType<true> {
+  typedef float type;
+};
+// bilinear keeps its float64 window (3 rows); so does Malvar2004 on float64 frames, in the per-pixel form
+template <int PY, bool WF32>
+R2L_HD void r2l_stream_malvar_rowT(const float* w0, const float* w1, const float* w2, const float* w3, const float* w4,
+                                   double d[4][3]) {
+  r2l_stream_malvar_row_shared<PY, float>(w0, w1, w2, w3, w4, d);
+}
+template <int PY, bool WF32>
+R2L_HD void r2l_stream_malvar_rowT(const double* w0, const double* w1, const double* w2, const double* w3,
+                                   const double* w4, double d[4][3]) {
+  r2l_stream_malvar_row<PY>(w0, w1, w2, w3, w4, d);
+}
 #ifndef R2L_STREAM_PF_BILINEAR
 #define R2L_STREAM_PF_BILINEAR 5
 #endif
@@ -426,7 +475,9 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   const size_t plane = (size_t)a.H * a.W;
   const size_t img = (size_t)b * plane;  // element offset of image b
   float* outb = a.out + (size_t)b * 3 * plane;
-  double win[NR][8];
+  // Malvar2004 on float32 / 16-bit frames: a float32 window (r2l_stream_malvar_row_shared widens it)
+  constexpr bool WF32 = (DEB == 1) && RAWK != R2L_RAW_F64 && R2L_STREAM_MALVAR_F32WIN;
+  typename R2LWinType<WF32>::type win[NR][8];
   int par[NR];  // source row parity of each window slot
   // warm-up: slots 0..NR-2 hold rows y0-HALO .. y0+HALO-1
   R2LRowStageT<RAWK> st;
@@ -434,7 +485,7 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   for (int i = 0; i < NR - 1; ++i) {
     const int ys = r2l_symmetric(y0 - HALO + i, a.H);
     r2l_stream_fetch_row<RAWK, LANES>(a, img, ys, x0, le, re, st);
-    r2l_stream_convert_row<RAWK, LANES>(a, st, le, re, win[i]);
+    r2l_stream_convert_row<RAWK, LANES, typename R2LWinType<WF32>::type>(a, st, le, re, win[i]);
     par[i] = ys & 1;
   }
   // software pipeline, PF rows deep: the rows needed by the next PF output rows are in flight while this one
@@ -450,13 +501,13 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
       const int y = yb + k;
       if (y < y1) {
         // newest row y + HALO (fetched one iteration ago) goes to slot (k + NR - 1) % NR
-        r2l_stream_convert_row<RAWK, LANES>(a, pf[0], le, re, win[(k + NR - 1) % NR]);
+        r2l_stream_convert_row<RAWK, LANES, typename R2LWinType<WF32>::type>(a, pf[0], le, re, win[(k + NR - 1) % NR]);
         par[(k + NR - 1) % NR] = pf[0].ys & 1;
         R2L_PRAGMA_UNROLL
         for (int i = 0; i + 1 < PF; ++i) pf[i] = pf[i + 1];
         if (y + PF < y1) r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(y + PF + HALO, a.H), x0, le, re, pf[PF - 1]);
         double d[4][3];
-        if (DEB == 0) {
+        if constexpr (DEB == 0) {
           // interior rows: closed-form sums (left / right image edge included); the first / last image row sees
           // a mirrored row and takes the masked form
           if (y > 0 && y < a.H - 1) {
@@ -470,11 +521,11 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
           }
         } else {
           if (y & 1)
-            r2l_stream_malvar_row<1>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], win[(k + 3) % NR],
-                                     win[(k + 4) % NR], d);
+            r2l_stream_malvar_rowT<1, WF32>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], win[(k + 3) % NR],
+                                            win[(k + 4) % NR], d);
           else
-            r2l_stream_malvar_row<0>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], win[(k + 3) % NR],
-                                     win[(k + 4) % NR], d);
+            r2l_stream_malvar_rowT<0, WF32>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], win[(k + 3) % NR],
+                                            win[(k + 4) % NR], d);
         }
         if (LUMA && sa.luma_out)
           r2l_stream_luma_out_row(a, d, sa.luma_out, img + (size_t)y * a.W + x0);

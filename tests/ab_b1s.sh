@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel B1 with the kept luma plane: variants (tests/_build/ab/<name>.so, built by tests/build_ab.sh with -DR2L_TEST_HOOKS)
 cd "$(dirname "$0")/.."
-run() { python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
+run() { python bench.py --steps 30 --warmup 5 --quick 2>/dev/null | python -c "
 import sys, json
 o = json.loads(sys.stdin.readline()); k = o['kernels']
 print('%-40s ms/step %.4f ' % ('$1', o['ms_per_step']) + ' '.join('%s=%.1f' % (a.replace('r2l_launch_', '').replace('_kernel', ''), b['avg_us']) for a, b in sorted(k.items())))

@@ -3,7 +3,7 @@
 rounds=$1; shift
 for r in $(seq $rounds); do
   for n in "$@"; do
-    R2L_LIB_PATH=tests/_build/ab/$n.so python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
+    R2L_LIB_PATH=tests/_build/ab/$n.so python bench.py --steps 30 --warmup 5 --quick 2>/dev/null | python -c "
 import sys, json
 o = json.loads(sys.stdin.readline())
 k = o['kernels']

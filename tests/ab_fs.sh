@@ -2,7 +2,7 @@
 # forward-stream experiments: tests/ab_fs.sh name[:band] ...
 for spec in "$@"; do
   n=${spec%%:*}; band=${spec#*:}; [ "$band" = "$spec" ] && band=0
-  R2L_FS_BAND=$band R2L_LIB_PATH=tests/_build/ab/$n.so python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
+  R2L_FS_BAND=$band R2L_LIB_PATH=tests/_build/ab/$n.so python bench.py --steps 30 --warmup 5 --quick 2>/dev/null | python -c "
 import sys, json
 o = json.loads(sys.stdin.readline())
 k = o['kernels']

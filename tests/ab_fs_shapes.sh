@@ -3,7 +3,7 @@
 shape=$1; shift
 set -- $shape "$@"; B=$1; S=$2; shift 2
 for band in "$@"; do
-  R2L_FS_BAND=$band R2L_LIB_PATH=tests/_build/libr2l_isp_hooks.so python bench.py --batch $B --size $S --steps 40 --warmup 8 --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
+  R2L_FS_BAND=$band R2L_LIB_PATH=tests/_build/libr2l_isp_hooks.so python bench.py --batch $B --size $S --steps 40 --warmup 8 --quick 2>/dev/null | python -c "
 import sys, json
 o = json.loads(sys.stdin.readline())
 k = o['kernels']

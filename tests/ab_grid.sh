@@ -2,7 +2,7 @@
 # workgroups-per-CU experiments on the tile kernels (diagnostic build honours R2L_GRID_*)
 export R2L_LIB_PATH=tests/_build/libr2l_isp_hooks.so
 run() {
-  python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
+  python bench.py --steps 30 --warmup 5 --quick 2>/dev/null | python -c "
 import sys, json
 o = json.loads(sys.stdin.readline())
 k = o['kernels']

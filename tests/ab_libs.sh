@@ -2,7 +2,7 @@
 # A/B of device-library builds over the headline bench and the static workloads: tests/ab_libs.sh lib.so ...
 for r in 1 2; do
 for lib in "$@"; do
-  R2L_LIB_PATH=$lib python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
+  R2L_LIB_PATH=$lib python bench.py --steps 30 --warmup 5 --quick 2>/dev/null | python -c "
 import sys, json
 o = json.loads(sys.stdin.readline())
 k = o['kernels']
