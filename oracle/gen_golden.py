@@ -125,6 +125,8 @@ def gen_param_cases(ppt, out):
                 proc.batch_norm.running_mean.copy_(torch.tensor([0.4, 0.45, 0.35]))
                 proc.batch_norm.running_var.copy_(torch.tensor([0.03, 0.05, 0.04]))
         proc.train(case['training'])
+        import copy
+        proc64 = copy.deepcopy(proc)            # before the float32 run touches the running statistics
         raw = torch.from_numpy(raw_np).requires_grad_(True)
         y = proc(raw)
         rng = np.random.default_rng(1000 + case['seed'])
@@ -162,6 +164,24 @@ def gen_param_cases(ppt, out):
                 out[pre + 'bn_running_mean_2'] = bnm.running_mean.numpy().copy()
                 out[pre + 'bn_running_var_2'] = bnm.running_var.numpy().copy()
                 out[pre + 'bn_nbt_2'] = np.int64(bnm.num_batches_tracked.item())
+        # The reference itself in float64 (same module, same inputs: a deep copy made before the float32 run, converted
+        # with .double() and run under a float64 default dtype -- raw2rgb allocates with torch.zeros(), :261 / :272):
+        # |ref32 - ref64| is how far the reference's OWN float32 arithmetic is from exact, per pixel; the tests bound
+        # this library's distance from ref64 by a multiple of it.
+        torch.set_default_dtype(torch.float64)
+        try:
+            p64 = proc64.double()
+            p64.train(case['training'])
+            raw64 = torch.from_numpy(raw_np).double().requires_grad_(True)
+            y64 = p64(raw64)
+            (y64 * torch.from_numpy(cot).double()).sum().backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        assert y64.dtype == torch.float64
+        out[pre + 'out64'] = sample(y64.detach().numpy(), full)
+        for k, p in p64.named_parameters():
+            g = p.grad.numpy()
+            out[pre + 'grad64/' + k] = sample(g, full) if k == 'additive_layer' else g
         # cross-check the oracle right here so a bad restatement is caught at generation time
         bn = None
         if case['bn']:

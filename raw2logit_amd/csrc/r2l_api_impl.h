@@ -372,7 +372,7 @@ static R2LWorkspace r2l_carve(void* base, int B, int H, int W) {
   w.part_b2 = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * R2L_B2_NACC * R2L_MAX_BLOCKS);
   w.part_small = (float*)(p + off);
-  off += r2l_align_up(sizeof(float) * 8 * R2L_MAX_BLOCKS);
+  off += r2l_align_up(sizeof(float) * 12 * R2L_MAX_BLOCKS);
   w.sums = (double*)(p + off);
   off += r2l_align_up(sizeof(double) * R2L_NSUMS);
   w.gpartial = (double*)(p + off);
@@ -529,7 +529,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     long cap = r2l_env_int("R2L_GRID_FWD", (int)(resident < R2L_MAX_BLOCKS ? resident : R2L_MAX_BLOCKS));
     if (cap > R2L_MAX_BLOCKS) cap = R2L_MAX_BLOCKS;
     const int sgrid = (int)(nitems < cap ? nitems : cap);
-    fa.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6, 0};
+    fa.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 12, 0};
     fa.stats_out = stats;
     if (fin)
       fa.fin = *fin;
@@ -559,7 +559,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
   a.debug = ws.debug;
   // the statistics are reduced by the last workgroups of the same launch (the workspace's arrival counters
   // are valid: this call or an earlier one on this workspace ran the fold kernel)
-  a.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 6, 0};
+  a.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 12, 0};
   a.stats_out = stats;
   if (fin)
     a.fin = *fin;

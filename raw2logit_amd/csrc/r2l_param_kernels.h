@@ -806,7 +806,7 @@ struct R2LFwdArgs {
   const R2LFolded* F;
   const float* bn;      // mean[3], istd[3] or null
   float* out;           // (B,3,H,W) or null (stats only)
-  float* stat_partial;  // [6][nblk] or null
+  float* stat_partial;  // [12][nblk] or null: (high, low) float32 halves of the workgroups' float64 totals
   int B, H, W;
   float* debug;  // diagnostic builds
   R2LTree tree;  // in-kernel final reduction of the statistics -> stats_out[0..6), stats_out[6] = B*H*W
@@ -824,10 +824,14 @@ struct R2LFwdArgs {
 #ifndef R2L_PRIO_STENCIL
 #define R2L_PRIO_STENCIL 2
 #endif
+// BatchNorm statistics of a thread: sum (x - p), sum (x - p)^2 per channel and pair half about the thread's own pivot p
+// (the first pixel it sees), npx pixels.  Re-based to the common pivot 0.5 in float64 when the workgroup reduces
+// (r2l_fwd_stats_reduce; see R2LFsState in r2l_param_stream.h for why).
 struct R2LFwdRegs {
-  r2l_p2 acc[6];  // per pair half; the halves are added when the workgroup reduces
+  r2l_p2 acc[6];
+  float piv[3];
+  float npx;
 };
-#define R2L_ACC_FWD(regs, i) (R2L_TREG(regs).acc[i][0] + R2L_TREG(regs).acc[i][1])
 
 template <class G, int PY, bool RAGGED, bool ADD>
 R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, int tx, int frow, int gx0,
@@ -865,7 +869,8 @@ R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, in
         x[p] = r2l_padd(x[p], r2l_mk2(a0, a1));
       }
       if (a.stat_partial) {
-        r2l_p2 d = r2l_padd(x[p], r2l_splat2(-0.5f));
+        if (p == 0) regs.piv[k] = (regs.npx == 0.f) ? x[0][0] : regs.piv[k];  // (pixel 0 of an active thread is inside the image)
+        r2l_p2 d = r2l_padd(x[p], r2l_splat2(-regs.piv[k]));
         if (RAGGED) d = r2l_mk2(gx0 + 2 * p < a.W ? d[0] : 0.f, gx0 + 2 * p + 1 < a.W ? d[1] : 0.f);
         regs.acc[k] = r2l_padd(regs.acc[k], d);
         regs.acc[3 + k] = r2l_pfma(d, d, regs.acc[3 + k]);
@@ -888,6 +893,11 @@ R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, in
           if (gx0 + c < a.W) ob[off + c] = x[c >> 1][c & 1];
       }
     }
+  }
+  if (a.stat_partial) {
+    float n = 4.f;
+    if (RAGGED) n = (float)((gx0 < a.W) + (gx0 + 1 < a.W) + (gx0 + 2 < a.W) + (gx0 + 3 < a.W));
+    regs.npx += n;
   }
 }
 
@@ -981,6 +991,8 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   R2L_PHASE_BEGIN
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 6; ++i) R2L_TREG(regs).acc[i] = r2l_splat2(0.f);
+  R2L_TREG(regs).piv[0] = R2L_TREG(regs).piv[1] = R2L_TREG(regs).piv[2] = 0.5f;
+  R2L_TREG(regs).npx = 0.f;
   if (have) r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   R2L_PHASE_END
   R2L_STAMP_DECL
@@ -1022,10 +1034,44 @@ R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* ld
   }
   R2L_STAMP_FLUSH(a.debug, bid)
   if (a.stat_partial) {
-    R2L_BLOCK_REDUCE_F(6, R2L_ACC_FWD, regs, lds, a.stat_partial, bid, nblk)
+    // threads -> one float64 total per slot and workgroup, in a fixed order: every thread re-bases its sums to the pivot
+    // 0.5 and parks them in LDS (6 x R2L_NT doubles), 16 threads per slot add 32 of them each, one adds the 16.  The
+    // workgroup's totals travel as (high, low) float32 pairs -- slots i and 6 + i -- which the tree adds up separately.
+    double* dl = (double*)lds;
+    R2L_PHASE_BEGIN
+    const R2LFwdRegs& r = R2L_TREG(regs);
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      const double s1 = (double)r.acc[k][0] + (double)r.acc[k][1], s2 = (double)r.acc[3 + k][0] + (double)r.acc[3 + k][1];
+      const double dp = (double)r.piv[k] - 0.5, n = (double)r.npx;
+      dl[k * R2L_NT + tid] = fma(n, dp, s1);
+      dl[(3 + k) * R2L_NT + tid] = fma(dp, fma(n, dp, 2.0 * s1), s2);
+    }
+    R2L_PHASE_END
+    R2L_PHASE_BEGIN
+    if (tid < 96) {
+      const int slot = tid >> 4, part = tid & 15;
+      double acc = 0.0;
+      for (int j = 0; j < R2L_NT / 16; ++j) acc += dl[slot * R2L_NT + part + 16 * j];
+      dl[6 * R2L_NT + tid] = acc;
+    }
+    R2L_PHASE_END
+    R2L_PHASE_BEGIN
+    if (tid < 6) {
+      double acc = 0.0;
+      for (int j = 0; j < 16; ++j) acc += dl[6 * R2L_NT + tid * 16 + j];
+      const float hi = (float)acc;
+      r2l_store_coherent(&a.stat_partial[(size_t)tid * nblk + bid], hi);
+      r2l_store_coherent(&a.stat_partial[(size_t)(6 + tid) * nblk + bid], (float)(acc - (double)hi));
+    }
+    R2L_STORES_DONE();
+    R2L_PHASE_END
     double* sl = (double*)(lds + 4);  // totals in LDS: the bookkeeping below reads them back
-    if (a.tree.counters && r2l_tree_finish<6>(a.tree, bid, nblk, lds, sl, (double*)(lds + 512),
-                                              (R2L_RED_FLOATS - 512) / 2)) {
+    if (a.tree.counters && r2l_tree_finish<12>(a.tree, bid, nblk, lds, sl, (double*)(lds + 512),
+                                               (R2L_RED_FLOATS - 512) / 2)) {
+      R2L_PHASE_BEGIN
+      if (tid < 6) sl[tid] += sl[6 + tid];
+      R2L_PHASE_END
       R2L_PHASE_BEGIN
       if (tid == 0) sl[6] = (double)a.B * (double)a.H * (double)a.W;
       R2L_PHASE_END

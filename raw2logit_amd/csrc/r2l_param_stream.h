@@ -31,7 +31,7 @@ struct R2LFwdStreamArgs {
   const float* bn;      // mean[3], istd[3] or null
   float* out;           // (B,3,H,W) or null (statistics only)
   float* yp_out;        // (B,H,W) or null: the sharpened luma Y', kept for the backward (written with `out`)
-  float* stat_partial;  // [6][nblk] or null
+  float* stat_partial;  // [12][nblk] or null: (high, low) float32 halves of the workgroups' float64 totals
   int B, H, W;
   int nband, band_h, nitems;  // work item = (image, band); workgroup bid takes items bid, bid + nblk, ...
   R2LTree tree;
@@ -52,7 +52,7 @@ R2L_HD float r2l_wshl(float x, float edge) {  // next lane's x; lane 63 gets `ed
 #define R2L_FS_FIFO_ROWS 6                   // (chroma waits 4 rows for its luma; slot = row mod 6 = unroll position)
 #define R2L_FS_FIFO_F4 (R2L_FS_FIFO_ROWS * 2 * 64)  // (U[4], V[4]) of 6 rows x 64 lanes = 12 KB per wavefront
 // reduction scratch ((6 NT + 96) doubles, >= the tree's scratch): it reuses the chroma rings, which are idle by then
-#define R2L_FS_RED_FLOATS(NW) (14 * (NW) * 64 > 1024 ? 14 * (NW) * 64 : 1024)
+#define R2L_FS_RED_FLOATS(NW) 3072  // (<= one wavefront's ring: 12 slots x 128 groups of the tree in one pass)
 #define R2L_FS_RING_FLOATS(NW) ((NW) * R2L_FS_FIFO_F4 * 4 > R2L_FS_RED_FLOATS(NW) ? (NW) * R2L_FS_FIFO_F4 * 4 : R2L_FS_RED_FLOATS(NW))
 #define R2L_FS_LDS_FLOATS(NW) (2 * (NW) * R2L_FS_EX + 16 + R2L_FS_RING_FLOATS(NW) + 12 * (NW))  // + 6 doubles per wave
 
@@ -117,7 +117,14 @@ struct R2LFsState {
   float v[3][6];   // V rows (slot = row mod 3)
   float y[3][6];   // Y rows with their left / right neighbours (slot = row mod 3)
   float yp[6][8];  // Y' rows with two neighbours each side (slot = row mod 6)
-  r2l_p2 acc[6];   // statistics: sum (x - .5), sum (x - .5)^2 per channel, per pair half
+  // statistics: sum (x - p), sum (x - p)^2 per channel, per pair half, about a PIVOT p of the lane's own: the value of its
+  // first pixel of the band.  Images are locally smooth, so the float32 sums stay small and exact-ish; with a fixed pivot
+  // (0.5, rounds 1-2) a channel near saturation (mean 0.99, variance 1.4e-3) lost 170x of the sums' precision to the
+  // cancellation in E[d^2] - E[d]^2: 7e-6 relative in the variance, 2e-5 in the normalised output -- five times the
+  // distance of the reference's own float32 run from its float64 run (tests: "out vs reference float64").  The lane
+  // re-bases its sums to the common pivot 0.5 in float64 when the band is done.
+  r2l_p2 acc[6];
+  float piv[3];
 };
 
 // 3x3 stencil with per-column-parity weights on a 6-wide 3-row window -> 4 outputs as 2 pairs
@@ -279,7 +286,8 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
         const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));                    // :209
         x[p] = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
         if (a.stat_partial && store_ok) {
-          const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-0.5f));
+          if (p == 0) st.piv[k] = (y == y0) ? x[0][0] : st.piv[k];
+          const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-st.piv[k]));
           st.acc[k] = r2l_padd(st.acc[k], d);
           st.acc[3 + k] = r2l_pfma(d, d, st.acc[3 + k]);
         }
@@ -357,6 +365,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     float* ypb = (a.out && a.yp_out) ? a.yp_out + (size_t)b * plane : nullptr;
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 6; ++i) st.acc[i] = r2l_splat2(0.f);
+    st.piv[0] = st.piv[1] = st.piv[2] = 0.5f;
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 3; ++i)
       R2L_PRAGMA_UNROLL
@@ -419,12 +428,21 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // exchange buffers free for the next item
     if (a.stat_partial) {
       double part[6];
+      const double npx = store_ok ? 4.0 * (double)(y1 - y0) : 0.0;  // pixels behind this lane's sums
       R2L_PRAGMA_UNROLL
-      for (int i = 0; i < 6; ++i) {
-        double v = (double)st.acc[i][0] + (double)st.acc[i][1];
+      for (int k = 0; k < 3; ++k) {
+        // from the lane's pivot p to the common pivot 0.5:  x - .5 = (x - p) + dp
+        const double s1 = (double)st.acc[k][0] + (double)st.acc[k][1];
+        const double s2 = (double)st.acc[3 + k][0] + (double)st.acc[3 + k][1];
+        const double dp = store_ok ? (double)st.piv[k] - 0.5 : 0.0;
+        double v1 = fma(npx, dp, s1), v2 = fma(dp, fma(npx, dp, 2.0 * s1), s2);
         R2L_PRAGMA_UNROLL
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        part[i] = v;
+        for (int m = 32; m >= 1; m >>= 1) {
+          v1 += __shfl_xor(v1, m, 64);
+          v2 += __shfl_xor(v2, m, 64);
+        }
+        part[k] = v1;
+        part[3 + k] = v2;
       }
       if (lane == 0) {
         R2L_PRAGMA_UNROLL
@@ -435,16 +453,20 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
   // ---- statistics: lanes -> one partial per slot and workgroup (fixed order), then the shared tree ------------
   if (a.stat_partial) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wavefront is done with its chroma ring
-    if (tid < 6) {  // the wavefronts' totals in wavefront order
+    if (tid < 6) {  // the wavefronts' totals in wavefront order; (high, low) float32 halves in slots tid and 6 + tid
       double acc = 0.0;
       for (int w = 0; w < NW; ++w) acc += (tots - wave * 6)[w * 6 + tid];
-      r2l_store_coherent(&a.stat_partial[(size_t)tid * nblk + bid], (float)acc);
+      const float hi = (float)acc;
+      r2l_store_coherent(&a.stat_partial[(size_t)tid * nblk + bid], hi);
+      r2l_store_coherent(&a.stat_partial[(size_t)(6 + tid) * nblk + bid], (float)(acc - (double)hi));
     }
     R2L_STORES_DONE();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     double* sl = (double*)(red + 4);  // totals in LDS: the bookkeeping below reads them back
     if (a.tree.counters &&
-        r2l_tree_finish<6, NT>(a.tree, bid, nblk, red, sl, (double*)(red + 512), (R2L_FS_RED_FLOATS(NW) - 512) / 2)) {
+        r2l_tree_finish<12, NT>(a.tree, bid, nblk, red, sl, (double*)(red + 512), (R2L_FS_RED_FLOATS(NW) - 512) / 2)) {
+      if (tid < 6) sl[tid] += sl[6 + tid];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (tid == 0) sl[6] = (double)a.B * (double)a.H * (double)a.W;
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (tid < 7) a.stats_out[tid] = sl[tid];

@@ -155,6 +155,27 @@ def check_param_case(case, golden, device):
     report(f'param/{case["name"]}/out vs reference (golden, float32)', gerr[gw], gtol[gw])
     assert np.all(gerr <= gtol), (case['name'], 'out vs golden', gerr.max())
 
+    # ... and against the reference's OWN float64 run (golden out64 / grad64: the unmodified reference module under a float64
+    # default dtype).  |ref32 - ref64| is the float32 conditioning of the case measured on the reference itself; this
+    # library, another float32 evaluation of the same formulas in another order, must sit at the same distance from ref64:
+    # band by band its RMS error may be at most twice the reference's (+ 2e-7), and its largest error at most 6 x the
+    # reference's largest (+ 1e-6) -- the maximum over a few hundred pixels of independent round-offs times slopes of up
+    # to 241 (pipeline_torch.py:206-209) is a noisy statistic, the RMS is not.
+    ref64, ref32 = g[pre + 'out64'], g[pre + 'out'].astype(np.float64)
+    mine = _sample(out, full).astype(np.float64)
+    wellS = _sample(well, full)
+    for band, sel in (('pre-gamma > 3e-3', wellS), ('pre-gamma <= 3e-3', ~wellS)):
+        if sel.any():
+            d_ref, d_mine = (ref32 - ref64)[sel], (mine - ref64)[sel]
+            r_ref, r_mine = np.sqrt(np.mean(d_ref ** 2)), np.sqrt(np.mean(d_mine ** 2))
+            report(f'param/{case["name"]}/out vs REFERENCE float64, rms ({band}); reference float32 rms {r_ref:.2e}',
+                   r_mine, 2 * r_ref + 2e-7)
+            report(f'param/{case["name"]}/out vs REFERENCE float64, max ({band}); reference float32 max {np.abs(d_ref).max():.2e}',
+                   np.abs(d_mine).max(), 6 * np.abs(d_ref).max() + 1e-6)
+            assert r_mine <= 2 * r_ref + 2e-7, (case['name'], band, 'rms vs reference float64', r_mine, r_ref)
+            assert np.abs(d_mine).max() <= 6 * np.abs(d_ref).max() + 1e-6, \
+                (case['name'], band, 'max vs reference float64', np.abs(d_mine).max(), np.abs(d_ref).max())
+
     res = {'out_err': float(err.max())}
     for k, og in o_grads.items():
         got = NAME2ATTR[k](m).grad.detach().cpu().numpy().reshape(np.asarray(og).shape)
@@ -168,6 +189,12 @@ def check_param_case(case, golden, device):
                2 * grad_rtol * (np.abs(ref).max() + 1e-6) + 2 * flip[k])
         assert e2 <= 2 * grad_rtol * (np.abs(ref).max() + 1e-6) + 2 * flip[k], \
             (case['name'], k, 'grad vs golden', e2, flip[k])
+        g64 = g[pre + 'grad64/' + k]
+        mine_g = (_sample(got, full) if k == 'additive_layer' else got).astype(np.float64)
+        e_ref, e_mine = np.abs(ref.astype(np.float64) - g64).max(), np.abs(mine_g - g64).max()
+        lim64 = 2 * e_ref + 5e-4 * (np.abs(g64).max() + 1e-6) + 2 * flip[k]
+        report(f'param/{case["name"]}/grad {k} vs reference float64; reference float32 is {e_ref:.2e} away', e_mine, lim64)
+        assert e_mine <= lim64, (case['name'], k, 'grad vs reference float64', e_mine, e_ref)
         res['grad/' + k] = float(e / scale)
     if case['bn'] and case['training']:
         bnm = m.batch_norm

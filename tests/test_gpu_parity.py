@@ -59,23 +59,30 @@ def test_cpu_tensor_is_refused(dev):
 
 
 def test_full_size_config2_properties(dev):
-    """BASELINE config 2 (64 x 512 x 512, BatchNorm train): size-independent properties.
-    (i) normalised output has zero mean / unit biased variance per channel, (ii) two runs are bitwise
-    identical (fixed-order reductions), (iii) a 2-image slice equals the oracle, (iv) the parameter
-    gradient equals the sum of per-half-batch gradients computed with the same global statistics."""
+    """BASELINE config 2 (64 x 512 x 512, BatchNorm train) at full size; the float64 oracle needs minutes for the whole
+    batch, so size-independent properties: (i) the normalised output has zero mean / unit biased variance per channel,
+    (ii) two runs are bitwise identical (fixed-order reductions), (iii) eval mode with the batch statistics reproduces the
+    train-mode output (frames decouple), (iv) a 2-frame slice in that eval mode -- output and all 132 gradients -- against
+    the float64 oracle (the pattern of test_full_size_config4_microscopy; round 2 compared the slice through a least-squares
+    affine fit), (v) eval-mode gradients of the whole batch are the sum of the gradients of its four quarters."""
+    import copy
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     B, H, W = 64, 512, 512
     raw_np = orc.synth_raw(B, H, W, seed=0, kind='uniform')
     raw = torch.from_numpy(raw_np).to(dev)
     m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).to(dev)
     m.train()
+    m.batch_norm.momentum = 1.0                 # running statistics := this batch's statistics
     y = m(raw)
     mean = y.detach().double().mean(dim=(0, 2, 3))
     var = y.detach().double().var(dim=(0, 2, 3), unbiased=False)
+    pc.report('config2/train-mode output: |mean|', mean.abs().max().item(), 1e-4)
+    pc.report('config2/train-mode output: |var - 1|', (var - 1).abs().max().item(), 1e-3)
     assert mean.abs().max() < 1e-4 and (var - 1).abs().max() < 1e-3
     g = torch.randn(y.shape, device=dev, generator=torch.Generator(dev).manual_seed(1))
     (y * g).sum().backward()
     grads1 = [p.grad.clone() for p in m.parameters()]
+    rm1, rv1 = m.batch_norm.running_mean.clone(), m.batch_norm.running_var.clone()
     for p in m.parameters():
         p.grad = None
     y2 = m(raw)
@@ -83,21 +90,62 @@ def test_full_size_config2_properties(dev):
     assert torch.equal(y, y2)
     for a, p in zip(grads1, m.parameters()):
         assert torch.equal(a, p.grad)
-    # eval-mode slice vs the oracle with the batch statistics the kernels found
-    rm = m.batch_norm.running_mean.double().cpu().numpy()
+    assert torch.equal(rm1, m.batch_norm.running_mean) and torch.equal(rv1, m.batch_norm.running_var)
+    # (iii) eval mode with the batch statistics
+    n = B * H * W
+    with torch.no_grad():
+        m.batch_norm.running_var.mul_((n - 1) / n)          # unbiased -> the biased variance train mode used
+    m.eval()
+    for p in m.parameters():
+        p.grad = None
+    y_ev = m(raw)
+    y_ev.backward(g)
+    e = (y_ev.detach() - y.detach()).abs().max().item()
+    pc.report('config2/eval mode with the batch statistics vs train mode', e, 2e-5)
+    assert e <= 2e-5
+    g_full = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    # (iv) 2-frame slice against the float64 oracle
+    ms = copy.deepcopy(m)
+    for p in ms.parameters():
+        p.grad = None
+    ys = ms(raw[:2])
+    ys.backward(g[:2])
+    assert torch.equal(ys.detach(), y_ev.detach()[:2])
     P = orc.IspParams(orc.DRONE_CAMERA_PARAMS, dtype=np.float64)
-    o, _, c = orc.parametrized_forward(raw_np[:2], P, bn=None)
-    bmean = rm / 0.1 if int(m.batch_norm.num_batches_tracked) == 1 else None
-    if bmean is not None:
-        pre = y[:2].detach().double().cpu().numpy()
-        # y = (x - mu) * istd  ->  x = y / istd + mu ; istd from the oracle slice is not available, so
-        # compare through the affine relation channel by channel (least squares slope/intercept)
-        for k in range(3):
-            A = np.stack([o[:, k].ravel(), np.ones(o[:, k].size)], 1)
-            coef, *_ = np.linalg.lstsq(A, pre[:, k].ravel(), rcond=None)
-            fit = A @ coef
-            assert np.abs(fit - pre[:, k].ravel()).max() < 5e-4
-            assert abs(-coef[1] / coef[0] - bmean[k]) < 1e-4
+    bn = dict(training=False, running_mean=m.batch_norm.running_mean.double().cpu().numpy(),
+              running_var=m.batch_norm.running_var.double().cpu().numpy())
+    o, _, c = orc.parametrized_forward(raw_np[:2], P, bn=bn)
+    tol = pc.out_tolerance(c, True)
+    err = np.abs(ys.detach().cpu().numpy() - o)
+    w = np.unravel_index((err / tol).argmax(), err.shape)
+    pc.report('config2/2-frame slice: out vs float64 oracle', err[w], tol[w])
+    assert np.all(err <= tol), (err.max(), w)
+    cot_np = g[:2].cpu().numpy()
+    og_all, _, _ = orc.parametrized_backward(P, c, cot_np)
+    lo, _, _ = orc.parametrized_backward(P, c, cot_np, clip_shift=1e-6)
+    hi, _, _ = orc.parametrized_backward(P, c, cot_np, clip_shift=-1e-6)
+    for k, og in og_all.items():
+        got = pc.NAME2ATTR[k](ms).grad.detach().cpu().numpy().reshape(np.asarray(og).shape)
+        flip = max(np.abs(np.asarray(lo[k]) - og).max(), np.abs(np.asarray(hi[k]) - og).max())
+        lim = pc.DEFAULT_GRAD_RTOL * (np.abs(og).max() + 1e-6) + flip
+        e = np.abs(got - og).max()
+        pc.report(f'config2/2-frame slice: grad {k} vs float64 oracle', e, lim)
+        assert e <= lim, (k, e, lim)
+    # (v) gradients add up over the batch
+    acc = {k: torch.zeros_like(v) for k, v in g_full.items()}
+    for q in range(4):
+        mq = copy.deepcopy(m)
+        for p in mq.parameters():
+            p.grad = None
+        sl = slice(16 * q, 16 * (q + 1))
+        mq(raw[sl]).backward(g[sl])
+        for k, p in mq.named_parameters():
+            acc[k] += p.grad
+    for k in g_full:
+        scale = g_full[k].abs().max().item() + 1e-6
+        e = (acc[k] - g_full[k]).abs().max().item()
+        pc.report(f'config2/grad {k}: whole batch vs sum of quarters', e, 1e-4 * scale)
+        assert e <= 1e-4 * scale, (k, e, scale)
 
 
 def test_full_size_static_config3_slice(dev):
@@ -253,7 +301,7 @@ def test_bench_line_carries_roofline_and_static_c3(dev):
     for r in recs:
         assert 0 < r['frac'] < 1 and r['avg_us'] > 0
         # algorithmic bytes over HIP-event time cannot beat the wall clock of the same call
-        assert r['avg_us'] * 1e-3 <= r['ms_per_call_wall'] * 1.05
+        assert r['avg_us'] * 1e-3 <= r['ms_per_call_wall'] * 1.10, r    # (two passes of 20 launches: +-4 % between them)
 
 
 def test_bench_two_ranks_nccl(dev):
