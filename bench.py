@@ -37,7 +37,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PREROLL_S = 0.3                # untimed pre-roll of the step before the W warm-up steps (GPU clocks, see main())
+PREROLL_S = float(os.environ.get('R2L_BENCH_PREROLL_S', '0.3'))   # untimed pre-roll of the step before the W warm-up steps
+                               # (GPU clocks, see main(); counter-collection runs of the profiling scripts set 0)
 # algorithmic HBM bytes per raw pixel of each kernel family, by kernel-name prefix; the
 # `_u16` instantiations (16-bit containers) read 2 B/px less raw
 ALGO_BYTES_PER_PX = (
@@ -55,7 +56,7 @@ def algo_bytes_per_px(kernel):
     return None
 
 
-PMC_PARAM = 'r02_pmc_traffic.json'
+PMC_PARAM = 'r03_pmc_traffic.json'
 PMC_STATIC = 'r02_pmc_traffic_static.json'
 
 

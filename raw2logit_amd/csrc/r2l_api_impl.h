@@ -687,10 +687,11 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC, g1};
   a2.params = params;
   a2.grad_params = grad_params;
-  // two workgroups per CU: the older one (dispatched first) gets more issue slots -- and one tile more every 4 rounds
-  // (r2l_walk_init); only when the launch really is two resident workgroups per CU with several tiles each
+  // uneven tile shares for the two workgroups of a CU (r2l_walk_init): measured, no gain -- the younger workgroup is
+  // starved while the older one runs and catches up afterwards, the CU finishes its 16 tiles at the same time whatever the
+  // split (profiles/r03_bwd2_tile_shares.txt).  Even shares (0) are the default; diagnostic builds can sweep it.
 #ifndef R2L_B2_ASYM
-#define R2L_B2_ASYM 4
+#define R2L_B2_ASYM 0
 #endif
   a2.asym = (R2L_OCC_BWD2 >= 4 && g2 == 512 && ntiles2 >= 4 * g2) ? r2l_env_int("R2L_B2_ASYM", R2L_B2_ASYM) : 0;
   if (a2.asym == 1) a2.asym = 0;

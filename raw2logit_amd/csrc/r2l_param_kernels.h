@@ -23,7 +23,7 @@
   if (threadIdx.x == 0 && (dbg)) for (int k_ = 0; k_ < 8; ++k_) (dbg)[(size_t)(bid) * 8 + k_] = (float)st_[k_];
 // stage stamps inside kernel B1's pixel phase (slots 1, 2 -- unused when Y' comes from the forward: blur + chroma | pointwise)
 #define R2L_SUB_ARG , unsigned long long* sub_
-#define R2L_SUB_PASS , st_
+#define R2L_SUB_PASS , (SAVED ? st_ : (unsigned long long*)nullptr)
 #define R2L_SUB_PASS_FWD , sub_
 #define R2L_SUB_PASS_NONE , (unsigned long long*)nullptr
 #define R2L_SUB_BEGIN unsigned long long s0_ = __builtin_amdgcn_s_memtime(), s1_;
@@ -102,12 +102,12 @@ struct R2LTileWalk {
   int asym;  // > 0: every asym-th round of the walk is a HALF round, served by the older half of the workgroups only
   R2LDiv dx, dy, dj, dh;
 };
-// asym: two workgroups share a CU and the hardware's issue arbitration favours the waves of the one dispatched first
-// (by age): with equal shares the older workgroup of kernel B2 finishes its tiles in ~140 kcycles, the younger one needs
-// ~178 and the launch lasts as long as the slowest (profiles/r02_l_bwd2_stream_experiment.txt).  Workgroups are
-// dispatched in id order, so ids below nblk / 2 are the older ones: they take one tile more every `asym` rounds (asym = 4,
-// 8 tiles per workgroup on average: 9 vs 7).  The tile -> workgroup map stays a pure function of (bid, nblk): sums do not
-// depend on the schedule.
+// asym (experiment, off by default): two workgroups share a CU and the hardware's issue arbitration favours the waves of
+// the one dispatched first (by age): with equal shares the older workgroup of kernel B2 finishes its tiles in ~140 kcycles,
+// the younger one needs ~178.  Workgroups are dispatched in id order, so ids below nblk / 2 are the older ones: with
+// asym = n they take one tile more every n rounds (n = 4, 8 tiles per workgroup on average: 9 vs 7).  The tile ->
+// workgroup map stays a pure function of (bid, nblk): sums do not depend on the schedule.  Measured: the launch takes as
+// long as before -- the CU's throughput, not the split, sets the time (profiles/r03_bwd2_tile_shares.txt).
 R2L_HD R2LTileWalk r2l_walk_init(int B, int H, int W, int TW, int TH, int bid, int nblk, int asym = 0) {
   R2LTileWalk w;
   w.ntx = (W + TW - 1) / TW;

@@ -8,11 +8,11 @@ TAG=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
-python3 bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-small-shapes > $OUT/stats.log 2>&1)
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-run() { n=$1; shift; (cd /tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/$n.log 2>&1); }
+run() { n=$1; shift; (cd /tmp && R2L_BENCH_PREROLL_S=0 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $ROOT/bench.py --steps 3 --warmup 1 --quick --no-roofline > $OUT/$n.log 2>&1); }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run tcc1 FETCH_SIZE
@@ -55,5 +55,5 @@ bash tests/sizes.sh > $OUT/sizes.txt 2>&1
 python3 bench.py --workload static --steps 30 --warmup 10 --debayer malvar2004 --no-cpu-baseline > $OUT/bench_static_malvar.json 2>> $OUT/bench.err
 python3 tests/bench_static.py > $OUT/static.txt 2>&1
 python3 tests/bench_aux.py > $OUT/aux.txt 2>&1
-if [ -f tests/_build/lib_stamps.so ]; then python3 tests/stamps.py > $OUT/stamps.txt 2>&1; fi
+if [ -f tests/_build/lib_stamps.so ]; then R2L_STAMPS_KEEP_LUMA=1 R2L_STAMPS_DETAIL=1 python3 tests/stamps.py > $OUT/stamps.txt 2>&1; fi
 ls -la $OUT
