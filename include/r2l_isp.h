@@ -185,6 +185,13 @@ enum { R2L_BN_NONE = 0, R2L_BN_TRAIN = 1, R2L_BN_EVAL = 2 };
 enum { R2L_STEP_ALL = 0, R2L_STEP_A = 1, R2L_STEP_B = 2 };
 /* or-ed into `phase` of r2l_isp_step_fwd AND r2l_isp_step_bwd of a step whose backward will run: R2L_F_KEEP_LUMA */
 enum { R2L_STEP_KEEP_LUMA = 8 };
+/* Output epilogue: the weak augmentation of utils/augmentation.py:70-74, applied to the
+ * processor's output at model.py:79-81 -- rot90^k(vflip(hflip(out))) over the last two axes, k as in
+ * out.rot90(k, dims=(-1, -2)) -- written by the forward's own stores instead of a separate permutation pass.  Or these
+ * into `phase` of r2l_isp_step_fwd AND of the r2l_isp_step_bwd of the same step: `out` / `grad_out` are then in the
+ * augmented layout ((B,3,W,H) for odd k, which needs H == W).  Not with an additive layer (error -3: use r2l_augment
+ * on the plain output).  Bit-identical to r2l_augment(r2l_isp_step_fwd(...)).                                        */
+enum { R2L_STEP_EPI_HFLIP = 16, R2L_STEP_EPI_VFLIP = 32, R2L_STEP_EPI_ROT_SHIFT = 6 /* k << 6: bits 64, 128 */ };
 enum { R2L_STEP_STATS = 0, R2L_STEP_MOMENTS = 1, R2L_STEP_BN_SUMS = 2, R2L_STEP_PACKED = 3, R2L_STEP_BN = 4 };
 size_t r2l_isp_step_offset(int which, int B, int H, int W); /* byte offset inside the workspace */
 int r2l_isp_step_fwd(const void *raw, int raw_u16, float denom, const float *const *params_host,

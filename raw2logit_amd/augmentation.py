@@ -170,7 +170,8 @@ class ComposeState:
                 self.mask_transforms.append(t)
         self.seed = None
 
-    def __call__(self, x, retain_state=False, mask_transform=False):
+    def _enter(self, retain_state):
+        """the reference's seed bookkeeping at the head of a call (:51-57)"""
         if self.seed is not None:   # retain previous state
             set_global_seed(self.seed)
         if retain_state:    # save state for next call
@@ -178,6 +179,42 @@ class ComposeState:
             set_global_seed(self.seed)
         else:
             self.seed = None    # reset / ignore state
+
+    def arm(self, processor, retain_state=False):
+        """Make the NEXT ``processor(x)`` call return the augmented batch: the draws of this transform list are made NOW
+        (the processor consumes no host randomness, so a seeded run takes the same decisions as the reference, which
+        draws after the processor call) and handed to the processor as a one-shot output epilogue -- the fused kernels
+        then write the flipped / rotated output themselves instead of a separate 24 B/px pass, and the backward reads
+        ``grad_out`` through the same map.  The ``self(x, retain_state=...)`` call that follows in model.py:79-81 returns
+        its argument unchanged (once).  In LitModel.forward that is ONE added line in front of ``self.processor(x)``:
+
+            if self.augmentation is not None and apply_augmentation_step:
+                self.augmentation.arm(self.processor, retain_state=self.is_segmentation_task)
+
+        Returns False (and arms nothing) for transform lists that hold anything but flips / rot90, or an order of them
+        that does not commute into one permutation.  ``processor.buffer['processed_rgb']`` of an armed call holds the
+        augmented output."""
+        if not all(hasattr(t, 'decide') for t in self.transforms):
+            return False
+        state = (torch.random.get_rng_state(), np.random.get_state(), random.getstate(), self.seed)
+        self._enter(retain_state)
+        pending = _Pending()
+        for t in self.transforms:
+            if t.decide(pending):           # needs a flush in between: not one permutation -- undo the draws
+                torch.random.set_rng_state(state[0])
+                np.random.set_state(state[1])
+                random.setstate(state[2])
+                self.seed = state[3]
+                return False
+        processor.__dict__['_epilogue'] = (pending.hflip, pending.vflip, pending.k)
+        self._armed = True
+        return True
+
+    def __call__(self, x, retain_state=False, mask_transform=False):
+        if getattr(self, '_armed', False) and not mask_transform:
+            self._armed = False             # the processor's epilogue already applied this call's moves
+            return x
+        self._enter(retain_state)
         transforms = self.transforms if not mask_transform else self.mask_transforms
         pending = _Pending()
         for t in transforms:

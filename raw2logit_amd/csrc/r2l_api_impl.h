@@ -184,6 +184,17 @@ R2L_FS_KERNEL(r2l_launch_fwd_stream_w1_u16, 1, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w2_u16, 2, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w4_u16, 4, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w8_u16, 8, true)
+// ... with the output epilogue (flip / flip / rot90 of the output planes as part of the stores, R2LEpi)
+#define R2L_FS_KERNEL_EPI(name, NW, U16)                                                                \
+  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC, r2l_fwd_stream_block<NW, U16, true>)
+R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w1, 1, false)
+R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w2, 2, false)
+R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w4, 4, false)
+R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w8, 8, false)
+R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w1_u16, 1, true)
+R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w2_u16, 2, true)
+R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w4_u16, 4, true)
+R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w8_u16, 8, true)
 #endif
 R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, false>)
 R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, false>)
@@ -482,7 +493,7 @@ static bool r2l_fwd_streams(const float* additive, int W) {
 static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float* additive,
                             const float* bn_mean_istd, float* out, double* stats, void* workspace,
                             size_t workspace_bytes, int B, int H, int W, int flags, void* stream,
-                            const R2LBnFinalizeArgs* fin = nullptr) {
+                            const R2LBnFinalizeArgs* fin = nullptr, const R2LEpi* ep = nullptr) {
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (int e = r2l_check_raw(raw, W, "r2l_isp_fwd")) return e;
   if (!params || !workspace) return r2l_fail(-1, "r2l_isp_fwd: null pointer");
@@ -537,13 +548,20 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
       fa.fin.bn = nullptr;
     const int nw = W <= 256 ? 0 : (W <= 512 ? 1 : (W <= 1024 ? 2 : 3));
     typedef int (*launch_t)(const R2LFwdStreamArgs&, int, void*);
-    static const launch_t table[2][4] = {
-        {r2l_launch_fwd_stream_w1, r2l_launch_fwd_stream_w2, r2l_launch_fwd_stream_w4, r2l_launch_fwd_stream_w8},
-        {r2l_launch_fwd_stream_w1_u16, r2l_launch_fwd_stream_w2_u16, r2l_launch_fwd_stream_w4_u16,
-         r2l_launch_fwd_stream_w8_u16}};
-    return table[raw.u16 ? 1 : 0][nw](fa, sgrid, stream);
+    static const launch_t table[2][2][4] = {
+        {{r2l_launch_fwd_stream_w1, r2l_launch_fwd_stream_w2, r2l_launch_fwd_stream_w4, r2l_launch_fwd_stream_w8},
+         {r2l_launch_fwd_stream_w1_u16, r2l_launch_fwd_stream_w2_u16, r2l_launch_fwd_stream_w4_u16,
+          r2l_launch_fwd_stream_w8_u16}},
+        {{r2l_launch_fwd_stream_epi_w1, r2l_launch_fwd_stream_epi_w2, r2l_launch_fwd_stream_epi_w4,
+          r2l_launch_fwd_stream_epi_w8},
+         {r2l_launch_fwd_stream_epi_w1_u16, r2l_launch_fwd_stream_epi_w2_u16, r2l_launch_fwd_stream_epi_w4_u16,
+          r2l_launch_fwd_stream_epi_w8_u16}}};
+    const bool epi = ep && ep->on && out;
+    fa.ep = epi ? *ep : R2LEpi{0, 0, 0, 0};
+    return table[epi ? 1 : 0][raw.u16 ? 1 : 0][nw](fa, sgrid, stream);
   }
 #endif
+  if (ep && ep->on && out && additive) return r2l_fail(-3, "r2l_isp_fwd: no output epilogue with an additive layer");
   const int ntiles = B * ((H + GFwd::TH - 1) / GFwd::TH) * ((W + GFwd::TW - 1) / GFwd::TW);
   const int grid = r2l_tile_grid(ntiles, r2l_env_int("R2L_GRID_FWD", 512));
   R2LFwdArgs a;
@@ -565,6 +583,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     a.fin = *fin;
   else
     a.fin.bn = nullptr;
+  a.ep = (ep && ep->on && out) ? *ep : R2LEpi{0, 0, 0, 0};
   const bool exact = (H % GFwd::TH == 0) && (W % GFwd::TW == 0);
   int e;
   if (raw.u16)
@@ -622,7 +641,7 @@ int r2l_bn_bwd_reduce(const float* grad_out, const float* out, const double* tot
 static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float* additive,
                             const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,
                             float* grad_params, float* grad_raw, void* workspace, size_t workspace_bytes, int B,
-                            int H, int W, int flags, void* stream) {
+                            int H, int W, int flags, void* stream, const R2LEpi* ep = nullptr) {
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (int e = r2l_check_raw(raw, W, "r2l_isp_bwd")) return e;
   if (!params || !grad_out || !grad_params || !workspace)
@@ -655,6 +674,8 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   a1.debug = ws.debug + 8 * R2L_MAX_BLOCKS;
   const bool saved = (flags & R2L_F_KEEP_LUMA) && r2l_fwd_streams(additive, W) && !r2l_env_int("R2L_BWD1_RECOMPUTE", 0);
   a1.yp = saved ? ws.yp : nullptr;
+  a1.ep = (ep && ep->on) ? *ep : R2LEpi{0, 0, 0, 0};
+  if (a1.ep.on && additive) return r2l_fail(-3, "r2l_isp_bwd: no output epilogue with an additive layer");
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
   int e1;
   if (saved)
@@ -718,6 +739,26 @@ int r2l_additive_bwd(const float* grad_out, const float* out, const float* bn_me
 }
 
 // ---- one training step in two calls (r2l_isp_step_fwd / r2l_isp_step_bwd) --------------------------------
+// the output epilogue travels in the bits of `phase` above R2L_STEP_KEEP_LUMA (R2L_STEP_EPI_*); the affine map of
+// R2LEpi follows from r2l_aug_map, the definition the stand-alone permutation kernel (r2l_augment) uses
+static int r2l_epi_from_phase(int phase, int H, int W, R2LEpi& ep) {
+  const int hflip = (phase & R2L_STEP_EPI_HFLIP) != 0, vflip = (phase & R2L_STEP_EPI_VFLIP) != 0;
+  const int k = (phase >> R2L_STEP_EPI_ROT_SHIFT) & 3;
+  ep = R2LEpi{0, 0, 0, 0};
+  if (!(hflip || vflip || k)) return 0;
+  if ((k & 1) && H != W) return r2l_fail(-1, "output epilogue: a rotation by 90 degrees needs square frames");
+  const int Wo = (k & 1) ? H : W;
+  int r0, c0, r1, c1, r2, c2;
+  r2l_aug_map(H, W, hflip, vflip, k, 0, 0, r0, c0);
+  r2l_aug_map(H, W, hflip, vflip, k, 1, 0, r1, c1);
+  r2l_aug_map(H, W, hflip, vflip, k, 0, 1, r2, c2);
+  ep.on = 1;
+  ep.s0 = r0 * Wo + c0;
+  ep.sr = (r1 * Wo + c1) - ep.s0;
+  ep.sc = (r2 * Wo + c2) - ep.s0;
+  return 0;
+}
+#define R2L_STEP_EPI_MASK (R2L_STEP_EPI_HFLIP | R2L_STEP_EPI_VFLIP | (3 << R2L_STEP_EPI_ROT_SHIFT))
 static R2LRaw r2l_raw_any(const void* raw, int raw_u16, float denom) {
   return raw_u16 ? r2l_raw_u16((const unsigned short*)raw, denom) : r2l_raw_f32((const float*)raw);
 }
@@ -739,8 +780,10 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
                      size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
                      const double* gathered_stats, void* stream) {
   const int keep = (phase & R2L_STEP_KEEP_LUMA) ? R2L_F_KEEP_LUMA : 0;
-  phase &= ~R2L_STEP_KEEP_LUMA;
+  R2LEpi ep;
   if (int e = r2l_check_dims(B, H, W)) return e;
+  if (int e = r2l_epi_from_phase(phase, H, W, ep)) return e;
+  phase &= ~(R2L_STEP_KEEP_LUMA | R2L_STEP_EPI_MASK);
   if (!raw || !out || !workspace) return r2l_fail(-1, "r2l_isp_step_fwd: null pointer");
   if (bn_mode != R2L_BN_NONE && bn_mode != R2L_BN_TRAIN && bn_mode != R2L_BN_EVAL)
     return r2l_fail(-1, "r2l_isp_step_fwd: bn_mode must be R2L_BN_NONE, R2L_BN_TRAIN or R2L_BN_EVAL");
@@ -788,15 +831,18 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
     if (int e = r2l_launch_bn_finalize(f, 1, stream)) return e;
   }
   return r2l_isp_fwd_impl(rw, ws.packed, additive, bn_mode == R2L_BN_NONE ? nullptr : ws.bn, out, nullptr, workspace,
-                          workspace_bytes, B, H, W, R2L_F_FOLDED_VALID | keep, stream);
+                          workspace_bytes, B, H, W, R2L_F_FOLDED_VALID | keep, stream, nullptr, &ep);
 }
 int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* additive, const float* grad_out,
                      const float* out, float* grad_params, float* grad_additive, int bn_mode, void* workspace,
                      size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
                      const double* gathered_sums, void* stream) {
   const int keep = (phase & R2L_STEP_KEEP_LUMA) ? R2L_F_KEEP_LUMA : 0;
-  phase &= ~R2L_STEP_KEEP_LUMA;
+  R2LEpi ep;
   if (int e = r2l_check_dims(B, H, W)) return e;
+  if (int e = r2l_epi_from_phase(phase, H, W, ep)) return e;
+  phase &= ~(R2L_STEP_KEEP_LUMA | R2L_STEP_EPI_MASK);
+  if (ep.on && grad_additive) return r2l_fail(-3, "r2l_isp_step_bwd: no output epilogue with an additive layer");
   if (!raw || !grad_out || !workspace) return r2l_fail(-1, "r2l_isp_step_bwd: null pointer");
   if (phase != R2L_STEP_ALL && phase != R2L_STEP_A && phase != R2L_STEP_B)
     return r2l_fail(-1, "r2l_isp_step_bwd: unknown phase");
@@ -823,7 +869,7 @@ int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* add
   }
   if (grad_params) {
     if (int e = r2l_isp_bwd_impl(rw, ws.packed, additive, bn, bn_bwd, grad_out, grad_params, nullptr, workspace,
-                                 workspace_bytes, B, H, W, R2L_F_FOLDED_VALID | keep, stream))
+                                 workspace_bytes, B, H, W, R2L_F_FOLDED_VALID | keep, stream, &ep))
       return e;
   }
   if (grad_additive) return r2l_additive_bwd(grad_out, out, bn, bn_bwd, grad_additive, B, H, W, stream);

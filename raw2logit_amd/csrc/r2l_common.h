@@ -409,6 +409,18 @@ R2L_HD int r2l_symmetric(int i, int n) {
 // (pipeline_torch.py:256-259, :274-277)
 R2L_HD int r2l_site_channel(int py, int px) { return (py & 1) + (px & 1); }
 
+// ---- output epilogue: the weak augmentation as part of the forward's stores ----------------------------------------
+// utils/augmentation.py:70-74 applied to the processor's output (model.py:79-81): RandomHorizontalFlip, RandomVerticalFlip,
+// RandomRotate90 = rot90^k(vflip(hflip(x))), a permutation of every (H, W) plane.  It is affine in the pixel coordinates:
+// pixel (y, x) of the ISP's own layout goes to element  s0 + sr * y + sc * x  of its output plane (k even: sc = +-1, the
+// lane's 4 pixels stay one 16-byte vector, reversed for a horizontal flip; k odd: sc = +-H, four scalar accesses).  The
+// apply pass writes there directly, the backward reads grad_out from there (bn_reduce pairs grad_out with the saved output
+// element by element: both are in the permuted layout), so the separate permutation kernel (24 B/px) and its inverse in the
+// backward disappear.  r2l_aug_map (r2l_staged_kernels.h) is the definition the host derives (s0, sr, sc) from.
+struct R2LEpi {
+  int on, s0, sr, sc;
+};
+
 // ---- folded parameters -------------------------------------------------------------------------
 // The chain  mosaic -> Debayer conv -> white balance -> CCM -> RGB->YUV  (pipeline_torch.py:183-194)
 // is linear in the black-level-corrected raw value v: because each mosaic plane is non-zero only on

@@ -812,6 +812,7 @@ struct R2LFwdArgs {
   R2LTree tree;  // in-kernel final reduction of the statistics -> stats_out[0..6), stats_out[6] = B*H*W
   double* stats_out;
   R2LBnFinalizeArgs fin;  // fin.bn != null (one rank): the last workgroup also runs the BatchNorm bookkeeping
+  R2LEpi ep;              // ep.on: the output goes to its augmented position (R2LEpi)
 };
 
 // Two forward workgroups share a CU; the hardware favours the older one's waves, so left alone the younger
@@ -880,7 +881,12 @@ R2L_HD void r2l_fwd_row(const float* V, const float* YP, const R2LFwdArgs& a, in
       R2L_PRAGMA_UNROLL
       for (int p = 0; p < 2; ++p)
         x[p] = r2l_pmul(r2l_padd(x[p], r2l_splat2(-mean[k])), r2l_splat2(istd[k]));  // :217
-      if (vec_ok) {
+      if (a.ep.on) {  // output epilogue (this tile kernel is the fallback forward: element by element)
+        float* o = ob + (unsigned)k * plane + (a.ep.s0 + a.ep.sr * (int)((off0 - (unsigned)gx0) / (unsigned)a.W) + a.ep.sc * gx0);
+        R2L_PRAGMA_UNROLL
+        for (int c = 0; c < 4; ++c)
+          if (!RAGGED || gx0 + c < a.W) o[c * a.ep.sc] = x[c >> 1][c & 1];
+      } else if (vec_ok) {
         r2l_f4 st;
         st.x = x[0][0];
         st.y = x[0][1];
@@ -1103,6 +1109,7 @@ struct R2LBwd1Args {
   int B, H, W;
   float* debug;
   const float* yp;      // (B,H,W) or null: the sharpened luma Y' the forward kept (SAVED instantiations)
+  R2LEpi ep;            // ep.on: grad_out arrives in the augmented layout the forward's epilogue wrote (R2LEpi)
 };
 
 // per-thread accumulators of B1, as pairs: element h of a pair belongs to the pixels in the even (h = 0) or
@@ -1136,6 +1143,25 @@ struct R2LBnConsts {
   float mean[3], istd[3], mg[3], mgx[3];
 };
 
+// 4 consecutive pixels of the ISP's layout read back from the augmented layout: p = the position of the first one
+R2L_HD r2l_f4 r2l_epi_load4(const float* p, int sc) {
+  r2l_f4 v;
+  if (sc == 1) {
+    v = *(const r2l_f4*)p;
+  } else if (sc == -1) {
+    const r2l_f4 q = *(const r2l_f4*)(p - 3);
+    v.x = q.w;
+    v.y = q.z;
+    v.z = q.y;
+    v.w = q.x;
+  } else {
+    v.x = p[0];
+    v.y = p[sc];
+    v.z = p[2 * sc];
+    v.w = p[3 * sc];
+  }
+  return v;
+}
 // grad_out of this thread's 2 rows x 4 columns x 3 channels, fetched two phases ahead of its use: in the
 // pixel phase a wave has one other wave per SIMD to hide behind (VGPR-bound, 1 workgroup per CU), which
 // does not cover an HBM round trip; issued before the Y phase the loads have ~2 phases to land.
@@ -1149,6 +1175,12 @@ R2L_HD void r2l_bwd1_fetch_gout(int tid, const R2LBwd1Args& a, const R2LTile& t,
   const unsigned plane = (unsigned)a.H * (unsigned)a.W;
   const float* gb = a.gout + (size_t)t.b * 3 * plane;
   const unsigned pix0 = (unsigned)(t.oy + row0) * (unsigned)a.W + (unsigned)(t.ox + 4 * tx);
+  if (a.ep.on) {  // (store phase: registers and branches are cheap here)
+    const float* o = gb + (a.ep.s0 + a.ep.sr * (t.oy + row0 + 2 * r) + a.ep.sc * (t.ox + 4 * tx));
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) gp.g[r][k] = r2l_epi_load4(o + (unsigned)k * plane, a.ep.sc);
+    return;
+  }
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k)
     // read once here: nontemporal, so that it does not evict the raw frames / dL/dY'' (A/B: -1 % on the step)
@@ -1250,15 +1282,20 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
       g[2] = r2l_pick(second, gpre.g[0][k].z, gpre.g[1][k].z);
       g[3] = r2l_pick(second, gpre.g[0][k].w, gpre.g[1][k].w);
     } else if (vec_ok) {
-      const r2l_f4 q = *(const r2l_f4*)(gb + off);
+      // (with an output epilogue the frames are W % 4 == 0: this branch; gy = off0 / W)
+      const r2l_f4 q = a.ep.on ? r2l_epi_load4(gb + (unsigned)k * plane + (a.ep.s0 + a.ep.sr * (int)((off0 - (unsigned)gx0) / (unsigned)a.W) + a.ep.sc * gx0), a.ep.sc)
+                               : *(const r2l_f4*)(gb + off);
       g[0] = q.x;
       g[1] = q.y;
       g[2] = q.z;
       g[3] = q.w;
     } else {
+      const float* o = a.ep.on ? gb + (unsigned)k * plane + (a.ep.s0 + a.ep.sr * (int)((off0 - (unsigned)gx0) / (unsigned)a.W) + a.ep.sc * gx0)
+                               : gb + off;
+      const int sc = a.ep.on ? a.ep.sc : 1;
       R2L_PRAGMA_UNROLL
       for (int c = 0; c < 4; ++c)
-        if (gx0 + c < a.W) g[c] = gb[off + c];
+        if (gx0 + c < a.W) g[c] = o[c * sc];
     }
     R2L_PRAGMA_UNROLL
     for (int p = 0; p < 2; ++p) {

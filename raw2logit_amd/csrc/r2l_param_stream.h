@@ -37,6 +37,7 @@ struct R2LFwdStreamArgs {
   R2LTree tree;
   double* stats_out;
   R2LBnFinalizeArgs fin;
+  R2LEpi ep;  // EPI instantiations: where the output goes (R2LEpi)
 };
 
 R2L_HD float r2l_wshr(float x, float edge) {  // previous lane's x; lane 0 of the wavefront gets `edge`
@@ -142,7 +143,7 @@ R2L_HD void r2l_fs_stencil_parity(const float* r0, const float* r1, const float*
   }
 }
 
-template <int NW, bool U16, int K>
+template <int NW, bool U16, int K, bool EPI>
 R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0, int y1, bool le, bool re,
                         int wave, int lane, float* ex, r2l_f4* fifo, float* ob, float* ypb, unsigned plane, int x0,
                         bool store_ok, const float mean[3], const float istd[3]) {
@@ -301,7 +302,26 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
         s4.y = x[0][1];
         s4.z = x[1][0];
         s4.w = x[1][1];
-        *(r2l_f4*)(ob + (unsigned)k * plane + off0) = s4;
+        if (!EPI) {
+          *(r2l_f4*)(ob + (unsigned)k * plane + off0) = s4;
+        } else {  // the augmented position of this lane's 4 pixels (R2LEpi)
+          float* o = ob + (unsigned)k * plane + (a.ep.s0 + a.ep.sr * y + a.ep.sc * x0);
+          if (a.ep.sc == 1) {
+            *(r2l_f4*)o = s4;
+          } else if (a.ep.sc == -1) {
+            r2l_f4 r4;
+            r4.x = s4.w;
+            r4.y = s4.z;
+            r4.z = s4.y;
+            r4.w = s4.x;
+            *(r2l_f4*)(o - 3) = r4;
+          } else {
+            o[0] = s4.x;
+            o[a.ep.sc] = s4.y;
+            o[2 * a.ep.sc] = s4.z;
+            o[3 * a.ep.sc] = s4.w;
+          }
+        }
       }
     }
     // Y'(y), kept for kernel B1 of the backward: the middle row of the blur's window, stored last (the step's
@@ -326,7 +346,7 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
   }
 }
 
-template <int NW, bool U16>
+template <int NW, bool U16, bool EPI = false>
 R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -415,7 +435,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     const int q = qb + K;                                                                                       \
     r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
     if (q + 1 + PF <= q1) r2l_fs_fetch<U16>(a, img, r2l_mirror(q + 1 + PF, a.H), x0, le, re, lane, pf[K % PF]); \
-    r2l_fs_step<NW, U16, K>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, store_ok, mean, istd); \
+    r2l_fs_step<NW, U16, K, EPI>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, store_ok, mean, istd); \
   }
       R2L_FS_STEP(0)
       R2L_FS_STEP(1)

@@ -335,7 +335,7 @@ struct R2LAugArgs {
   int hflip, vflip, k, inverse;
 };
 // forward map of one input coordinate: (r, c) in H x W -> (r2, c2) in Ho x Wo
-R2L_HD void r2l_aug_map(int H, int W, int hflip, int vflip, int k, int r, int c, int& r2, int& c2) {
+R2L_HOSTDEV void r2l_aug_map(int H, int W, int hflip, int vflip, int k, int r, int c, int& r2, int& c2) {
   if (hflip) c = W - 1 - c;
   if (vflip) r = H - 1 - r;
   int h = H, w = W;

@@ -265,6 +265,21 @@ def bn_bwd_means(lib, stream, sums, moments, group):
 
 _STEP_ALL, _STEP_A, _STEP_B = 0, 1, 2
 _STEP_KEEP_LUMA = 8      # or-ed into `phase` of both calls of a step whose backward will run (R2L_STEP_KEEP_LUMA)
+_STEP_EPI_HFLIP, _STEP_EPI_VFLIP, _STEP_EPI_ROT_SHIFT = 16, 32, 6       # output epilogue (R2L_STEP_EPI_*)
+
+
+def epilogue_bits(epilogue):
+    """(hflip, vflip, k) -> the bits r2l_isp_step_fwd / _bwd take in `phase` (include/r2l_isp.h: R2L_STEP_EPI_*)"""
+    if not epilogue:
+        return 0
+    hflip, vflip, k = epilogue
+    return (_STEP_EPI_HFLIP if hflip else 0) | (_STEP_EPI_VFLIP if vflip else 0) | ((int(k) & 3) << _STEP_EPI_ROT_SHIFT)
+
+
+def epilogue_supported(raw, module):
+    """can the fused kernels write this module's output through an epilogue?  (no additive layer: its gradient is
+    summed in the ISP's own layout; rotations by 90 degrees need square frames -- checked per draw)"""
+    return module.additive_layer is None
 _STEP_STATS, _STEP_MOMENTS, _STEP_BN_SUMS = 0, 1, 2
 _STEP_LAYOUT = {}
 
@@ -291,7 +306,7 @@ class _IspFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, bl, wb, ccm, gamma, deb, sharp, blur, m1, m2, additive, bn_mode, bn_module, eps,
-                momentum, group, bits=16, grad_mode=True):
+                momentum, group, bits=16, grad_mode=True, epilogue=None):
         raw, denom = _raw_arg(raw, bits)
         params = (bl, wb, ccm, gamma, deb, sharp, blur, m1, m2)
         sizes = (4, 3, 9, 1, 81, 9, 25, 9, 9)
@@ -318,7 +333,11 @@ class _IspFused(torch.autograd.Function):
         nws, off_stats, off_sums = _step_layout(lib, B, H, W)
         dev = raw.device
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        epi = epilogue_bits(epilogue)
+        if epi and (additive is not None or ((epilogue[2] & 1) and H != W)):
+            raise _lib.R2LError('this call cannot take an output epilogue (no additive layer; square frames for a rotation '
+                                'by 90 degrees): apply the augmentation to the output instead')
+        out = torch.empty((B, 3, W, H) if (epi and (epilogue[2] & 1)) else (B, 3, H, W), dtype=torch.float32, device=dev)
         rm = rv = nbt = None
         if bn_mode == BN_TRAIN:
             rm, rv, nbt = _bn_buffers(bn_module, dev)
@@ -335,7 +354,7 @@ class _IspFused(torch.autograd.Function):
         def call(phase, gathered):
             lib.check(lib.r2l_isp_step_fwd(ptr(raw), int(denom is not None), denom or 1.0, table, ptr(additive),
                                            bn_mode, ptr(rm), ptr(rv), ptr(nbt), float(eps), mom, ptr(out), ptr(ws),
-                                           nws, B, H, W, nranks, phase | keep, ptr(gathered), stream),
+                                           nws, B, H, W, nranks, phase | keep | epi, ptr(gathered), stream),
                       'r2l_isp_step_fwd')
         if nranks == 1:
             call(_STEP_ALL, None)
@@ -346,7 +365,7 @@ class _IspFused(torch.autograd.Function):
             call(_STEP_B, gathered)
         del alive
         ctx.bn_mode = bn_mode
-        ctx.keep = keep
+        ctx.keep = keep | epi
         ctx.group = group
         ctx.nranks = nranks
         ctx.denom = denom
@@ -391,18 +410,19 @@ class _IspFused(torch.autograd.Function):
             for i, ((_, off, n), shape) in enumerate(zip(PARAM_LAYOUT, ctx.shapes)):
                 if ctx.needs_input_grad[1 + i]:
                     grads[i] = gp[off:off + n].view(shape)
-        return (None, *grads, None, None, gadd, None, None, None, None, None, None, None)
+        return (None, *grads, None, None, gadd, None, None, None, None, None, None, None, None)
 
 
-def isp_fused(raw, module, bn_mode=BN_NONE, group=None):
-    """fused forward of a ParametrizedProcessing-shaped module (parameters by the reference's names)."""
+def isp_fused(raw, module, bn_mode=BN_NONE, group=None, epilogue=None):
+    """fused forward of a ParametrizedProcessing-shaped module (parameters by the reference's names).  epilogue =
+    (hflip, vflip, k): the output leaves the kernels as rot90^k(vflip(hflip(out)))."""
     bn = module.batch_norm
     return _IspFused.apply(raw, module.black_level, module.white_balance, module.colour_correction,
                            module.gamma_correct, module.debayer.weight, module.sharpening_filter.weight,
                            module.gaussian_blur.weight, module.M_RGB_2_YUV, module.M_YUV_2_RGB,
                            module.additive_layer, bn_mode, bn, bn.eps if bn is not None else 1e-5,
                            bn.momentum if bn is not None else None, group, getattr(module, 'raw_bits', 16),
-                           torch.is_grad_enabled())
+                           torch.is_grad_enabled(), epilogue)
 
 
 # --------------------------------------------------------------------------------------------------

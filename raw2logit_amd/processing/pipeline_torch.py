@@ -290,12 +290,24 @@ class ParametrizedProcessing(nn.Module):
         # tensors nor produce d/d raw.  Whenever a caller can observe either (track_stages=True, or frames
         # that require grad as in model.py:228), the stage-by-stage kernels run instead and fill
         # ``self.stages`` exactly like the reference (:183-214).
+        # a one-shot output epilogue armed by the augmentation drop-in (ComposeState.arm): the flips / rot90 of
+        # utils/augmentation.py:70-74 (applied to this module's output at model.py:79-81) leave the fused kernels as part
+        # of their output stores; on the staged path, or where the kernels cannot take it, the moves run as the separate
+        # permutation kernel right here -- either way the caller gets the augmented batch
+        epilogue = d.pop('_epilogue', None)
         if self.track_stages or (raw.requires_grad and torch.is_grad_enabled()):
             from ..staged import staged_forward
             rgb = staged_forward(self, raw)
         else:
-            rgb = self._fused_forward(raw)
+            fuse = epilogue is not None and F_.epilogue_supported(raw, self) and \
+                not ((epilogue[2] & 1) and raw.shape[-1] != raw.shape[-2])
+            rgb = self._fused_forward(raw, epilogue if fuse else None)
             d['stages'] = _LazyStages(self, raw)
+            if fuse:
+                epilogue = None
+        if epilogue is not None:
+            from ..augmentation import flip_rot
+            rgb = flip_rot(rgb, *epilogue)
 
         if self.track_stages and raw.requires_grad:
             for stage in self.stages.values():
@@ -305,7 +317,7 @@ class ParametrizedProcessing(nn.Module):
 
         return rgb
 
-    def _fused_forward(self, raw):
+    def _fused_forward(self, raw, epilogue=None):
         bn = self.batch_norm
         if bn is None:
             mode = F_.BN_NONE
@@ -313,4 +325,4 @@ class ParametrizedProcessing(nn.Module):
             mode = F_.BN_TRAIN      # batch statistics; running statistics are updated on the device
         else:
             mode = F_.BN_EVAL
-        return F_.isp_fused(raw, self, mode, self.process_group)
+        return F_.isp_fused(raw, self, mode, self.process_group, epilogue)

@@ -599,6 +599,90 @@ def check_aux_losses(golden, device):
     assert all(p.grad is None for p in p_def.parameters())
 
 
+def check_output_epilogue(device):
+    """the weak augmentation as the forward's OUTPUT EPILOGUE (R2L_STEP_EPI_*): the fused
+    kernels write rot90^k(vflip(hflip(out))) themselves and the backward reads grad_out through the same map.  Against the
+    two-kernel form -- processor, then the permutation kernel (itself pinned to torch's flip / rot90 above) -- outputs and
+    all parameter gradients BIT FOR BIT, on frames that take the row-streaming forward and on a ragged width (tile
+    kernels), float32 frames and 16-bit containers, with and without train-mode BatchNorm; and through
+    ComposeState.arm(), the one-line hook of model.py:77-81, with the reference's seeded draws."""
+    import copy
+    from raw2logit_amd import augmentation as aug
+    worst_bn = 0.0
+    for (B, H, W), frames in (((2, 64, 64), 'f32'), ((1, 40, 72), 'f32'), ((2, 24, 264), 'u16'), ((1, 30, 30), 'f32'),
+                              ((1, 36, 70), 'f32')):
+        u = np.rint(orc.synth_raw(B, H, W, seed=H + W, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
+        raw = torch.from_numpy(u.view(np.int16) if frames == 'u16' else u.astype(np.float32) / np.float32(4095)).to(device)
+        P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+        P.perturb(3)
+        for bn in (True, False):
+            case = dict(camera='drone', track=False, additive=False, training=True, bn=bn)
+            for h in (False, True):
+                for v in (False, True):
+                    for k in range(4):
+                        if (k & 1) and H != W:
+                            continue
+                        if not (h or v or k):
+                            continue
+                        m1, m2 = make_module(case, P, device), make_module(case, P, device)
+                        m1.raw_bits = m2.raw_bits = 12
+                        y1 = aug.flip_rot(m1(raw), h, v, k)
+                        m2.__dict__['_epilogue'] = (h, v, k)
+                        y2 = m2(raw)
+                        assert '_epilogue' not in m2.__dict__                      # one shot
+                        assert tuple(y1.shape) == tuple(y2.shape) and torch.equal(y1, y2), ((B, H, W), frames, bn, h, v, k)
+                        cot = torch.from_numpy(np.random.default_rng(k).standard_normal(tuple(y1.shape)).astype(np.float32)).to(device)
+                        y1.backward(cot)
+                        y2.backward(cot)
+                        for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+                            if bn:
+                                # the BatchNorm backward sums (sum g, sum g * xhat) run over grad_out and the saved
+                                # output element by element: in the augmented layout the same products are added in
+                                # another order -- float32 round-off of those two means, nothing else
+                                d, sc = (p1.grad - p2.grad).abs().max().item(), p1.grad.abs().max().item() + 1e-6
+                                worst_bn = max(worst_bn, d / sc)
+                                assert d <= 1e-4 * sc, ((B, H, W), frames, bn, h, v, k, n, d, sc)
+                            else:
+                                assert torch.equal(p1.grad, p2.grad), ((B, H, W), frames, bn, h, v, k, n)
+                        if bn:
+                            assert torch.equal(m1.batch_norm.running_mean, m2.batch_norm.running_mean)
+    report('augmentation/output epilogue vs processor + permutation kernel: outputs and gradients bit-identical; gradients '
+           'under train-mode BatchNorm (relative)', worst_bn, 1e-4)
+    # ComposeState.arm(): the reference's draws, made before the processor call
+    raw = torch.from_numpy(orc.synth_raw(2, 32, 32, seed=9, kind='scene')).to(device)
+    case = dict(camera='drone', track=False, additive=False, training=True, bn=True)
+    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+    for seed in range(8):
+        m1, m2 = make_module(case, P, device), make_module(case, P, device)
+        w1, w2 = aug.get_augmentation('weak'), copy.deepcopy(aug.get_augmentation('weak'))
+        # classification (model.py:77-81 with retain_state=False): the draws follow the global seed
+        aug.set_global_seed(seed)
+        ref = w1(m1(raw))
+        aug.set_global_seed(seed)
+        assert w2.arm(m2)
+        x = m2(raw)
+        got = w2(x)                                          # returns its argument: the epilogue did the moves
+        assert got is x and torch.equal(got, ref), seed
+        # segmentation (retain_state=True: the call draws a fresh seed with torch.seed() and keeps it for the mask call)
+        ref = w1(m1(raw), retain_state=True)
+        seed_used = w1.seed
+        ref_mask = w1(raw, mask_transform=True)
+        w2.seed = seed_used                                  # the same state the reference's call left behind
+        assert w2.arm(m2, retain_state=True)
+        x = m2(raw)
+        got = w2(x, retain_state=True)
+        assert got is x and torch.equal(got, ref), seed
+        assert torch.equal(w2(raw, mask_transform=True), ref_mask) and w2.seed is None
+    # a transform list that is not one permutation is not armed (and the draws are left untouched)
+    w3 = aug.ComposeState([aug.RandomRotate90(), aug.RandomHorizontalFlip(p=1.0)])
+    m3 = make_module(case, P, device)
+    aug.set_global_seed(3)
+    state = torch.random.get_rng_state()
+    armed = w3.arm(m3)
+    assert armed or (torch.equal(state, torch.random.get_rng_state()) and '_epilogue' not in m3.__dict__)
+    assert not aug.ComposeState([aug.AddGaussianNoise(0.1)]).arm(make_module(case, P, device))
+
+
 def check_augmentation(device):
     """utils/augmentation.py weak set: the fused flip/rot90 kernel against the torch ops the reference composes
     (x.flip / x.rot90(k, dims=(-1, -2))), its VJP against autograd through those ops, and ComposeState's
@@ -653,6 +737,7 @@ def check_augmentation(device):
         aug.set_global_seed(seed_used)
         assert torch.equal(gm.cpu(), eager(mask.cpu()))
     assert len(seen) == 2            # both orientations occurred
+    check_output_epilogue(device)
     # AddGaussianNoise: the deviates are generated inside the kernel (Philox4x32-10 + Box-Muller) -- against the
     # oracle's restatement of the same counter-based generator, element by element, for odd sizes and offsets
     for shape, seed, off in (((2, 3, 17, 23), 12345, 0), ((1, 3, 64, 64), 2 ** 61 + 7, 5), ((7,), 1, 2 ** 40)):
