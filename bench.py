@@ -42,7 +42,9 @@ PREROLL_S = float(os.environ.get('R2L_BENCH_PREROLL_S', '0.3'))   # untimed pre-
 # algorithmic HBM bytes per raw pixel of each kernel family, by kernel-name prefix; the
 # `_u16` instantiations (16-bit containers) read 2 B/px less raw
 ALGO_BYTES_PER_PX = (
-    ('r2l_launch_fwd', 16.0),        # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0); tile or row-streaming
+    ('r2l_launch_fwd_apply', 20.0),  # apply pass on the kept luma plane: raw 4 + Y' 4 in, RGB 12 out
+    ('r2l_launch_fwd', 16.0),        # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0 -- or Y', 4, when the
+                                     # backward / the apply pass will read it); tile or row-streaming
     ('r2l_launch_bwd1', 20.0),       # raw 4 + grad_out 12 in, dL/dY'' 4 out
     ('r2l_launch_bwd2', 8.0),        # raw 4 + dL/dY'' 4 in
     ('r2l_launch_bn_reduce', 24.0),  # grad_out 12 + saved output 12 in
@@ -639,9 +641,12 @@ def main():
             dom = max(total, key=total.get)
             avg_us = cand[dom]['avg_us']
             bpp = algo_bytes_per_px(dom)
-            if dom.startswith('r2l_launch_fwd') and cand[dom]['launches'] == 2 * args.steps:
-                # two launches per step: stats-only (raw only) and apply (raw + 12 B/px out): average bytes
-                bpp = ((bpp - 12.0) + bpp) / 2
+            if dom.startswith('r2l_launch_fwd') and not dom.startswith('r2l_launch_fwd_apply'):
+                if cand[dom]['launches'] == 2 * args.steps:
+                    # two launches per step: stats-only (raw only) and apply (raw + 12 B/px out): average bytes
+                    bpp = ((bpp - 12.0) + bpp) / 2
+                elif any(k.startswith('r2l_launch_fwd_apply') for k in cand):
+                    bpp = bpp - 12.0 + 4.0   # the statistics pass alone: raw in, the kept luma plane out
             achieved = B * S * S * bpp / (avg_us * 1e-6) / 1e9
             traffic, source = pmc_traffic(dom, B, S) if not args.raw_u16 else \
                 (None, 'no PMC profile for 16-bit containers')

@@ -195,6 +195,16 @@ R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w1_u16, 1, true)
 R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w2_u16, 2, true)
 R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w4_u16, 4, true)
 R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w8_u16, 8, true)
+// the apply pass of train-mode BatchNorm on the Y' plane the statistics pass kept: independent wavefronts, no LDS
+#ifndef R2L_FA_OCC
+#define R2L_FA_OCC 3
+#endif
+#define R2L_FA_KERNEL(name, U16, EPI) \
+  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, 64, 4, R2L_FA_OCC, r2l_fwd_apply_block<U16, EPI>)
+R2L_FA_KERNEL(r2l_launch_fwd_apply, false, false)
+R2L_FA_KERNEL(r2l_launch_fwd_apply_u16, true, false)
+R2L_FA_KERNEL(r2l_launch_fwd_apply_epi, false, true)
+R2L_FA_KERNEL(r2l_launch_fwd_apply_epi_u16, true, true)
 #endif
 R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, false>)
 R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, false>)
@@ -481,6 +491,9 @@ static int r2l_check_raw(const R2LRaw& raw, int W, const char* who) {
   return 0;
 }
 
+// internal flag of r2l_isp_fwd_impl (r2l_isp_step_fwd sets it): the workspace's Y' plane is this batch's, written by the
+// statistics pass with R2L_F_KEEP_LUMA -- the apply pass reads it instead of computing it again
+#define R2L_F_LUMA_VALID 1024
 // where the row-streaming forward (r2l_param_stream.h) runs -- and with R2L_F_KEEP_LUMA leaves Y' for kernel B1
 static bool r2l_fwd_streams(const float* additive, int W) {
 #ifdef R2L_EMUL
@@ -518,7 +531,8 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     fa.F = ws.folded;
     fa.bn = bn_mean_istd;
     fa.out = out;
-    fa.yp_out = (out && (flags & R2L_F_KEEP_LUMA)) ? ws.yp : nullptr;
+    fa.yp_out = (flags & R2L_F_KEEP_LUMA) ? ws.yp : nullptr;  // (the statistics pass keeps it for the apply pass too)
+    fa.yp_in = nullptr;
     fa.stat_partial = stats ? ws.part_small : nullptr;
     fa.B = B;
     fa.H = H;
@@ -558,6 +572,36 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
           r2l_launch_fwd_stream_epi_w8_u16}}};
     const bool epi = ep && ep->on && out;
     fa.ep = epi ? *ep : R2LEpi{0, 0, 0, 0};
+    if (out && !stats && (flags & R2L_F_KEEP_LUMA) && (flags & R2L_F_LUMA_VALID) && !r2l_env_int("R2L_FWD_APPLY_RECOMPUTE", 0)) {
+      // apply pass on the kept Y' (r2l_fwd_apply_block): one wavefront per (image, band, 256-column strip)
+      fa.yp_in = ws.yp;
+      fa.yp_out = nullptr;
+      fa.stat_partial = nullptr;
+      // band height, a multiple of 6 (bands start on multiples of 6 rows): the one that needs the fewest rounds of resident
+      // wavefronts (256 CUs x 4 SIMDs x R2L_FA_OCC) x the rows a wavefront walks (+ 4 warm-up steps that only load, + its
+      // start) -- 64x512x512: 24 rows = 2,816 wavefronts, one round (65 us; 18 rows = 3,712 wavefronts: 68.5 us; 12: 67.5;
+      // 36: 71.5; profiles/r03_apply_kept.txt); 64x256x256: 6 rows
+      const long nstrip = (W + 255) / 256, slots = 256L * 4 * R2L_FA_OCC;
+      int bh = 6;
+      long best = -1;
+      for (int c = 6; c <= 48; c += 6) {
+        const long items = (long)B * nstrip * ((H + c - 1) / c);
+        const long cost = ((items + slots - 1) / slots) * (10L * c + 32);
+        if (best < 0 || cost < best) {
+          best = cost;
+          bh = c;
+        }
+      }
+      bh = (r2l_env_int("R2L_FA_BAND", bh) + 5) / 6 * 6;
+      fa.band_h = bh;
+      fa.nband = (H + bh - 1) / bh;
+      const long grid = (long)B * fa.nband * nstrip;
+      if (grid > (1L << 30)) return r2l_fail(-1, "r2l_isp_fwd: batch too large");
+      fa.nitems = (int)grid;
+      static const launch_t atable[2][2] = {{r2l_launch_fwd_apply, r2l_launch_fwd_apply_u16},
+                                            {r2l_launch_fwd_apply_epi, r2l_launch_fwd_apply_epi_u16}};
+      return atable[epi ? 1 : 0][raw.u16 ? 1 : 0](fa, (int)grid, stream);
+    }
     return table[epi ? 1 : 0][raw.u16 ? 1 : 0][nw](fa, sgrid, stream);
   }
 #endif
@@ -821,7 +865,7 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
     // statistics pass; one rank: the last workgroup also does the BatchNorm bookkeeping
     R2LBnFinalizeArgs f{ws.stats, 1, ws.bn, ws.moments, running_mean, running_var, eps, momentum, num_batches_tracked};
     if (int e = r2l_isp_fwd_impl(rw, ws.packed, additive, nullptr, nullptr, ws.stats, workspace, workspace_bytes, B, H,
-                                 W, R2L_F_STATS_ONLY | R2L_F_FOLDED_VALID, stream, phase == R2L_STEP_ALL ? &f : nullptr))
+                                 W, R2L_F_STATS_ONLY | R2L_F_FOLDED_VALID | keep, stream, phase == R2L_STEP_ALL ? &f : nullptr))
       return e;
     if (phase == R2L_STEP_A) return 0;
   }
@@ -830,8 +874,11 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
                         num_batches_tracked};
     if (int e = r2l_launch_bn_finalize(f, 1, stream)) return e;
   }
+  // (train mode: the statistics pass of this call -- or of phase A of this step -- has kept Y' if `keep` is set)
   return r2l_isp_fwd_impl(rw, ws.packed, additive, bn_mode == R2L_BN_NONE ? nullptr : ws.bn, out, nullptr, workspace,
-                          workspace_bytes, B, H, W, R2L_F_FOLDED_VALID | keep, stream, nullptr, &ep);
+                          workspace_bytes, B, H, W,
+                          R2L_F_FOLDED_VALID | keep | ((keep && bn_mode == R2L_BN_TRAIN) ? R2L_F_LUMA_VALID : 0), stream,
+                          nullptr, &ep);
 }
 int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* additive, const float* grad_out,
                      const float* out, float* grad_params, float* grad_additive, int bn_mode, void* workspace,
@@ -1196,7 +1243,7 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
                 const float* bn_mean_istd, float* out, double* stats, void* workspace,
                 size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
   return r2l_isp_fwd_impl(r2l_raw_f32(raw), params, additive, bn_mean_istd, out, stats, workspace, workspace_bytes,
-                          B, H, W, flags, stream);
+                          B, H, W, flags & ~R2L_F_LUMA_VALID, stream);
 }
 // statistics pass + BatchNorm bookkeeping in one launch (one rank: no exchange between the two)
 static int r2l_isp_fwd_stats_bn_impl(const R2LRaw& raw, const float* params, const float* additive, double* stats,
@@ -1230,7 +1277,7 @@ int r2l_isp_fwd_u16(const unsigned short* raw, float denom, const float* params,
                     const float* bn_mean_istd, float* out, double* stats, void* workspace,
                     size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
   return r2l_isp_fwd_impl(r2l_raw_u16(raw, denom), params, additive, bn_mean_istd, out, stats, workspace,
-                          workspace_bytes, B, H, W, flags, stream);
+                          workspace_bytes, B, H, W, flags & ~R2L_F_LUMA_VALID, stream);
 }
 int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
                 const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,

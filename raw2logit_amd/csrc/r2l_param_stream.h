@@ -30,7 +30,8 @@ struct R2LFwdStreamArgs {
   const R2LFolded* F;
   const float* bn;      // mean[3], istd[3] or null
   float* out;           // (B,3,H,W) or null (statistics only)
-  float* yp_out;        // (B,H,W) or null: the sharpened luma Y', kept for the backward (written with `out`)
+  float* yp_out;        // (B,H,W) or null: the sharpened luma Y', kept for the backward and for the apply pass
+  const float* yp_in;   // r2l_fwd_apply_block: the plane an earlier pass kept
   float* stat_partial;  // [12][nblk] or null: (high, low) float32 halves of the workgroups' float64 totals
   int B, H, W;
   int nband, band_h, nitems;  // work item = (image, band); workgroup bid takes items bid, bid + nblk, ...
@@ -140,6 +141,65 @@ R2L_HD void r2l_fs_stencil_parity(const float* r0, const float* r1, const float*
     const r2l_p2 wy = r2l_mk2(w[i * 3 + j][0], w[i * 3 + j][1]);
     R2L_PRAGMA_UNROLL
     for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(wy, r2l_mk2(rows[i][2 * p + j], rows[i][2 * p + j + 1]), o[p]);
+  }
+}
+
+// the colour code of one output row (:203-217): Y'', U, V of the lane's 4 pixels -> RGB, clip, gamma, [statistics about the
+// lane's pivot], [BatchNorm], store (EPI: at the augmented position, R2LEpi)
+template <bool EPI, bool STATS>
+R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc, float* piv, const r2l_p2 ypp[2],
+                          const r2l_p2 u[2], const r2l_p2 v[2], int y, int y0, int x0, float* ob, unsigned plane,
+                          bool store_ok, const float mean[3], const float istd[3]) {
+  const unsigned off0 = (unsigned)y * (unsigned)a.W + (unsigned)x0;
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) {
+    r2l_p2 x[2];
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) {
+      r2l_p2 rgb = r2l_pmul(r2l_splat2(F.M2[k * 3]), ypp[p]);
+      rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 1]), u[p], rgb);
+      rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 2]), v[p], rgb);
+      const r2l_p2 lg = r2l_mk2(r2l_log2(fminf(fmaxf(rgb[0], 1e-5f), 1.0f)),     // :206
+                                r2l_log2(fminf(fmaxf(rgb[1], 1e-5f), 1.0f)));
+      const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));                    // :209
+      x[p] = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
+      if (STATS && a.stat_partial && store_ok) {
+        if (p == 0) piv[k] = (y == y0) ? x[0][0] : piv[k];
+        const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-piv[k]));
+        acc[k] = r2l_padd(acc[k], d);
+        acc[3 + k] = r2l_pfma(d, d, acc[3 + k]);
+      }
+    }
+    if (ob && store_ok) {
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p)
+        x[p] = r2l_pmul(r2l_padd(x[p], r2l_splat2(-mean[k])), r2l_splat2(istd[k]));  // :217
+      r2l_f4 s4;
+      s4.x = x[0][0];
+      s4.y = x[0][1];
+      s4.z = x[1][0];
+      s4.w = x[1][1];
+      if (!EPI) {
+        *(r2l_f4*)(ob + (unsigned)k * plane + off0) = s4;
+      } else {  // the augmented position of this lane's 4 pixels (R2LEpi)
+        float* o = ob + (unsigned)k * plane + (a.ep.s0 + a.ep.sr * y + a.ep.sc * x0);
+        if (a.ep.sc == 1) {
+          *(r2l_f4*)o = s4;
+        } else if (a.ep.sc == -1) {
+          r2l_f4 r4;
+          r4.x = s4.w;
+          r4.y = s4.z;
+          r4.z = s4.y;
+          r4.w = s4.x;
+          *(r2l_f4*)(o - 3) = r4;
+        } else {
+          o[0] = s4.x;
+          o[a.ep.sc] = s4.y;
+          o[2 * a.ep.sc] = s4.z;
+          o[3 * a.ep.sc] = s4.w;
+        }
+      }
+    }
   }
 }
 
@@ -273,57 +333,8 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
     const r2l_f4* f = fifo + ((K + 2) % R2L_FS_FIFO_ROWS) * 2 * 64 + lane;  // row q-4
     const r2l_f4 fu = f[0], fv = f[64];
     const r2l_p2 u[2] = {r2l_mk2(fu.x, fu.y), r2l_mk2(fu.z, fu.w)}, v[2] = {r2l_mk2(fv.x, fv.y), r2l_mk2(fv.z, fv.w)};
+    r2l_fs_colour<EPI, true>(a, F, st.acc, st.piv, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd);
     const unsigned off0 = (unsigned)y * (unsigned)a.W + (unsigned)x0;
-    R2L_PRAGMA_UNROLL
-    for (int k = 0; k < 3; ++k) {
-      r2l_p2 x[2];
-      R2L_PRAGMA_UNROLL
-      for (int p = 0; p < 2; ++p) {
-        r2l_p2 rgb = r2l_pmul(r2l_splat2(F.M2[k * 3]), ypp[p]);
-        rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 1]), u[p], rgb);
-        rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 2]), v[p], rgb);
-        const r2l_p2 lg = r2l_mk2(r2l_log2(fminf(fmaxf(rgb[0], 1e-5f), 1.0f)),     // :206
-                                  r2l_log2(fminf(fmaxf(rgb[1], 1e-5f), 1.0f)));
-        const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));                    // :209
-        x[p] = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
-        if (a.stat_partial && store_ok) {
-          if (p == 0) st.piv[k] = (y == y0) ? x[0][0] : st.piv[k];
-          const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-st.piv[k]));
-          st.acc[k] = r2l_padd(st.acc[k], d);
-          st.acc[3 + k] = r2l_pfma(d, d, st.acc[3 + k]);
-        }
-      }
-      if (ob && store_ok) {
-        R2L_PRAGMA_UNROLL
-        for (int p = 0; p < 2; ++p)
-          x[p] = r2l_pmul(r2l_padd(x[p], r2l_splat2(-mean[k])), r2l_splat2(istd[k]));  // :217
-        r2l_f4 s4;
-        s4.x = x[0][0];
-        s4.y = x[0][1];
-        s4.z = x[1][0];
-        s4.w = x[1][1];
-        if (!EPI) {
-          *(r2l_f4*)(ob + (unsigned)k * plane + off0) = s4;
-        } else {  // the augmented position of this lane's 4 pixels (R2LEpi)
-          float* o = ob + (unsigned)k * plane + (a.ep.s0 + a.ep.sr * y + a.ep.sc * x0);
-          if (a.ep.sc == 1) {
-            *(r2l_f4*)o = s4;
-          } else if (a.ep.sc == -1) {
-            r2l_f4 r4;
-            r4.x = s4.w;
-            r4.y = s4.z;
-            r4.z = s4.y;
-            r4.w = s4.x;
-            *(r2l_f4*)(o - 3) = r4;
-          } else {
-            o[0] = s4.x;
-            o[a.ep.sc] = s4.y;
-            o[2 * a.ep.sc] = s4.z;
-            o[3 * a.ep.sc] = s4.w;
-          }
-        }
-      }
-    }
     // Y'(y), kept for kernel B1 of the backward: the middle row of the blur's window, stored last (the step's
     // registers are free here; next to the sharpen, or in front of the colour code, the kernel spills)
     if (ypb && store_ok) {
@@ -382,7 +393,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
     const size_t img = (size_t)b * plane;
     float* ob = a.out ? a.out + (size_t)b * 3 * plane : nullptr;
-    float* ypb = (a.out && a.yp_out) ? a.yp_out + (size_t)b * plane : nullptr;
+    float* ypb = a.yp_out ? a.yp_out + (size_t)b * plane : nullptr;
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 6; ++i) st.acc[i] = r2l_splat2(0.f);
     st.piv[0] = st.piv[1] = st.piv[2] = 0.5f;
@@ -499,6 +510,177 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
       }
     }
   }
+}
+
+
+// ================================================================================================
+// The APPLY pass of train-mode BatchNorm when the statistics pass has kept Y' (R2L_F_KEEP_LUMA): everything in front of
+// the blur is already there, so the second pass over the batch is  out = BN(gamma(M * (blur5x5(Y'), U, V)))  with (U, V)
+// the 3x3 chroma stencils of the raw frame -- no luma stencil, no sharpen, no halo rows to re-compute (a band re-READS 4
+// rows of Y' and 2 raw rows, nothing else), no strip-edge exchange: the neighbour columns of a strip's first and last
+// lane are two 8-byte loads.  Wavefronts are independent (one per workgroup, no LDS, no barrier); a wavefront owns
+// (image, 256-column strip, band of rows) and walks down the band with V (3 rows x 6) and Y' (6-slot ring x 8) in
+// registers.  The arithmetic of an output row is the streaming kernel's, function by function (r2l_fs_stencil_parity,
+// r2l_blur_row2w with the same edge weight sets, r2l_fs_colour), on the same Y' values: the two apply passes agree bit
+// for bit (tests/test_gpu_parity.py: test_apply_pass_reads_the_luma_plane_the_statistics_pass_kept).  20 B/px of traffic
+// (4 raw + 4 Y' + 12 out) against 16 B/px and 31 % fewer vector instructions (16.5 M against 23.9 M per launch at
+// 64x512x512): the pass is bound by its HBM traffic -- 65 us = 5.1 TB/s; 29 us with the stores taken out, 44 us with the
+// loads taken out (profiles/r03_apply_kept.txt) -- where the streaming apply pass is bound by instruction issue (72.5 us).
+struct R2LFaStage {  // one Y' row in flight: the lane's 4 values + the pair beyond the strip edge (first / last lane)
+  r2l_f4 c;
+  r2l_f2 e;
+};
+// The fetches are BRANCH-FREE (every lane loads an edge value from an in-row address; only the first and last lane use
+// theirs) and the loop below has no conditional memory operation but the predicated stores: hipcc's s_waitcnt insertion
+// then knows how many younger loads follow the row a step consumes and waits with vmcnt(4 (PF - 1)) -- with a conditional
+// fetch or a conditionally executed step anywhere in the loop it falls back to vmcnt(0), which waits for the loads just
+// issued AND for the output stores of the previous row (measured: 2,000 stall cycles per row step, twice its issue time).
+template <bool U16>
+R2L_HD void r2l_fa_fetch_raw(const R2LFwdStreamArgs& a, size_t img0, int ym, int x0, bool le, bool re, int lane,
+                             R2LFsStage& s) {
+  const size_t e = img0 + (size_t)ym * a.W + x0;
+  const int eo = (lane < 32) ? (le ? 0 : -1) : (re ? 3 : 4);
+  s.ym = ym;
+  if (U16) {
+    const unsigned short* r = a.raw.u16 + e;
+    const r2l_f2 b = *(const r2l_f2*)r;
+    s.c.x = b.x;
+    s.c.y = b.y;
+    s.e = r2l_u2f((unsigned)r[eo]);
+  } else {
+    const float* r = a.raw.f32 + e;
+    s.c = r2l_stream_load_f4(r);
+    s.e = r[eo];
+  }
+}
+R2L_HD void r2l_fa_fetch(const float* ypimg, int r, int H, int W, int x0, bool le, bool re, int lane, R2LFaStage& s) {
+  const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);  // rows outside the image are zeroed when the row is built
+  const float* p = ypimg + (size_t)rc * W + x0;
+  const int eo = (lane < 32) ? (le ? 0 : -2) : (re ? 2 : 4);
+  s.c = r2l_stream_load_f4(p);
+  s.e = *(const r2l_f2*)(p + eo);
+}
+// staged row -> 8 values, columns x0-2 .. x0+5 (mirror padding of the blur at the image edges, :165 reflect)
+R2L_HD void r2l_fa_build(const R2LFaStage& s, bool rin, bool le, bool re, float o[8]) {
+  const float c0 = rin ? s.c.x : 0.f, c1 = rin ? s.c.y : 0.f, c2 = rin ? s.c.z : 0.f, c3 = rin ? s.c.w : 0.f;
+  const float e0 = rin ? s.e.x : 0.f, e1 = rin ? s.e.y : 0.f;
+  const float l2 = r2l_wshr(c2, e0), l1 = r2l_wshr(c3, e1);
+  const float r1 = r2l_wshl(c0, e0), r2 = r2l_wshl(c1, e1);
+  o[0] = le ? c2 : l2;
+  o[1] = le ? c1 : l1;
+  o[2] = c0;
+  o[3] = c1;
+  o[4] = c2;
+  o[5] = c3;
+  o[6] = re ? c2 : r1;
+  o[7] = re ? c1 : r2;
+}
+struct R2LFaState {
+  float v[3][6];   // V rows (slot = row mod 3)
+  float yp[6][8];  // Y' rows (slot = row mod 6)
+};
+template <int K, bool EPI>
+R2L_HD void r2l_fa_step(const R2LFwdStreamArgs& a, R2LFaState& st, int y, int y0, bool store_ok, float* ob,
+                        unsigned plane, int x0, const float mean[3], const float istd[3]) {
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
+  R2LFoldedRef Fh = R2L_FOLDED_REF(a.F);
+  constexpr int PY = K & 1;
+  const int H = a.H;
+  const float* vu = st.v[(K + 2) % 3];  // V(y-1)
+  const float* vm = st.v[K % 3];        // V(y)
+  const float* vl = st.v[(K + 1) % 3];  // V(y+1)
+  r2l_p2 u[2], v[2], ypp[2];
+  r2l_fs_stencil_parity(vu, vm, vl, F.AU2[PY], u);
+  r2l_fs_stencil_parity(vu, vm, vl, F.AV2[PY], v);
+  {
+    float yw[5][8];  // window rows y-2 .. y+2 sit in ring slots K+4 .. K+8
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 5; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 8; ++j) yw[i][j] = st.yp[(K + 4 + i) % 6][j];
+    const int set = (y < 2) ? y : (y - (H - 2)) + 2;
+    const __attribute__((address_space(4))) float* w25 =
+        (y >= 2 && y < H - 2) ? &Fh.blur[0] : &F.blur_edge[0][0] + 25 * set;
+    r2l_blur_row2w(yw, w25, ypp);
+  }
+  r2l_fs_colour<EPI, false>(a, F, nullptr, nullptr, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd);
+}
+
+#ifndef R2L_FA_PF
+#define R2L_FA_PF 2
+#endif
+
+template <bool U16, bool EPI>
+R2L_BLOCKFN void r2l_fwd_apply_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
+  (void)lds;
+  (void)nblk;
+  const int lane = threadIdx.x & 63;
+  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
+  // work item = (image, band, strip), strips fastest: neighbouring workgroup ids share halo rows and strip edges
+  const int nstrip = (a.W + 255) >> 8;
+  const int strip = bid % nstrip, ib = bid / nstrip;
+  const int band = ib % a.nband, b = ib / a.nband;
+  const int xs = strip * 256 + 4 * lane;
+  const bool in_w = xs < a.W;
+  const int x0 = in_w ? xs : a.W - 4;
+  const bool le = x0 == 0, re = x0 + 4 >= a.W;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  float mean[3] = {0.f, 0.f, 0.f}, istd[3] = {1.f, 1.f, 1.f};
+  if (a.bn) {
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      mean[k] = a.bn[k];
+      istd[k] = a.bn[3 + k];
+    }
+  }
+  // bands start on multiples of 6 rows (the host rounds band_h): the ring slot of a row, row mod 6, is then the unroll
+  // position K of its step in every band, and the warm-up is the same four steps everywhere
+  const int y0 = band * a.band_h;
+  const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
+  const size_t img = (size_t)b * plane;
+  float* ob = a.out + (size_t)b * 3 * plane;
+  __builtin_assume(ob != nullptr);
+  const float* ypimg = a.yp_in + img;
+  R2LFaState st;
+  constexpr int PF = R2L_FA_PF;
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  R2LFsStage pf[PF];   // ring: step K consumes pf[K % PF] (raw row q + 1) and refills it with row q + 1 + PF
+  R2LFaStage pfy[PF];  // likewise Y' row q + 2
+  // step q builds V(q+1) and Y'(q+2); from q = y0 on it also finishes output row q.  Warm-up: q = y0-4 .. y0-1 = K 2 .. 5.
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i) {
+    r2l_fa_fetch_raw<U16>(a, img, r2l_mirror(y0 - 3 + i, a.H), x0, le, re, lane, pf[(2 + i) % PF]);
+    r2l_fa_fetch(ypimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
+  }
+#define R2L_FA_LOAD_STEP(K, q)                                                                          \
+  {                                                                                                     \
+    r2l_fs_convert<U16>(a, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3]);                               \
+    r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, st.yp[((K) + 2) % 6]);     \
+    r2l_fa_fetch_raw<U16>(a, img, r2l_mirror((q) + 1 + PF, a.H), x0, le, re, lane, pf[(K) % PF]);       \
+    r2l_fa_fetch(ypimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);                       \
+  }
+  R2L_FA_LOAD_STEP(2, y0 - 4)
+  R2L_FA_LOAD_STEP(3, y0 - 3)
+  R2L_FA_LOAD_STEP(4, y0 - 2)
+  R2L_FA_LOAD_STEP(5, y0 - 1)
+  // every group of 6 steps runs in full: rows past the band's end (last band of an image whose height is not a multiple
+  // of 6) are computed from clamped fetches and not stored
+  for (int qb = y0; qb < y1; qb += 6) {
+#define R2L_FA_STEP(K)                                                                                  \
+  {                                                                                                     \
+    const int q = qb + K;                                                                               \
+    R2L_FA_LOAD_STEP(K, q)                                                                              \
+    r2l_fa_step<K, EPI>(a, st, q, y0, in_w && q < y1, ob, plane, x0, mean, istd);                       \
+  }
+    R2L_FA_STEP(0)
+    R2L_FA_STEP(1)
+    R2L_FA_STEP(2)
+    R2L_FA_STEP(3)
+    R2L_FA_STEP(4)
+    R2L_FA_STEP(5)
+#undef R2L_FA_STEP
+  }
+#undef R2L_FA_LOAD_STEP
 }
 
 #endif  // !R2L_EMUL

@@ -75,6 +75,6 @@ PROBE(p_b1_rows2, 2, {
   t.ragged = false;
   r2l_bwd1_fetch_gout<G>(tid, a1, t, gp, 0);
   r2l_bwd1_fetch_gout<G>(tid, a1, t, gp, 1);
-  r2l_bwd1_pixels<G, false, false, true>(tid, V, P2, a1, t, gp, regs);
+  r2l_bwd1_pixels<G, false, false, true>(tid, V, P2, a1, t, gp, regs, [](int) {});
   for (int i = 0; i < R2L_L1_NACC; ++i) a1.partial[i * 512 + tid] = regs.acc[i][0] + regs.acc[i][1];
 })

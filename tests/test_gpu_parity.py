@@ -471,6 +471,65 @@ def test_backward_reads_the_luma_plane_the_forward_kept(shape, dev):
 
 
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
+                                   (5, 18, 8), (2, 514, 512), (3, 4, 4), (2, 6, 1024), (4, 256, 256)], ids=str)
+def test_apply_pass_reads_the_luma_plane_the_statistics_pass_kept(shape, dev):
+    """Train-mode BatchNorm with a backward to follow (R2L_F_KEEP_LUMA): the statistics pass keeps Y', and the apply pass
+    is r2l_fwd_apply_block -- blur, chroma, colour code on the kept plane, independent wavefronts -- instead of a second
+    run of the streaming forward.  Same arithmetic on the same Y' values: the output is BIT-identical to the streaming
+    apply pass of the diagnostic build (R2L_FWD_APPLY_RECOMPUTE), whatever the band height, for float32 and 16-bit
+    frames, with and without an output epilogue; the gradients behind it are the same bits too (kernel B1 reads the
+    same plane)."""
+    import os
+    from raw2logit_amd import augmentation as aug
+    B, H, W = shape
+    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+    P.perturb(13)
+    u = np.rint(orc.synth_raw(B, H, W, seed=H + W, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
+    cot = torch.from_numpy(np.random.default_rng(W).standard_normal((B, 3, H, W)).astype(np.float32)).to(dev)
+    case = dict(camera='drone', track=False, additive=False, training=True, bn=True)
+
+    def run(env, frames, epilogue=None):
+        m = pc.make_module(case, P, dev)
+        if frames == 'u16':
+            m.raw_bits = 12
+            raw = torch.from_numpy(u).to(dev)
+        else:
+            raw = torch.from_numpy(u.astype(np.float32) / np.float32(4095)).to(dev)
+        os.environ.update(env)
+        try:
+            with pc.launch_shape_overrides(dev):
+                if epilogue is not None:
+                    m.__dict__['_epilogue'] = epilogue
+                y = m(raw)
+                (y * (cot if epilogue is None else aug.flip_rot(cot, *epilogue))).sum().backward()
+        finally:
+            for k in env:
+                del os.environ[k]
+        return y.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    ref, gref = run({'R2L_FWD_APPLY_RECOMPUTE': '1'}, 'f32')
+    # the float64 oracle, so that "identical" is not "identically wrong"
+    o, _, c = orc.parametrized_forward(u.astype(np.float32) / np.float32(4095), P.astype(np.float64), bn=pc.oracle_bn(case))
+    tol = pc.out_tolerance(c, True)
+    for env, frames in (({}, 'f32'), ({}, 'u16'), ({'R2L_FA_BAND': '2'}, 'f32'), ({'R2L_FA_BAND': '6'}, 'u16'),
+                        ({'R2L_FA_BAND': '50'}, 'f32'), ({'R2L_FA_BAND': '1000'}, 'f32')):
+        y, g = run(env, frames)
+        assert torch.equal(y, ref), (shape, env, frames, (y - ref).abs().max().item())
+        for n in gref:
+            assert torch.equal(g[n], gref[n]), (shape, env, frames, n)
+        err = np.abs(y.cpu().numpy() - o)
+        assert np.all(err <= tol), (shape, env, frames, err.max())
+    pc.report(f'fwd-apply/{shape}/kept-luma apply pass vs streaming apply pass (bits differing)', 0.0, 0.0)
+    for epilogue in ((True, False, 0), (False, True, 2)) + (((True, True, 1), (False, False, 3)) if H == W else ()):
+        ye, ge = run({}, 'f32', epilogue)
+        yr, gr = run({'R2L_FWD_APPLY_RECOMPUTE': '1'}, 'f32', epilogue)
+        assert torch.equal(ye, yr), (shape, epilogue)
+        assert torch.equal(ye, aug.flip_rot(ref, *epilogue)), (shape, epilogue, 'vs permutation kernel')
+        for n in gr:
+            assert torch.equal(ge[n], gr[n]), (shape, epilogue, n)
+
+
+@pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
                                    (5, 18, 8), (2, 514, 512)], ids=str)
 def test_fused_forward_streaming_kernel(shape, dev):
     """the row-streaming forward (r2l_param_stream.h) on frames 1, 2, 4 and 8 wavefronts wide, several bands high,
