@@ -192,7 +192,8 @@ enum { R2L_STEP_KEEP_LUMA = 8 };
  * augmented layout ((B,3,W,H) for odd k, which needs H == W).  Not with an additive layer (error -3: use r2l_augment
  * on the plain output).  Bit-identical to r2l_augment(r2l_isp_step_fwd(...)).                                        */
 enum { R2L_STEP_EPI_HFLIP = 16, R2L_STEP_EPI_VFLIP = 32, R2L_STEP_EPI_ROT_SHIFT = 6 /* k << 6: bits 64, 128 */ };
-enum { R2L_STEP_STATS = 0, R2L_STEP_MOMENTS = 1, R2L_STEP_BN_SUMS = 2, R2L_STEP_PACKED = 3, R2L_STEP_BN = 4 };
+enum { R2L_STEP_STATS = 0, R2L_STEP_MOMENTS = 1, R2L_STEP_BN_SUMS = 2, R2L_STEP_PACKED = 3, R2L_STEP_BN = 4,
+       R2L_STEP_LUMA = 5 /* (B,H,W) float32: the sharpened luma plane Y' a train-mode / R2L_STEP_KEEP_LUMA forward leaves */ };
 size_t r2l_isp_step_offset(int which, int B, int H, int W); /* byte offset inside the workspace */
 int r2l_isp_step_fwd(const void *raw, int raw_u16, float denom, const float *const *params_host,
                      const float *additive, int bn_mode, float *running_mean, float *running_var,

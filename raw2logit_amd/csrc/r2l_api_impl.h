@@ -199,12 +199,32 @@ R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w8_u16, 8, true)
 #ifndef R2L_FA_OCC
 #define R2L_FA_OCC 3
 #endif
+#ifndef R2L_FA_NWV
+#define R2L_FA_NWV 4  // wavefronts (= work items) per workgroup of the apply and luma passes
+#endif
 #define R2L_FA_KERNEL(name, U16, EPI) \
-  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, 64, 4, R2L_FA_OCC, r2l_fwd_apply_block<U16, EPI>)
+  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, 64 * R2L_FA_NWV, 4, R2L_FA_OCC, r2l_fwd_apply_block<U16, EPI, false, R2L_FA_NWV>)
 R2L_FA_KERNEL(r2l_launch_fwd_apply, false, false)
 R2L_FA_KERNEL(r2l_launch_fwd_apply_u16, true, false)
 R2L_FA_KERNEL(r2l_launch_fwd_apply_epi, false, true)
 R2L_FA_KERNEL(r2l_launch_fwd_apply_epi_u16, true, true)
+// ... the same walk without output: the BatchNorm statistics from the kept plane (2 wavefronts per workgroup, each with
+// its own work items; <= R2L_MAX_BLOCKS workgroups = partials of the reduction tree)
+#define R2L_FA_STATS_NWV 4
+#ifndef R2L_FA_STATS_OCC
+#define R2L_FA_STATS_OCC 3
+#endif
+R2L_KERNEL_NT_LDS(r2l_launch_fwd_stats, R2LFwdStreamArgs, 64 * R2L_FA_STATS_NWV, R2L_FA_LDS_FLOATS(R2L_FA_STATS_NWV, true),
+                  R2L_FA_STATS_OCC, r2l_fwd_apply_block<false, false, true, R2L_FA_STATS_NWV>)
+R2L_KERNEL_NT_LDS(r2l_launch_fwd_stats_u16, R2LFwdStreamArgs, 64 * R2L_FA_STATS_NWV,
+                  R2L_FA_LDS_FLOATS(R2L_FA_STATS_NWV, true), R2L_FA_STATS_OCC,
+                  r2l_fwd_apply_block<true, false, true, R2L_FA_STATS_NWV>)
+// the luma pass in front of them: raw -> Y' (independent wavefronts, no LDS)
+#ifndef R2L_FL_OCC
+#define R2L_FL_OCC 4
+#endif
+R2L_KERNEL_NT_LDS(r2l_launch_fwd_luma, R2LFwdStreamArgs, 64 * R2L_FA_NWV, 4, R2L_FL_OCC, r2l_fwd_luma_block<false, R2L_FA_NWV>)
+R2L_KERNEL_NT_LDS(r2l_launch_fwd_luma_u16, R2LFwdStreamArgs, 64 * R2L_FA_NWV, 4, R2L_FL_OCC, r2l_fwd_luma_block<true, R2L_FA_NWV>)
 #endif
 R2L_KERNEL_V(r2l_launch_bwd1, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, false>)
 R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, false>)
@@ -494,6 +514,10 @@ static int r2l_check_raw(const R2LRaw& raw, int W, const char* who) {
 // internal flag of r2l_isp_fwd_impl (r2l_isp_step_fwd sets it): the workspace's Y' plane is this batch's, written by the
 // statistics pass with R2L_F_KEEP_LUMA -- the apply pass reads it instead of computing it again
 #define R2L_F_LUMA_VALID 1024
+// ... and of the statistics pass: luma pass (raw -> Y' into the workspace) + statistics from that plane, instead of the
+// streaming forward without output (r2l_isp_step_fwd sets it in train mode)
+#define R2L_F_SPLIT_STATS 2048
+#define R2L_F_INTERNAL (R2L_F_LUMA_VALID | R2L_F_SPLIT_STATS)
 // where the row-streaming forward (r2l_param_stream.h) runs -- and with R2L_F_KEEP_LUMA leaves Y' for kernel B1
 static bool r2l_fwd_streams(const float* additive, int W) {
 #ifdef R2L_EMUL
@@ -512,6 +536,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
   if (!params || !workspace) return r2l_fail(-1, "r2l_isp_fwd: null pointer");
   if (additive && (H != 256 || W != 256))
     return r2l_fail(-1, "additive_layer is (1,3,256,256): needs 256x256 frames");
+  if (r2l_env_int("R2L_FORCE_SPLIT", 0)) flags |= R2L_F_INTERNAL;  // (diagnostic builds: tests/timeline_fwd.py)
   const bool stats_only = (flags & R2L_F_STATS_ONLY) != 0;
   if (stats_only) out = nullptr;
   if (!out && !stats) return r2l_fail(-1, "r2l_isp_fwd: nothing to compute (no out, no stats)");
@@ -531,8 +556,12 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     fa.F = ws.folded;
     fa.bn = bn_mean_istd;
     fa.out = out;
-    fa.yp_out = (flags & R2L_F_KEEP_LUMA) ? ws.yp : nullptr;  // (the statistics pass keeps it for the apply pass too)
+    // (a statistics pass of the streaming kernel keeps Y' too: for kernel B1 and for the apply pass)
+    fa.yp_out = (flags & (R2L_F_KEEP_LUMA | R2L_F_SPLIT_STATS)) ? ws.yp : nullptr;
     fa.yp_in = nullptr;
+#ifdef R2L_EXP_STAMPS
+    fa.tl = nullptr;
+#endif
     fa.stat_partial = stats ? ws.part_small : nullptr;
     fa.B = B;
     fa.H = H;
@@ -572,16 +601,13 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
           r2l_launch_fwd_stream_epi_w8_u16}}};
     const bool epi = ep && ep->on && out;
     fa.ep = epi ? *ep : R2LEpi{0, 0, 0, 0};
-    if (out && !stats && (flags & R2L_F_KEEP_LUMA) && (flags & R2L_F_LUMA_VALID) && !r2l_env_int("R2L_FWD_APPLY_RECOMPUTE", 0)) {
-      // apply pass on the kept Y' (r2l_fwd_apply_block): one wavefront per (image, band, 256-column strip)
-      fa.yp_in = ws.yp;
-      fa.yp_out = nullptr;
-      fa.stat_partial = nullptr;
-      // band height, a multiple of 6 (bands start on multiples of 6 rows): the one that needs the fewest rounds of resident
-      // wavefronts (256 CUs x 4 SIMDs x R2L_FA_OCC) x the rows a wavefront walks (+ 4 warm-up steps that only load, + its
-      // start) -- 64x512x512: 24 rows = 2,816 wavefronts, one round (65 us; 18 rows = 3,712 wavefronts: 68.5 us; 12: 67.5;
-      // 36: 71.5; profiles/r03_apply_kept.txt); 64x256x256: 6 rows
-      const long nstrip = (W + 255) / 256, slots = 256L * 4 * R2L_FA_OCC;
+    // The passes on the kept luma plane (r2l_param_stream.h: r2l_fwd_luma_block, r2l_fwd_apply_block): independent
+    // wavefronts, one per (image, band, 256-column strip).  Band height, a multiple of 6 (bands start on multiples of 6
+    // rows): the one that needs the fewest rounds of resident wavefronts x the rows a wavefront walks (+ 4 warm-up steps
+    // that only load, + its start) -- 64x512x512 apply pass: 24 rows = 2,816 wavefronts, one round at 3 per SIMD (65 us;
+    // 18 rows = 3,712 wavefronts: 68.5 us; 12: 67.5; 36: 71.5; profiles/r03_apply_kept.txt); 64x256x256: 6 rows
+    const long nstrip = (W + 255) / 256;
+    auto band_rows = [&](long slots, const char* env) {
       int bh = 6;
       long best = -1;
       for (int c = 6; c <= 48; c += 6) {
@@ -592,15 +618,57 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
           bh = c;
         }
       }
-      bh = (r2l_env_int("R2L_FA_BAND", bh) + 5) / 6 * 6;
-      fa.band_h = bh;
-      fa.nband = (H + bh - 1) / bh;
+      return (r2l_env_int(env, bh) + 5) / 6 * 6;
+    };
+    const bool kept_ok = !r2l_env_int("R2L_FWD_APPLY_RECOMPUTE", 0);
+    // statistics pass = luma pass + statistics from the plane, where that is faster than the streaming forward without
+    // output: frames one strip wide (64x256x256: 12 + 26 us against 46; 128x256x256: 17 + 36 against 61).  On 512-wide
+    // frames the two kernels issue as many vector instructions as the one (7.1 M + 15.9 M against 23.9 M at 64x512x512)
+    // and take as long (28.5 + 55 us against 79.7): profiles/r03_split_stats.txt
+    const bool split = r2l_env_int("R2L_FWD_STATS_SPLIT", 0) || (W <= 256 && !r2l_env_int("R2L_FWD_STATS_STREAM", 0));
+    if (!out && stats && (flags & R2L_F_SPLIT_STATS) && kept_ok && split) {
+      R2LFwdStreamArgs la = fa;
+      la.stat_partial = nullptr;
+#ifdef R2L_EXP_STAMPS
+      la.tl = (unsigned long long*)ws.debug;
+      fa.tl = (unsigned long long*)ws.debug + 8192;
+#endif
+      la.band_h = band_rows(256L * 4 * R2L_FL_OCC, "R2L_FL_BAND");
+      la.nband = (H + la.band_h - 1) / la.band_h;
+      const long lgrid = (long)B * la.nband * nstrip;
+      if (lgrid > (1L << 30)) return r2l_fail(-1, "r2l_isp_fwd: batch too large");
+      la.nitems = (int)lgrid;
+      const int lg = (int)((lgrid + R2L_FA_NWV - 1) / R2L_FA_NWV);
+      if (int e = raw.u16 ? r2l_launch_fwd_luma_u16(la, lg, stream) : r2l_launch_fwd_luma(la, lg, stream)) return e;
+      fa.yp_in = ws.yp;
+      fa.yp_out = nullptr;
+      fa.band_h = band_rows(256L * 4 * R2L_FA_STATS_OCC, "R2L_FST_BAND");
+      fa.nband = (H + fa.band_h - 1) / fa.band_h;
+      const long items = (long)B * fa.nband * nstrip;
+      if (items > (1L << 30)) return r2l_fail(-1, "r2l_isp_fwd: batch too large");
+      fa.nitems = (int)items;
+      long g = (items + R2L_FA_STATS_NWV - 1) / R2L_FA_STATS_NWV;
+      const long gcap = r2l_env_int("R2L_GRID_FWD", R2L_MAX_BLOCKS);
+      if (g > gcap) g = gcap;
+      if (g > R2L_MAX_BLOCKS) g = R2L_MAX_BLOCKS;
+      return raw.u16 ? r2l_launch_fwd_stats_u16(fa, (int)g, stream) : r2l_launch_fwd_stats(fa, (int)g, stream);
+    }
+    if (out && !stats && (flags & R2L_F_LUMA_VALID) && kept_ok) {
+      // apply pass on the kept Y'
+#ifdef R2L_EXP_STAMPS
+      fa.tl = (unsigned long long*)ws.debug + 16384;
+#endif
+      fa.yp_in = ws.yp;
+      fa.yp_out = nullptr;
+      fa.stat_partial = nullptr;
+      fa.band_h = band_rows(256L * 4 * R2L_FA_OCC, "R2L_FA_BAND");
+      fa.nband = (H + fa.band_h - 1) / fa.band_h;
       const long grid = (long)B * fa.nband * nstrip;
       if (grid > (1L << 30)) return r2l_fail(-1, "r2l_isp_fwd: batch too large");
       fa.nitems = (int)grid;
       static const launch_t atable[2][2] = {{r2l_launch_fwd_apply, r2l_launch_fwd_apply_u16},
                                             {r2l_launch_fwd_apply_epi, r2l_launch_fwd_apply_epi_u16}};
-      return atable[epi ? 1 : 0][raw.u16 ? 1 : 0](fa, (int)grid, stream);
+      return atable[epi ? 1 : 0][raw.u16 ? 1 : 0](fa, (int)((grid + R2L_FA_NWV - 1) / R2L_FA_NWV), stream);
     }
     return table[epi ? 1 : 0][raw.u16 ? 1 : 0][nw](fa, sgrid, stream);
   }
@@ -815,6 +883,7 @@ size_t r2l_isp_step_offset(int which, int B, int H, int W) {
     case R2L_STEP_BN_SUMS: return (size_t)((char*)ws.bsums - (char*)nullptr);
     case R2L_STEP_PACKED: return (size_t)((char*)ws.packed - (char*)nullptr);
     case R2L_STEP_BN: return (size_t)((char*)ws.bn - (char*)nullptr);
+    case R2L_STEP_LUMA: return (size_t)((char*)ws.yp - (char*)nullptr);
     default: return 0;
   }
 }
@@ -865,7 +934,8 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
     // statistics pass; one rank: the last workgroup also does the BatchNorm bookkeeping
     R2LBnFinalizeArgs f{ws.stats, 1, ws.bn, ws.moments, running_mean, running_var, eps, momentum, num_batches_tracked};
     if (int e = r2l_isp_fwd_impl(rw, ws.packed, additive, nullptr, nullptr, ws.stats, workspace, workspace_bytes, B, H,
-                                 W, R2L_F_STATS_ONLY | R2L_F_FOLDED_VALID | keep, stream, phase == R2L_STEP_ALL ? &f : nullptr))
+                                 W, R2L_F_STATS_ONLY | R2L_F_FOLDED_VALID | R2L_F_SPLIT_STATS | keep, stream,
+                                 phase == R2L_STEP_ALL ? &f : nullptr))
       return e;
     if (phase == R2L_STEP_A) return 0;
   }
@@ -874,11 +944,11 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
                         num_batches_tracked};
     if (int e = r2l_launch_bn_finalize(f, 1, stream)) return e;
   }
-  // (train mode: the statistics pass of this call -- or of phase A of this step -- has kept Y' if `keep` is set)
+  // (train mode: the statistics pass of this call -- or of phase A of this step -- has left Y' in the workspace wherever the
+  // row-streaming forward runs, and the apply pass reads it)
   return r2l_isp_fwd_impl(rw, ws.packed, additive, bn_mode == R2L_BN_NONE ? nullptr : ws.bn, out, nullptr, workspace,
                           workspace_bytes, B, H, W,
-                          R2L_F_FOLDED_VALID | keep | ((keep && bn_mode == R2L_BN_TRAIN) ? R2L_F_LUMA_VALID : 0), stream,
-                          nullptr, &ep);
+                          R2L_F_FOLDED_VALID | keep | (bn_mode == R2L_BN_TRAIN ? R2L_F_LUMA_VALID : 0), stream, nullptr, &ep);
 }
 int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* additive, const float* grad_out,
                      const float* out, float* grad_params, float* grad_additive, int bn_mode, void* workspace,
@@ -1243,7 +1313,7 @@ int r2l_isp_fwd(const float* raw, const float* params, const float* additive,
                 const float* bn_mean_istd, float* out, double* stats, void* workspace,
                 size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
   return r2l_isp_fwd_impl(r2l_raw_f32(raw), params, additive, bn_mean_istd, out, stats, workspace, workspace_bytes,
-                          B, H, W, flags & ~R2L_F_LUMA_VALID, stream);
+                          B, H, W, flags & ~R2L_F_INTERNAL, stream);
 }
 // statistics pass + BatchNorm bookkeeping in one launch (one rank: no exchange between the two)
 static int r2l_isp_fwd_stats_bn_impl(const R2LRaw& raw, const float* params, const float* additive, double* stats,
@@ -1277,7 +1347,7 @@ int r2l_isp_fwd_u16(const unsigned short* raw, float denom, const float* params,
                     const float* bn_mean_istd, float* out, double* stats, void* workspace,
                     size_t workspace_bytes, int B, int H, int W, int flags, void* stream) {
   return r2l_isp_fwd_impl(r2l_raw_u16(raw, denom), params, additive, bn_mean_istd, out, stats, workspace,
-                          workspace_bytes, B, H, W, flags & ~R2L_F_LUMA_VALID, stream);
+                          workspace_bytes, B, H, W, flags & ~R2L_F_INTERNAL, stream);
 }
 int r2l_isp_bwd(const float* raw, const float* params, const float* additive,
                 const float* bn_mean_istd, const float* bn_bwd, const float* grad_out,

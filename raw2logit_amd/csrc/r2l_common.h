@@ -471,6 +471,18 @@ R2L_HD const R2LFolded* r2l_opaque(const R2LFolded* p) {
   return p;
 }
 
+// ... and not before `dep` exists: in a loop body without branches (r2l_fwd_apply_block) nothing else keeps hipcc from
+// floating the invariant scalar loads of ALL the unrolled steps to the top of the block (__builtin_amdgcn_sched_barrier
+// does not order them: 280 spilled SGPRs, 1 KB of scratch)
+R2L_HD const R2LFolded* r2l_opaque_after(const R2LFolded* p, float dep) {
+#ifndef R2L_EMUL
+  asm volatile("" : "+s"(p) : "v"(dep));
+#else
+  (void)dep;
+#endif
+  return p;
+}
+
 // element (k, c) of T = M_RGB_2_YUV * colour_correction * diag(white_balance), float64
 R2L_HD double r2l_fold_T_one(const float* P, int k, int c) {
   double s = 0;

@@ -39,7 +39,21 @@ struct R2LFwdStreamArgs {
   double* stats_out;
   R2LBnFinalizeArgs fin;
   R2LEpi ep;  // EPI instantiations: where the output goes (R2LEpi)
+#ifdef R2L_EXP_STAMPS
+  unsigned long long* tl;  // diagnostic builds: (start, end) s_memrealtime of every workgroup's first wavefront
+#endif
 };
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+#define R2L_TL_BEGIN(a, bid) const unsigned long long tl0_ = __builtin_amdgcn_s_memrealtime();
+#define R2L_TL_END(a, bid)                                                       \
+  if ((a).tl && (bid) < 4096 && threadIdx.x == 0) {                              \
+    (a).tl[2 * (bid)] = tl0_;                                                    \
+    (a).tl[2 * (bid) + 1] = __builtin_amdgcn_s_memrealtime();                    \
+  }
+#else
+#define R2L_TL_BEGIN(a, bid)
+#define R2L_TL_END(a, bid)
+#endif
 
 R2L_HD float r2l_wshr(float x, float edge) {  // previous lane's x; lane 0 of the wavefront gets `edge`
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
@@ -146,10 +160,13 @@ R2L_HD void r2l_fs_stencil_parity(const float* r0, const float* r1, const float*
 
 // the colour code of one output row (:203-217): Y'', U, V of the lane's 4 pixels -> RGB, clip, gamma, [statistics about the
 // lane's pivot], [BatchNorm], store (EPI: at the augmented position, R2LEpi)
-template <bool EPI, bool STATS>
+// STATS: 0 none; 1 the streaming kernel's form (under `a.stat_partial && store_ok`); 2 branch-free, weighted with smask
+// (1 for the pixels that count, 0 for the others), the pivot taken in the band's first row (`first`)
+template <bool EPI, int STATS>
 R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc, float* piv, const r2l_p2 ypp[2],
                           const r2l_p2 u[2], const r2l_p2 v[2], int y, int y0, int x0, float* ob, unsigned plane,
-                          bool store_ok, const float mean[3], const float istd[3]) {
+                          bool store_ok, const float mean[3], const float istd[3], float smask = 0.f,
+                          bool first = false) {
   const unsigned off0 = (unsigned)y * (unsigned)a.W + (unsigned)x0;
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
@@ -163,11 +180,18 @@ R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc
                                 r2l_log2(fminf(fmaxf(rgb[1], 1e-5f), 1.0f)));
       const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));                    // :209
       x[p] = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
-      if (STATS && a.stat_partial && store_ok) {
+      if (STATS == 1 && a.stat_partial && store_ok) {
         if (p == 0) piv[k] = (y == y0) ? x[0][0] : piv[k];
         const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-piv[k]));
         acc[k] = r2l_padd(acc[k], d);
         acc[3 + k] = r2l_pfma(d, d, acc[3 + k]);
+      }
+      if (STATS == 2) {
+        if (p == 0) piv[k] = first ? x[0][0] : piv[k];
+        const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-piv[k]));
+        const r2l_p2 t = r2l_pmul(d, r2l_splat2(smask));
+        acc[k] = r2l_padd(acc[k], t);
+        acc[3 + k] = r2l_pfma(t, d, acc[3 + k]);
       }
     }
     if (ob && store_ok) {
@@ -333,7 +357,7 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
     const r2l_f4* f = fifo + ((K + 2) % R2L_FS_FIFO_ROWS) * 2 * 64 + lane;  // row q-4
     const r2l_f4 fu = f[0], fv = f[64];
     const r2l_p2 u[2] = {r2l_mk2(fu.x, fu.y), r2l_mk2(fu.z, fu.w)}, v[2] = {r2l_mk2(fv.x, fv.y), r2l_mk2(fv.z, fv.w)};
-    r2l_fs_colour<EPI, true>(a, F, st.acc, st.piv, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd);
+    r2l_fs_colour<EPI, 1>(a, F, st.acc, st.piv, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd);
     const unsigned off0 = (unsigned)y * (unsigned)a.W + (unsigned)x0;
     // Y'(y), kept for kernel B1 of the backward: the middle row of the blur's window, stored last (the step's
     // registers are free here; next to the sharpen, or in front of the colour code, the kernel spills)
@@ -354,6 +378,67 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
   if ((unsigned)(q - 1) >= (unsigned)H) {
     float* ypn = st.yp[(K + 5) % 6];
     ypn[2] = ypn[3] = ypn[4] = ypn[5] = 0.f;
+  }
+}
+
+// one work item's lane sums (float32 pairs about the lane's pivot) -> float64 about the common pivot 0.5, added over the
+// wavefront in a fixed butterfly order into its float64 totals in LDS; npx = pixels behind this lane's sums
+R2L_HD void r2l_fs_lane_sums(const r2l_p2* acc, const float* piv, double npx, bool ok, int lane, double* tots) {
+  double part[6];
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) {
+    // from the lane's pivot p to the common pivot 0.5:  x - .5 = (x - p) + dp
+    const double s1 = (double)acc[k][0] + (double)acc[k][1];
+    const double s2 = (double)acc[3 + k][0] + (double)acc[3 + k][1];
+    const double dp = ok ? (double)piv[k] - 0.5 : 0.0;
+    double v1 = fma(npx, dp, s1), v2 = fma(dp, fma(npx, dp, 2.0 * s1), s2);
+    R2L_PRAGMA_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) {
+      v1 += __shfl_xor(v1, m, 64);
+      v2 += __shfl_xor(v2, m, 64);
+    }
+    part[k] = v1;
+    part[3 + k] = v2;
+  }
+  if (lane == 0) {
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 6; ++i) tots[i] += part[i];
+  }
+}
+
+// ---- statistics: the wavefronts' float64 totals -> one partial per slot and workgroup (fixed order), then the shared
+// tree; the last workgroup of the launch writes the totals and, one rank, does the BatchNorm bookkeeping
+template <int NW, int NT>
+R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a, int bid, int nblk, int tid, int wave, double* tots,
+                                     float* red) {
+  // ---- statistics: lanes -> one partial per slot and workgroup (fixed order), then the shared tree ------------
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wavefront is done with its chroma ring
+    if (tid < 6) {  // the wavefronts' totals in wavefront order; (high, low) float32 halves in slots tid and 6 + tid
+      double acc = 0.0;
+      for (int w = 0; w < NW; ++w) acc += (tots - wave * 6)[w * 6 + tid];
+      const float hi = (float)acc;
+      r2l_store_coherent(&a.stat_partial[(size_t)tid * nblk + bid], hi);
+      r2l_store_coherent(&a.stat_partial[(size_t)(6 + tid) * nblk + bid], (float)(acc - (double)hi));
+    }
+    R2L_STORES_DONE();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    double* sl = (double*)(red + 4);  // totals in LDS: the bookkeeping below reads them back
+    if (a.tree.counters &&
+        r2l_tree_finish<12, NT>(a.tree, bid, nblk, red, sl, (double*)(red + 512), (R2L_FS_RED_FLOATS(NW) - 512) / 2)) {
+      if (tid < 6) sl[tid] += sl[6 + tid];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid == 0) sl[6] = (double)a.B * (double)a.H * (double)a.W;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 7) a.stats_out[tid] = sl[tid];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (a.fin.bn) {
+        R2LBnFinalizeArgs f = a.fin;
+        f.tot = sl;
+        f.nranks = 1;
+        r2l_bn_finalize_phases(f);
+      }
+    }
   }
 }
 
@@ -457,61 +542,10 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
 #undef R2L_FS_STEP
     }
     if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // exchange buffers free for the next item
-    if (a.stat_partial) {
-      double part[6];
-      const double npx = store_ok ? 4.0 * (double)(y1 - y0) : 0.0;  // pixels behind this lane's sums
-      R2L_PRAGMA_UNROLL
-      for (int k = 0; k < 3; ++k) {
-        // from the lane's pivot p to the common pivot 0.5:  x - .5 = (x - p) + dp
-        const double s1 = (double)st.acc[k][0] + (double)st.acc[k][1];
-        const double s2 = (double)st.acc[3 + k][0] + (double)st.acc[3 + k][1];
-        const double dp = store_ok ? (double)st.piv[k] - 0.5 : 0.0;
-        double v1 = fma(npx, dp, s1), v2 = fma(dp, fma(npx, dp, 2.0 * s1), s2);
-        R2L_PRAGMA_UNROLL
-        for (int m = 32; m >= 1; m >>= 1) {
-          v1 += __shfl_xor(v1, m, 64);
-          v2 += __shfl_xor(v2, m, 64);
-        }
-        part[k] = v1;
-        part[3 + k] = v2;
-      }
-      if (lane == 0) {
-        R2L_PRAGMA_UNROLL
-        for (int i = 0; i < 6; ++i) tots[i] += part[i];
-      }
-    }
+    if (a.stat_partial) r2l_fs_lane_sums(st.acc, st.piv, store_ok ? 4.0 * (double)(y1 - y0) : 0.0, store_ok, lane, tots);
   }
-  // ---- statistics: lanes -> one partial per slot and workgroup (fixed order), then the shared tree ------------
-  if (a.stat_partial) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wavefront is done with its chroma ring
-    if (tid < 6) {  // the wavefronts' totals in wavefront order; (high, low) float32 halves in slots tid and 6 + tid
-      double acc = 0.0;
-      for (int w = 0; w < NW; ++w) acc += (tots - wave * 6)[w * 6 + tid];
-      const float hi = (float)acc;
-      r2l_store_coherent(&a.stat_partial[(size_t)tid * nblk + bid], hi);
-      r2l_store_coherent(&a.stat_partial[(size_t)(6 + tid) * nblk + bid], (float)(acc - (double)hi));
-    }
-    R2L_STORES_DONE();
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    double* sl = (double*)(red + 4);  // totals in LDS: the bookkeeping below reads them back
-    if (a.tree.counters &&
-        r2l_tree_finish<12, NT>(a.tree, bid, nblk, red, sl, (double*)(red + 512), (R2L_FS_RED_FLOATS(NW) - 512) / 2)) {
-      if (tid < 6) sl[tid] += sl[6 + tid];
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (tid == 0) sl[6] = (double)a.B * (double)a.H * (double)a.W;
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (tid < 7) a.stats_out[tid] = sl[tid];
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (a.fin.bn) {
-        R2LBnFinalizeArgs f = a.fin;
-        f.tot = sl;
-        f.nranks = 1;
-        r2l_bn_finalize_phases(f);
-      }
-    }
-  }
+  if (a.stat_partial) r2l_fs_stats_finish<NW, NT>(a, bid, nblk, tid, wave, tots, red);
 }
-
 
 // ================================================================================================
 // The APPLY pass of train-mode BatchNorm when the statistics pass has kept Y' (R2L_F_KEEP_LUMA): everything in front of
@@ -532,9 +566,9 @@ struct R2LFaStage {  // one Y' row in flight: the lane's 4 values + the pair bey
 };
 // The fetches are BRANCH-FREE (every lane loads an edge value from an in-row address; only the first and last lane use
 // theirs) and the loop below has no conditional memory operation but the predicated stores: hipcc's s_waitcnt insertion
-// then knows how many younger loads follow the row a step consumes and waits with vmcnt(4 (PF - 1)) -- with a conditional
+// then knows how many younger loads follow the row a step consumes and waits with vmcnt(8 .. 13) -- with a conditional
 // fetch or a conditionally executed step anywhere in the loop it falls back to vmcnt(0), which waits for the loads just
-// issued AND for the output stores of the previous row (measured: 2,000 stall cycles per row step, twice its issue time).
+// issued AND for the output stores of the previous row.
 template <bool U16>
 R2L_HD void r2l_fa_fetch_raw(const R2LFwdStreamArgs& a, size_t img0, int ym, int x0, bool le, bool re, int lane,
                              R2LFsStage& s) {
@@ -575,15 +609,23 @@ R2L_HD void r2l_fa_build(const R2LFaStage& s, bool rin, bool le, bool re, float 
   o[6] = re ? c2 : r1;
   o[7] = re ? c1 : r2;
 }
+// a scalar 1 hipcc cannot see through: `if (r2l_opaque_true())` around a step's arithmetic makes the step a basic block
+// of its own (STATS: without a store or a branch the six unrolled steps are ONE block, scheduled as one: 215 VGPRs)
+R2L_HD bool r2l_opaque_true() {
+  int one = 1;
+  asm volatile("" : "+s"(one));
+  return one != 0;
+}
 struct R2LFaState {
   float v[3][6];   // V rows (slot = row mod 3)
   float yp[6][8];  // Y' rows (slot = row mod 6)
 };
-template <int K, bool EPI>
-R2L_HD void r2l_fa_step(const R2LFwdStreamArgs& a, R2LFaState& st, int y, int y0, bool store_ok, float* ob,
-                        unsigned plane, int x0, const float mean[3], const float istd[3]) {
-  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
-  R2LFoldedRef Fh = R2L_FOLDED_REF(a.F);
+template <int K, bool EPI, bool STATS>
+R2L_HD void r2l_fa_step(const R2LFwdStreamArgs& a, R2LFaState& st, r2l_p2* acc, float* piv, int y, int y0,
+                        bool store_ok, float* ob, unsigned plane, int x0, const float mean[3], const float istd[3]) {
+  // (the weights of one section at a time: chroma, blur, colour code -- r2l_opaque_after)
+  // the previous step's last result (STATS: there is no store to end a step with) / this step's newest window value
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, STATS ? acc[5][1] : st.yp[(K + 2) % 6][2]));
   constexpr int PY = K & 1;
   const int H = a.H;
   const float* vu = st.v[(K + 2) % 3];  // V(y-1)
@@ -593,6 +635,7 @@ R2L_HD void r2l_fa_step(const R2LFwdStreamArgs& a, R2LFaState& st, int y, int y0
   r2l_fs_stencil_parity(vu, vm, vl, F.AU2[PY], u);
   r2l_fs_stencil_parity(vu, vm, vl, F.AV2[PY], v);
   {
+    R2LFoldedRef Fb = R2L_FOLDED_REF(r2l_opaque_after(a.F, v[1][1]));
     float yw[5][8];  // window rows y-2 .. y+2 sit in ring slots K+4 .. K+8
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 5; ++i)
@@ -600,48 +643,48 @@ R2L_HD void r2l_fa_step(const R2LFwdStreamArgs& a, R2LFaState& st, int y, int y0
     for (int j = 0; j < 8; ++j) yw[i][j] = st.yp[(K + 4 + i) % 6][j];
     const int set = (y < 2) ? y : (y - (H - 2)) + 2;
     const __attribute__((address_space(4))) float* w25 =
-        (y >= 2 && y < H - 2) ? &Fh.blur[0] : &F.blur_edge[0][0] + 25 * set;
+        (y >= 2 && y < H - 2) ? &Fb.blur[0] : &Fb.blur_edge[0][0] + 25 * set;
     r2l_blur_row2w(yw, w25, ypp);
   }
-  r2l_fs_colour<EPI, false>(a, F, nullptr, nullptr, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd);
+  R2LFoldedRef Fc = R2L_FOLDED_REF(r2l_opaque_after(a.F, ypp[1][1]));
+  r2l_fs_colour<EPI, STATS ? 2 : 0>(a, Fc, acc, piv, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd,
+                                    store_ok ? 1.f : 0.f, K == 0 && y == y0);
 }
 
 #ifndef R2L_FA_PF
 #define R2L_FA_PF 2
 #endif
-
-template <bool U16, bool EPI>
-R2L_BLOCKFN void r2l_fwd_apply_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
-  (void)lds;
-  (void)nblk;
-  const int lane = threadIdx.x & 63;
+// STATS: no output -- the statistics of train-mode BatchNorm from the kept plane (the colour code's sums about the lane's
+// pivot, then the streaming kernel's reduction: r2l_fs_stats_finish); NWV wavefronts per workgroup, every one of them
+// walking its own work items (bid * NWV + wave, + nblk * NWV, ...), so that <= R2L_MAX_BLOCKS partials fill the chip.
+// The apply pass runs one wavefront per workgroup and one item per wavefront.
+#define R2L_FA_LDS_FLOATS(NWV, STATS) ((STATS) ? 16 + R2L_FS_RED_FLOATS(NWV) + 12 * (NWV) : 4)
+// one work item = (image, band, strip), strips fastest: neighbouring items share halo rows and strip edges
+template <bool U16, bool EPI, bool STATS>
+R2L_HD void r2l_fa_item(const R2LFwdStreamArgs& a, int item, int lane, const float mean[3], const float istd[3],
+                        double* tots) {
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
-  // work item = (image, band, strip), strips fastest: neighbouring workgroup ids share halo rows and strip edges
   const int nstrip = (a.W + 255) >> 8;
-  const int strip = bid % nstrip, ib = bid / nstrip;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const int strip = item % nstrip, ib = item / nstrip;
   const int band = ib % a.nband, b = ib / a.nband;
   const int xs = strip * 256 + 4 * lane;
   const bool in_w = xs < a.W;
   const int x0 = in_w ? xs : a.W - 4;
   const bool le = x0 == 0, re = x0 + 4 >= a.W;
-  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
-  float mean[3] = {0.f, 0.f, 0.f}, istd[3] = {1.f, 1.f, 1.f};
-  if (a.bn) {
-    R2L_PRAGMA_UNROLL
-    for (int k = 0; k < 3; ++k) {
-      mean[k] = a.bn[k];
-      istd[k] = a.bn[3 + k];
-    }
-  }
   // bands start on multiples of 6 rows (the host rounds band_h): the ring slot of a row, row mod 6, is then the unroll
   // position K of its step in every band, and the warm-up is the same four steps everywhere
   const int y0 = band * a.band_h;
   const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
   const size_t img = (size_t)b * plane;
-  float* ob = a.out + (size_t)b * 3 * plane;
-  __builtin_assume(ob != nullptr);
+  float* ob = STATS ? nullptr : a.out + (size_t)b * 3 * plane;
+  if (!STATS) __builtin_assume(ob != nullptr);
   const float* ypimg = a.yp_in + img;
   R2LFaState st;
+  r2l_p2 acc[6];
+  float piv[3] = {0.5f, 0.5f, 0.5f};
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 6; ++i) acc[i] = r2l_splat2(0.f);
   constexpr int PF = R2L_FA_PF;
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
   R2LFsStage pf[PF];   // ring: step K consumes pf[K % PF] (raw row q + 1) and refills it with row q + 1 + PF
@@ -664,13 +707,14 @@ R2L_BLOCKFN void r2l_fwd_apply_block(const R2LFwdStreamArgs& a, int bid, int nbl
   R2L_FA_LOAD_STEP(4, y0 - 2)
   R2L_FA_LOAD_STEP(5, y0 - 1)
   // every group of 6 steps runs in full: rows past the band's end (last band of an image whose height is not a multiple
-  // of 6) are computed from clamped fetches and not stored
+  // of 6) are computed from clamped fetches and neither stored nor counted
   for (int qb = y0; qb < y1; qb += 6) {
 #define R2L_FA_STEP(K)                                                                                  \
   {                                                                                                     \
     const int q = qb + K;                                                                               \
     R2L_FA_LOAD_STEP(K, q)                                                                              \
-    r2l_fa_step<K, EPI>(a, st, q, y0, in_w && q < y1, ob, plane, x0, mean, istd);                       \
+    if (!STATS || r2l_opaque_true())                                                                    \
+      r2l_fa_step<K, EPI, STATS>(a, st, acc, piv, q, y0, in_w && q < y1, ob, plane, x0, mean, istd);    \
   }
     R2L_FA_STEP(0)
     R2L_FA_STEP(1)
@@ -681,6 +725,217 @@ R2L_BLOCKFN void r2l_fwd_apply_block(const R2LFwdStreamArgs& a, int bid, int nbl
 #undef R2L_FA_STEP
   }
 #undef R2L_FA_LOAD_STEP
+  if (STATS) r2l_fs_lane_sums(acc, piv, in_w ? 4.0 * (double)(y1 - y0) : 0.0, in_w, lane, tots);
+}
+template <bool U16, bool EPI, bool STATS, int NWV>
+R2L_BLOCKFN void r2l_fwd_apply_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
+  // (the wavefront index as a SCALAR: the work item, its rows and the weight set of a row must not look lane-dependent)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  float mean[3] = {0.f, 0.f, 0.f}, istd[3] = {1.f, 1.f, 1.f};
+  R2L_TL_BEGIN(a, bid)
+  if (!STATS) {
+    if (a.bn) {
+      R2L_PRAGMA_UNROLL
+      for (int k = 0; k < 3; ++k) {
+        mean[k] = a.bn[k];
+        istd[k] = a.bn[3 + k];
+      }
+    }
+    // one item per wavefront; NWV wavefronts per workgroup only because the dispatcher starts ~250 workgroups per
+    // microsecond: 4,096 single-wavefront workgroups take 15 us to launch (tests/timeline_fwd.py)
+    const int item = bid * NWV + wave;
+    if (item < a.nitems) r2l_fa_item<U16, EPI, false>(a, item, lane, mean, istd, nullptr);
+    R2L_TL_END(a, bid)
+  } else {
+    float* red = lds + 16;
+    double* tots = (double*)(lds + 16 + R2L_FS_RED_FLOATS(NWV)) + wave * 6;
+    if (lane < 6) tots[lane] = 0.0;
+    R2L_PRAGMA_NOUNROLL
+    for (int item = bid * NWV + wave; item < a.nitems; item += nblk * NWV)
+      r2l_fa_item<U16, false, true>(a, item, lane, mean, istd, tots);
+    R2L_TL_END(a, bid)
+    r2l_fs_stats_finish<NWV, NWV * 64>(a, bid, nblk, tid, wave, tots, red);
+  }
+}
+
+// ================================================================================================
+// The LUMA pass: raw -> Y' = sharpen(Y) (pipeline_torch.py:183-195), the plane the two passes above (statistics, apply)
+// and kernel B1 of the backward read.  Independent wavefronts again: the sharpen needs Y one column beyond the lane's
+// four on each side; between lanes that is a DPP shift, and the strip's first and last lane compute the one column
+// their neighbour strip owns THEMSELVES -- one extra pair per row for all lanes, (Y(x0+4), Y(x0-1)) = (even, odd column)
+// like every other pair, from a raw window 8 columns wide (edge pairs: one 8-byte load per row) -- instead of an
+// exchange through LDS and a barrier per row.  Same functions, same order of operations as r2l_fs_step: the plane is
+// bit-identical to the one the streaming forward keeps.  8 B/px (4 in, 4 out) + 4 raw halo rows per band.
+struct R2LFlStage {
+  r2l_f4 c;
+  r2l_f2 e;  // columns (x0-2, x0-1) in the first half of the wavefront, (x0+4, x0+5) in the second: (even, odd)
+  int ym;
+};
+template <bool U16>
+R2L_HD void r2l_fl_fetch(const R2LFwdStreamArgs& a, size_t img0, int ym, int x0, bool le, bool re, int lane,
+                         R2LFlStage& s) {
+  const size_t e = img0 + (size_t)ym * a.W + x0;
+  const int eo = (lane < 32) ? (le ? 0 : -2) : (re ? 2 : 4);
+  s.ym = ym;
+  if (U16) {
+    const unsigned short* r = a.raw.u16 + e;
+    const r2l_f2 b = *(const r2l_f2*)r;
+    s.c.x = b.x;
+    s.c.y = b.y;
+    s.e.x = *(const float*)(r + eo);  // two 16-bit values
+  } else {
+    const float* r = a.raw.f32 + e;
+    s.c = r2l_stream_load_f4(r);
+    s.e = *(const r2l_f2*)(r + eo);
+  }
+}
+// staged row -> 8 black-level-corrected values, columns x0-2 .. x0+5 (mirror padding at the image edges)
+template <bool U16>
+R2L_HD void r2l_fl_convert(const R2LFwdStreamArgs& a, R2LFoldedRef F, const R2LFlStage& s, bool le, bool re, float v[6],
+                           r2l_p2 xp[3]) {
+  float c0, c1, c2, c3, e0, e1;
+  if (U16) {
+    const unsigned lo = r2l_f2u(s.c.x), hi = r2l_f2u(s.c.y), ee = r2l_f2u(s.e.x);
+    c0 = r2l_raw_decode(lo & 0xffffu, a.raw);
+    c1 = r2l_raw_decode(lo >> 16, a.raw);
+    c2 = r2l_raw_decode(hi & 0xffffu, a.raw);
+    c3 = r2l_raw_decode(hi >> 16, a.raw);
+    e0 = r2l_raw_decode(ee & 0xffffu, a.raw);
+    e1 = r2l_raw_decode(ee >> 16, a.raw);
+  } else {
+    c0 = s.c.x;
+    c1 = s.c.y;
+    c2 = s.c.z;
+    c3 = s.c.w;
+    e0 = s.e.x;
+    e1 = s.e.y;
+  }
+  const float be = (s.ym & 1) ? F.bl[2] : F.bl[0], bo = (s.ym & 1) ? F.bl[3] : F.bl[1];
+  c0 -= be;
+  c1 -= bo;
+  c2 -= be;
+  c3 -= bo;
+  e0 -= be;
+  e1 -= bo;
+  const float l2 = r2l_wshr(c2, e0), l1 = r2l_wshr(c3, e1);
+  const float r1 = r2l_wshl(c0, e0), r2 = r2l_wshl(c1, e1);
+  // column -2 is column 2, -1 is 1; W is W-2, W+1 is W-3
+  v[0] = le ? c1 : l1;
+  v[1] = c0;
+  v[2] = c1;
+  v[3] = c2;
+  v[4] = c3;
+  v[5] = re ? c2 : r1;
+  xp[0] = r2l_mk2(c3, le ? c2 : l2);
+  xp[1] = r2l_mk2(v[5], v[0]);
+  xp[2] = r2l_mk2(re ? c1 : r2, c0);
+}
+struct R2LFlState {
+  float v[3][6];  // V rows (slot = row mod 3), columns x0-1 .. x0+4 (the window of r2l_fs_step)
+  // ... and the inputs of the extra pair, (column x0+3+j, column x0-2+j), as PAIRS: read as floats out of an array (one
+  // 8-wide row, or two 3-wide ones) hipcc widens the loads into overlapping 8-byte ones, cannot take the array apart any
+  // more and parks it in LDS -- whose addressing reads the dispatch packet: workgroups then start 70 per us instead of 1,400
+  r2l_p2 xp[3][3];
+  float y[3][6];  // Y rows (slot = row mod 3), columns x0-1 .. x0+4
+};
+// step y (K = y mod 6): V(y+2) is in place; Y(y+1) from V(y .. y+2) [LUMA]; Y'(y) from Y(y-1 .. y+1), stored [OUT]
+template <int K, bool LUMA, bool OUT>
+R2L_HD void r2l_fl_step(const R2LFwdStreamArgs& a, R2LFlState& st, int y, bool le, bool re, bool store_ok, float* ypb,
+                        int x0) {
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
+  if (LUMA) {
+    constexpr int PY = (K + 1) & 1;
+    float* yq = st.y[(K + 1) % 3];
+    r2l_p2 o[2];
+    r2l_fs_stencil_parity(st.v[K % 3], st.v[(K + 1) % 3], st.v[(K + 2) % 3], F.AY2[PY], o);  // V(y), V(y+1), V(y+2)
+    // the columns beyond the lane's four, as ONE more pair: (Y(x0+4), Y(x0-1)) -- even column, odd column
+    r2l_p2 e = r2l_splat2(0.f);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j)
+      e = r2l_pfma(r2l_mk2(F.AY2[PY][i * 3 + j][0], F.AY2[PY][i * 3 + j][1]), st.xp[(K + i) % 3][j], e);
+    const bool qin = (unsigned)(y + 1) < (unsigned)a.H;  // zero padding of the sharpen conv (:162 padding=1)
+    yq[0] = (qin && !le) ? e[1] : 0.f;
+    yq[1] = qin ? o[0][0] : 0.f;
+    yq[2] = qin ? o[0][1] : 0.f;
+    yq[3] = qin ? o[1][0] : 0.f;
+    yq[4] = qin ? o[1][1] : 0.f;
+    yq[5] = (qin && !re) ? e[0] : 0.f;
+  }
+  if (OUT) {
+    r2l_p2 o[2];  // rows Y(y-1), Y(y), Y(y+1) = slots K+2, K, K+1
+    o[0] = o[1] = r2l_splat2(0.f);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      const r2l_p2 ws = r2l_splat2(F.sharp[i * 3 + j]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p)
+        o[p] = r2l_pfma(ws, r2l_mk2(st.y[(K + 2 + i) % 3][2 * p + j], st.y[(K + 2 + i) % 3][2 * p + j + 1]), o[p]);
+    }
+    if (store_ok) {
+      r2l_f4 s4;
+      s4.x = o[0][0];
+      s4.y = o[0][1];
+      s4.z = o[1][0];
+      s4.w = o[1][1];
+      *(r2l_f4*)(ypb + (unsigned)y * (unsigned)a.W + (unsigned)x0) = s4;
+    }
+  }
+}
+#ifndef R2L_FL_PF
+#define R2L_FL_PF 3
+#endif
+template <bool U16, int NWV>
+R2L_BLOCKFN void r2l_fwd_luma_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
+  (void)lds;
+  (void)nblk;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int item = bid * NWV + wave;  // one item per wavefront (NWV per workgroup: see r2l_fwd_apply_block)
+  if (item >= a.nitems) return;
+  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
+  const int nstrip = (a.W + 255) >> 8;
+  const int strip = item % nstrip, ib = item / nstrip;
+  const int band = ib % a.nband, b = ib / a.nband;
+  const int xs = strip * 256 + 4 * lane;
+  const bool in_w = xs < a.W;
+  const int x0 = in_w ? xs : a.W - 4;
+  const bool le = x0 == 0, re = x0 + 4 >= a.W;
+  const int y0 = band * a.band_h;  // a multiple of 6
+  const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
+  const size_t img = (size_t)b * a.H * a.W;
+  float* ypb = a.yp_out + img;
+  R2LFlState st;
+  R2L_TL_BEGIN(a, bid)
+  constexpr int PF = R2L_FL_PF;
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  R2LFlStage pf[PF];  // ring: step K consumes pf[K % PF] (raw row y + 2) and refills it with row y + 2 + PF
+  // warm-up: y = y0-4 (V(y0-2)), y0-3 (V(y0-1)), y0-2 (V(y0), Y(y0-1)), y0-1 (V(y0+1), Y(y0)) = K 2 .. 5
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i)
+    r2l_fl_fetch<U16>(a, img, r2l_mirror(y0 - 2 + i, a.H), x0, le, re, lane, pf[(2 + i) % PF]);
+#define R2L_FL_STEP(K, y, LUMA, OUT)                                                                    \
+  {                                                                                                     \
+    r2l_fl_convert<U16>(a, F, pf[(K) % PF], le, re, st.v[((K) + 2) % 3], st.xp[((K) + 2) % 3]);                      \
+    r2l_fl_fetch<U16>(a, img, r2l_mirror((y) + 2 + PF, a.H), x0, le, re, lane, pf[(K) % PF]);           \
+    r2l_fl_step<K, LUMA, OUT>(a, st, y, le, re, in_w && (y) < y1, ypb, x0);                             \
+  }
+  R2L_FL_STEP(2, y0 - 4, false, false)
+  R2L_FL_STEP(3, y0 - 3, false, false)
+  R2L_FL_STEP(4, y0 - 2, true, false)
+  R2L_FL_STEP(5, y0 - 1, true, false)
+  for (int qb = y0; qb < y1; qb += 6) {
+    R2L_FL_STEP(0, qb + 0, true, true)
+    R2L_FL_STEP(1, qb + 1, true, true)
+    R2L_FL_STEP(2, qb + 2, true, true)
+    R2L_FL_STEP(3, qb + 3, true, true)
+    R2L_FL_STEP(4, qb + 4, true, true)
+    R2L_FL_STEP(5, qb + 5, true, true)
+  }
+#undef R2L_FL_STEP
+  R2L_TL_END(a, bid)
 }
 
 #endif  // !R2L_EMUL

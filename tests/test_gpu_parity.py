@@ -507,13 +507,14 @@ def test_apply_pass_reads_the_luma_plane_the_statistics_pass_kept(shape, dev):
                 del os.environ[k]
         return y.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
 
+    # (statistics pass: the streaming kernel in every run, so that mean and 1/std are the same bits)
     ref, gref = run({'R2L_FWD_APPLY_RECOMPUTE': '1'}, 'f32')
     # the float64 oracle, so that "identical" is not "identically wrong"
     o, _, c = orc.parametrized_forward(u.astype(np.float32) / np.float32(4095), P.astype(np.float64), bn=pc.oracle_bn(case))
     tol = pc.out_tolerance(c, True)
     for env, frames in (({}, 'f32'), ({}, 'u16'), ({'R2L_FA_BAND': '2'}, 'f32'), ({'R2L_FA_BAND': '6'}, 'u16'),
                         ({'R2L_FA_BAND': '50'}, 'f32'), ({'R2L_FA_BAND': '1000'}, 'f32')):
-        y, g = run(env, frames)
+        y, g = run(dict(env, R2L_FWD_STATS_STREAM='1'), frames)
         assert torch.equal(y, ref), (shape, env, frames, (y - ref).abs().max().item())
         for n in gref:
             assert torch.equal(g[n], gref[n]), (shape, env, frames, n)
@@ -521,12 +522,79 @@ def test_apply_pass_reads_the_luma_plane_the_statistics_pass_kept(shape, dev):
         assert np.all(err <= tol), (shape, env, frames, err.max())
     pc.report(f'fwd-apply/{shape}/kept-luma apply pass vs streaming apply pass (bits differing)', 0.0, 0.0)
     for epilogue in ((True, False, 0), (False, True, 2)) + (((True, True, 1), (False, False, 3)) if H == W else ()):
-        ye, ge = run({}, 'f32', epilogue)
+        ye, ge = run({'R2L_FWD_STATS_STREAM': '1'}, 'f32', epilogue)
         yr, gr = run({'R2L_FWD_APPLY_RECOMPUTE': '1'}, 'f32', epilogue)
         assert torch.equal(ye, yr), (shape, epilogue)
         assert torch.equal(ye, aug.flip_rot(ref, *epilogue)), (shape, epilogue, 'vs permutation kernel')
         for n in gr:
             assert torch.equal(ge[n], gr[n]), (shape, epilogue, n)
+
+
+@pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
+                                   (5, 18, 8), (2, 514, 512), (3, 4, 4), (2, 6, 1024), (4, 256, 256), (2, 8, 256)], ids=str)
+def test_statistics_pass_is_a_luma_pass_and_a_pass_over_the_kept_plane(shape, dev):
+    """Train-mode BatchNorm, statistics pass: r2l_fwd_luma_block (raw -> Y', independent wavefronts that compute the one
+    column beyond their strip themselves) + r2l_fwd_apply_block<STATS> (the sums from the plane), instead of the streaming
+    forward without output.  The PLANE is bit-identical to the one the streaming forward keeps (diagnostic build,
+    R2L_FWD_STATS_STREAM), for float32 and 16-bit frames and whatever the band height; the statistics are the same sums
+    added in another order, so outputs, running statistics and gradients agree to float32 rounding of (mean, 1/std) -- and
+    the output is within tolerance of the float64 oracle.  (Default where frames are one 256-column strip wide.)"""
+    import os
+    from raw2logit_amd import _lib
+    B, H, W = shape
+    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+    P.perturb(17)
+    u = np.rint(orc.synth_raw(B, H, W, seed=H * 3 + W, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
+    cot = torch.from_numpy(np.random.default_rng(W + 1).standard_normal((B, 3, H, W)).astype(np.float32)).to(dev)
+    case = dict(camera='drone', track=False, additive=False, training=True, bn=True)
+
+    def run(env, frames):
+        m = pc.make_module(case, P, dev)
+        if frames == 'u16':
+            m.raw_bits = 12
+            raw = torch.from_numpy(u).to(dev)
+        else:
+            raw = torch.from_numpy(u.astype(np.float32) / np.float32(4095)).to(dev)
+        os.environ.update(env)
+        try:
+            with pc.launch_shape_overrides(dev):
+                lib, _ = _lib.library_for(raw)
+                y = m(raw)
+                off = lib.r2l_isp_step_offset(5, B, H, W)                      # R2L_STEP_LUMA
+                plane = y.grad_fn.ws[off:off + 4 * B * H * W].view(torch.float32).clone()
+                stats = y.grad_fn.ws[lib.r2l_isp_step_offset(0, B, H, W):][:56].view(torch.float64).clone()
+                (y * cot).sum().backward()
+        finally:
+            for k in env:
+                del os.environ[k]
+        return (y.detach(), plane, stats, {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+                m.batch_norm.running_mean.clone(), m.batch_norm.running_var.clone())
+
+    ref = run({'R2L_FWD_STATS_STREAM': '1'}, 'f32')
+    o, _, c = orc.parametrized_forward(u.astype(np.float32) / np.float32(4095), P.astype(np.float64), bn=pc.oracle_bn(case))
+    tol = pc.out_tolerance(c, True)
+    worst = 0.0
+    for env, frames in (({}, 'f32'), ({}, 'u16'), ({'R2L_FL_BAND': '6', 'R2L_FST_BAND': '12'}, 'f32'),
+                        ({'R2L_FL_BAND': '48', 'R2L_FST_BAND': '6'}, 'u16'), ({'R2L_FL_BAND': '1000'}, 'f32'),
+                        ({'R2L_GRID_FWD': '3'}, 'f32')):
+        y, plane, stats, g, rm, rv = run(dict(env, R2L_FWD_STATS_SPLIT='1'), frames)   # (the default only where W <= 256)
+        assert torch.equal(plane, ref[1]), (shape, env, frames, 'luma plane', (plane - ref[1]).abs().max().item())
+        # sums of (x - 0.5) and (x - 0.5)^2 per channel: float32 pair sums per work item (about the lane's pivot), float64
+        # from there on -- other bands round the float32 part differently: 1e-7 of a pixel's worth per pixel
+        rel = ((stats[:6] - ref[2][:6]).abs() / float(B * H * W)).max().item()
+        assert rel <= 1e-7, (shape, env, frames, 'float64 totals / n', rel)
+        assert stats[6].item() == float(B * H * W)
+        d = (y - ref[0]).abs().max().item()
+        worst = max(worst, d)
+        assert d <= 4e-6 * float(c['istd'].max()), (shape, env, frames, d)
+        assert torch.allclose(rm, ref[4], rtol=1e-6, atol=1e-9) and torch.allclose(rv, ref[5], rtol=1e-6, atol=1e-12)
+        for n in ref[3]:
+            e = (g[n] - ref[3][n]).abs().max().item()
+            assert e <= 1e-4 * (ref[3][n].abs().max().item() + 1e-6), (shape, env, frames, n, e)
+        err = np.abs(y.cpu().numpy() - o)
+        assert np.all(err <= tol), (shape, env, frames, err.max())
+    pc.report(f'fwd-stats/{shape}/luma + statistics passes vs streaming statistics pass: out', worst,
+              4e-6 * float(c['istd'].max()))
 
 
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),

@@ -1,0 +1,60 @@
+"""Diagnostic: start / end times (s_memrealtime, 100 MHz) of every workgroup of the three train-mode forward kernels
+(luma, statistics, apply), from a -DR2L_EXP_STAMPS -DR2L_TEST_HOOKS build:  R2L_STAMPS_LIB=... python tests/timeline_fwd.py"""
+import os, sys, ctypes, torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ['R2L_LIB_PATH'] = os.path.join(HERE, '_build', os.environ.get('R2L_STAMPS_LIB', 'lib_stamps.so'))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+from oracle import isp_oracle as orc
+from raw2logit_amd import _lib
+import parity_checks as pc
+B, H, W = [int(x) for x in os.environ.get('SHAPE', '64x512x512').split('x')]
+dev = torch.device('cuda')
+raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=0, kind='uniform')).to(dev)
+m = pc.make_module(dict(camera='drone', track=False, additive=False, training=True, bn=True), orc.IspParams(orc.DRONE_CAMERA_PARAMS), dev)
+for _ in range(4):
+    y = m(raw)
+torch.cuda.synchronize()
+lib = _lib.device_library()
+lib.cdll.r2l_test_debug_offset.restype = ctypes.c_size_t
+off = lib.cdll.r2l_test_debug_offset(B, H, W)
+tl = y.grad_fn.ws[off:off + 8 * 24576].view(torch.int64).cpu()
+t0 = None
+for k, name in enumerate(('luma', 'stats', 'apply')):
+    d = tl[8192 * k:8192 * (k + 1)].view(-1, 2)
+    d = d[d[:, 1] > 0]
+    if len(d) == 0:
+        continue
+    if t0 is None:
+        t0 = d[:, 0].min().item()
+    st, en = (d[:, 0] - t0).double() / 100, (d[:, 1] - t0).double() / 100
+    dur = en - st
+    print(f'{name}: {len(d)} workgroups; first start {st.min():.1f} us, last start {st.max():.1f}; first end {en.min():.1f}, last end '
+          f'{en.max():.1f}; duration min {dur.min():.1f} median {dur.median():.1f} max {dur.max():.1f} us')
+    q = torch.tensor([0.1, 0.25, 0.5, 0.75, 0.9], dtype=torch.float64)
+    print('   start quantiles', [round(x, 1) for x in st.quantile(q).tolist()], ' end quantiles', [round(x, 1) for x in en.quantile(q).tolist()])
+
+# ---- does the slow start of the first kernel come from the tiny prologue kernel in front of it?  The statistics pass alone
+# (C ABI, folded weights valid: no prologue launch), directly behind a chip-filling kernel
+if os.environ.get('R2L_FORCE_SPLIT'):
+    from raw2logit_amd._lib import ptr
+    P = torch.from_numpy(orc.IspParams(orc.DRONE_CAMERA_PARAMS).pack()).to(dev)
+    ws = y.grad_fn.ws
+    n = ws.numel()
+    st7 = torch.empty(7, dtype=torch.float64, device=dev)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    big = torch.empty(64 << 20, device=dev)
+    for mode in ('behind a fill kernel', 'behind an idle stream'):
+        for _ in range(3):
+            if mode == 'behind a fill kernel':
+                big.fill_(1.0)
+            else:
+                torch.cuda.synchronize()
+            lib.check(lib.r2l_isp_fwd(ptr(raw), ptr(P), None, None, None, ptr(st7), ptr(ws), n, B, H, W, 1 | 2, s), 'stats')
+        torch.cuda.synchronize()
+        tl = ws[off:off + 8 * 24576].view(torch.int64).cpu()
+        d = tl[:8192].view(-1, 2)
+        d = d[d[:, 1] > 0]
+        st = (d[:, 0] - d[:, 0].min()).double() / 100
+        print(f'luma pass {mode}, no prologue kernel: {len(d)} workgroups, last start {st.max():.1f} us; start quantiles',
+              [round(x, 1) for x in st.quantile(q).tolist()])
