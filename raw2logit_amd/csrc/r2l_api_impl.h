@@ -421,7 +421,11 @@ static R2LWorkspace r2l_carve(void* base, int B, int H, int W) {
   w.counters = (unsigned*)(p + off);
   off += r2l_align_up(sizeof(unsigned) * (1 + R2L_MAX_GROUPS));
   w.debug = (float*)(p + off);
+#ifdef R2L_EXP_STAMPS
+  off += r2l_align_up(sizeof(float) * 4 * 8 * R2L_MAX_BLOCKS);  // + the wavefront placement records (tests/timeline_fwd.py)
+#else
   off += r2l_align_up(sizeof(float) * 3 * 8 * R2L_MAX_BLOCKS);
+#endif
   w.packed = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * R2L_P_COUNT);
   w.bn = (float*)(p + off);

@@ -49,6 +49,11 @@ struct R2LFwdStreamArgs {
   if ((a).tl && (bid) < 4096 && threadIdx.x == 0) {                              \
     (a).tl[2 * (bid)] = tl0_;                                                    \
     (a).tl[2 * (bid) + 1] = __builtin_amdgcn_s_memrealtime();                    \
+  }                                                                              \
+  if ((a).tl && (a).stat_partial && (bid) < 1024 && (threadIdx.x & 63) == 0) { /* where every wavefront of the statistics kernel ran: HW_ID (4), XCC_ID (20) */ \
+    (a).tl[16384 + (bid) * 4 + (threadIdx.x >> 6)] = /* (tl = area + 8192 in this kernel) */                             \
+        ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32) | \
+        (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));         \
   }
 #else
 #define R2L_TL_BEGIN(a, bid)

@@ -19,6 +19,7 @@ lib = _lib.device_library()
 lib.cdll.r2l_test_debug_offset.restype = ctypes.c_size_t
 off = lib.cdll.r2l_test_debug_offset(B, H, W)
 tl = y.grad_fn.ws[off:off + 8 * 24576].view(torch.int64).cpu()
+hw = y.grad_fn.ws[off + 8 * 24576:off + 8 * (24576 + 4096)].view(torch.int64).cpu()
 t0 = None
 for k, name in enumerate(('luma', 'stats', 'apply')):
     d = tl[8192 * k:8192 * (k + 1)].view(-1, 2)
@@ -33,6 +34,32 @@ for k, name in enumerate(('luma', 'stats', 'apply')):
           f'{en.max():.1f}; duration min {dur.min():.1f} median {dur.median():.1f} max {dur.max():.1f} us')
     q = torch.tensor([0.1, 0.25, 0.5, 0.75, 0.9], dtype=torch.float64)
     print('   start quantiles', [round(x, 1) for x in st.quantile(q).tolist()], ' end quantiles', [round(x, 1) for x in en.quantile(q).tolist()])
+
+# ---- where the wavefronts of the statistics kernel ran: wavefronts per SIMD, and how long the workgroups of a CU took
+hw = hw[hw != 0]
+if len(hw):
+    import collections
+    hid, xcc = hw & 0xffffffff, (hw >> 32) & 0xf
+    simd, cu, sh, se = (hid >> 4) & 3, (hid >> 8) & 0xf, (hid >> 12) & 1, (hid >> 13) & 7
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    per_simd = collections.Counter((cuid * 4 + simd).tolist())
+    per_cu = collections.Counter(cuid.tolist())
+    print(f'statistics kernel: {len(hw)} wavefronts on {len(per_cu)} CUs / {len(per_simd)} SIMDs;',
+          'wavefronts per SIMD:', sorted(collections.Counter(per_simd.values()).items()),
+          ' per CU:', sorted(collections.Counter(per_cu.values()).items()))
+    d = tl[8192:16384].view(-1, 2)
+    nb = int((d[:, 1] > 0).sum())
+    dur = ((d[:nb, 1] - d[:nb, 0]).double() / 100)
+    wg_cu = cuid.view(-1)[::1]
+    # duration of a workgroup against the wavefronts its CU hosts (wavefront 0 of workgroup b is record 4 b)
+    hw_all = y.grad_fn.ws[off + 8 * 24576:off + 8 * (24576 + 4096)].view(torch.int64).cpu().view(-1, 4)[:nb]
+    c0 = hw_all[:, 0]
+    hid0, xcc0 = c0 & 0xffffffff, (c0 >> 32) & 0xf
+    cu0 = ((xcc0 * 8 + ((hid0 >> 13) & 7)) * 2 + ((hid0 >> 12) & 1)) * 16 + ((hid0 >> 8) & 0xf)
+    for n in sorted(set(per_cu.values())):
+        sel = torch.tensor([per_cu[int(c)] == n for c in cu0.tolist()])
+        if sel.any():
+            print(f'   workgroups on CUs with {n} wavefronts: {int(sel.sum())}, duration median {dur[sel].median():.1f} max {dur[sel].max():.1f} us')
 
 # ---- does the slow start of the first kernel come from the tiny prologue kernel in front of it?  The statistics pass alone
 # (C ABI, folded weights valid: no prologue launch), directly behind a chip-filling kernel
