@@ -4,7 +4,7 @@
 # Results land in gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -57,3 +57,5 @@ python3 tests/bench_static.py > $OUT/static.txt 2>&1
 python3 tests/bench_aux.py > $OUT/aux.txt 2>&1
 if [ -f tests/_build/lib_stamps.so ]; then R2L_STAMPS_KEEP_LUMA=1 R2L_STAMPS_DETAIL=1 python3 tests/stamps.py > $OUT/stamps.txt 2>&1; fi
 ls -la $OUT
+if [ -f tests/_build/lib_tl.so ]; then R2L_STAMPS_LIB=lib_tl.so python3 tests/timeline_fwd.py > $OUT/timeline_fwd.txt 2>&1; SHAPE=64x256x256 R2L_STAMPS_LIB=lib_tl.so python3 tests/timeline_fwd.py >> $OUT/timeline_fwd.txt 2>&1; fi
+python3 tests/bench_epilogue.py > $OUT/epilogue.txt 2>&1
