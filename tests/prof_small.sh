@@ -21,7 +21,8 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if r['Kernel_Name'].startsw
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last 20 steps: per-kernel duration in launch order + gaps
 names, seq = [], []
-for r in rows[-6 * 20:]:
+first = [i for i, r in enumerate(rows) if 'pack_fold' in r['Kernel_Name']]   # the step's first launch
+for r in rows[first[-21]:first[-1]]:                                          # the last 20 whole steps
     seq.append((r['Kernel_Name'].split('(')[0].replace('r2l_launch_', '').replace('_kernel', ''), int(r['Start_Timestamp']), int(r['End_Timestamp'])))
 import collections
 dur, gap = collections.defaultdict(list), collections.defaultdict(list)
@@ -34,7 +35,7 @@ for k, v in dur.items():
     print('  dur %-28s %7.2f us' % (k, sum(v) / len(v)))
 for k, v in gap.items():
     print('  gap %-40s %7.2f us' % (k, sum(v) / len(v)))
-period = (seq[-1][1] - seq[-1 - 6 * 10][1]) / 10 / 1e3
+period = (int(rows[first[-1]]['Start_Timestamp']) - int(rows[first[-21]]['Start_Timestamp'])) / 20 / 1e3
 print('  step period (GPU timeline) %.1f us' % period)
 PY
 rm -rf $OUT/stats
