@@ -483,6 +483,21 @@ R2L_HD const R2LFolded* r2l_opaque_after(const R2LFolded* p, float dep) {
   return p;
 }
 
+// A kernel's argument block, re-read from the kernarg segment at the point of use: arguments that only the end of a kernel
+// needs (reduction tree, BatchNorm bookkeeping: 32 scalar registers' worth) otherwise stay live through the whole main
+// loop, where scalar registers are what the streaming kernels run out of (SGPR spills into VGPR lanes: 44 -> 39 with this;
+// the rest are masks and row bookkeeping of the loop itself).  The kernels here take ONE struct by value, which is the
+// start of the segment.
+#ifndef R2L_EMUL
+template <class T>
+R2L_HD const __attribute__((address_space(4))) T* r2l_kernargs() {
+  const __attribute__((address_space(4))) T* p =
+      (const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#endif
+
 // element (k, c) of T = M_RGB_2_YUV * colour_correction * diag(white_balance), float64
 R2L_HD double r2l_fold_T_one(const float* P, int k, int c) {
   double s = 0;

@@ -414,8 +414,38 @@ R2L_HD void r2l_fs_lane_sums(const r2l_p2* acc, const float* piv, double npx, bo
 // ---- statistics: the wavefronts' float64 totals -> one partial per slot and workgroup (fixed order), then the shared
 // tree; the last workgroup of the launch writes the totals and, one rank, does the BatchNorm bookkeeping
 template <int NW, int NT>
-R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a, int bid, int nblk, int tid, int wave, double* tots,
+R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nblk, int tid, int wave, double* tots,
                                      float* red) {
+  (void)a_;
+  // the arguments of this part are read here, not carried through the main loop in scalar registers (r2l_kernargs)
+  const __attribute__((address_space(4))) R2LFwdStreamArgs* ka = r2l_kernargs<R2LFwdStreamArgs>();
+  struct {
+    float* stat_partial;
+    R2LTree tree;
+    double* stats_out;
+    R2LBnFinalizeArgs fin;
+    int B, H, W;
+  } a;
+  a.stat_partial = ka->stat_partial;
+  a.tree.partial = ka->tree.partial;
+  a.tree.partial2 = ka->tree.partial2;
+  a.tree.gpartial = ka->tree.gpartial;
+  a.tree.counters = ka->tree.counters;
+  a.tree.split = ka->tree.split;
+  a.tree.nblk1 = ka->tree.nblk1;
+  a.stats_out = ka->stats_out;
+  a.fin.tot = ka->fin.tot;
+  a.fin.nranks = ka->fin.nranks;
+  a.fin.bn = ka->fin.bn;
+  a.fin.moments = ka->fin.moments;
+  a.fin.running_mean = ka->fin.running_mean;
+  a.fin.running_var = ka->fin.running_var;
+  a.fin.eps = ka->fin.eps;
+  a.fin.momentum = ka->fin.momentum;
+  a.fin.num_batches_tracked = ka->fin.num_batches_tracked;
+  a.B = ka->B;
+  a.H = ka->H;
+  a.W = ka->W;
   // ---- statistics: lanes -> one partial per slot and workgroup (fixed order), then the shared tree ------------
   {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wavefront is done with its chroma ring
