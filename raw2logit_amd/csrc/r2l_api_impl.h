@@ -15,6 +15,7 @@
 
 #include "r2l_simple_kernels.h"
 #include "r2l_param_stream.h"
+#include "r2l_param_plane_bwd.h"
 #include "r2l_static_kernels.h"
 #include "r2l_static_stream.h"
 #include "r2l_static_chain.h"
@@ -238,6 +239,12 @@ R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC
 R2L_KERNEL_V(r2l_launch_bwd1_saved_u16, R2LBwd1Args, R2L_LDS3(GBwd1) + GBwd1::PAD + R2L_B1_FRAME_FLOATS, R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, true, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, true, true, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
+#ifndef R2L_EMUL
+// kernel B1 as two passes over planes (r2l_param_plane_bwd.h): where the forward kept Y' and no epilogue / additive layer
+R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<false>)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_u16, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<true>)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd1_blur, R2LBwd1Args, R2L_BP_NT, R2L_BP_RED_FLOATS, 3, r2l_bwd1_blur_block)
+#endif
 R2L_KERNEL_V(r2l_launch_bwd2, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bwd2_block<GBwd2, false>)
 R2L_KERNEL_V(r2l_launch_fwd_u16, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, true>)
 R2L_KERNEL_V(r2l_launch_fwd_ragged_u16, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true, true>)
@@ -791,10 +798,43 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   const bool saved = (flags & R2L_F_KEEP_LUMA) && r2l_fwd_streams(additive, W) && !r2l_env_int("R2L_BWD1_RECOMPUTE", 0);
   a1.yp = saved ? ws.yp : nullptr;
   a1.ep = (ep && ep->on) ? *ep : R2LEpi{0, 0, 0, 0};
+  a1.band_h = 0;
   if (a1.ep.on && additive) return r2l_fail(-3, "r2l_isp_bwd: no output epilogue with an additive layer");
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
+  int g1p = 0;  // workgroups of the plane passes, when they run
+#ifndef R2L_EMUL
+  if (saved && !a1.ep.on && !r2l_env_int("R2L_BWD1_TILED", 0)) {
+    // persistent workgroups of 4 independent wavefronts, two per CU (<= 256 VGPRs), not more workgroups than kernel B2
+    // runs (its last workgroups reduce both kernels' partials); band height as for the forward's plane passes
+    const long nstrip = (W + 255) / 256, slots = 256L * 4 * 2;
+    int bh = 6;
+    long best = -1;
+    for (int c = 6; c <= 48; c += 6) {
+      const long items = (long)B * nstrip * ((H + c - 1) / c);
+      const long cost = ((items + slots - 1) / slots) * (10L * c + 32);
+      if (best < 0 || cost < best) {
+        best = cost;
+        bh = c;
+      }
+    }
+    a1.band_h = (r2l_env_int("R2L_BP_BAND", bh) + 5) / 6 * 6;
+    const long items = (long)B * nstrip * ((H + a1.band_h - 1) / a1.band_h);
+    long g = (items + R2L_BP_NWV - 1) / R2L_BP_NWV;
+    const long cap = r2l_env_int("R2L_GRID_BWD1", 512);
+    if (g > cap) g = cap;
+    if (g > R2L_MAX_BLOCKS) g = R2L_MAX_BLOCKS;
+    g1p = (int)g;
+  }
+#endif
   int e1;
-  if (saved)
+  if (g1p) {
+#ifndef R2L_EMUL
+    e1 = raw.u16 ? r2l_launch_bwd1_plane_u16(a1, g1p, stream) : r2l_launch_bwd1_plane(a1, g1p, stream);
+    if (!e1) e1 = r2l_launch_bwd1_blur(a1, g1p, stream);
+#else
+    e1 = 0;
+#endif
+  } else if (saved)
     e1 = raw.u16 ? (exact ? r2l_launch_bwd1_saved_u16(a1, g1, stream) : r2l_launch_bwd1_saved_ragged_u16(a1, g1, stream))
                  : (exact ? r2l_launch_bwd1_saved(a1, g1, stream) : r2l_launch_bwd1_saved_ragged(a1, g1, stream));
   else if (raw.u16)
@@ -820,8 +860,9 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   // of B2's grid adds the B1 partials of its own 16 workgroup ids, as far as they exist) and unfold them into the
   // 132 gradients; if B1 ran MORE workgroups than B2 (R2L_GRID_* overrides of diagnostic builds) three tiny
   // launches do it
-  const bool in_kernel = g1 <= g2;
-  a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC, g1};
+  const int g1w = g1p ? g1p : g1;  // workgroups that wrote B1's partials
+  const bool in_kernel = g1w <= g2;
+  a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC, g1w};
   a2.params = params;
   a2.grad_params = grad_params;
   // uneven tile shares for the two workgroups of a CU (r2l_walk_init): measured, no gain -- the younger workgroup is
@@ -834,7 +875,7 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   if (a2.asym == 1) a2.asym = 0;
   if (int e = raw.u16 ? r2l_launch_bwd2_u16(a2, g2, stream) : r2l_launch_bwd2(a2, g2, stream)) return e;
   if (in_kernel) return 0;
-  R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1, 1.0, nullptr};
+  R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1w, 1.0, nullptr};
   if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
   R2LReduceRowsArgs r2{ws.part_b2, ws.sums + R2L_B1_NACC, g2, 1.0, nullptr};
   if (int e = r2l_launch_reduce_rows(r2, R2L_B2_NACC, stream)) return e;

@@ -1,0 +1,474 @@
+// r2l_param_plane_bwd.h -- kernel B1 of the backward (r2l_bwd1_block, r2l_param_kernels.h: BatchNorm / gamma / clip /
+// YUV->RGB adjoints, d/d blur weights, d/d chroma stencils, d/d gamma, dL/dY'' out) as TWO passes over planes, organised
+// like the apply pass of the forward (r2l_fwd_apply_block, r2l_param_stream.h) instead of as LDS tiles: INDEPENDENT
+// wavefronts, a wavefront owns (image, band of rows, 256-column strip) and walks down the band with its windows and
+// accumulators in registers.  Everything B1 needs is a gather from planes (raw, the kept Y', grad_out), so there is no
+// exchange between wavefronts, no halo to recompute, no phases, no barriers.
+//   r2l_bwd1_plane_block  raw + Y' + grad_out -> dL/dY'' (stored), chroma-stencil / black-level / gamma sums
+//   r2l_bwd1_blur_block   dL/dY'' + Y'        -> the 25 blur-weight sums
+// Two kernels because one does not fit: windows (66 registers) + prefetch (36) + all 46 accumulator pairs (92) +
+// the pointwise part's temporaries need more than the 256 registers of two wavefronts per SIMD (125 spilled registers);
+// without the 25 blur pairs the first pass takes 211.  The second pass re-reads dL/dY'' (4 B/px) and Y' (4 B/px).
+//
+// What the tile kernel's threads did not have to handle: a lane sees BOTH row parities.  The parity-indexed sums (folded
+// chroma stencils GAU / GAV [row parity][tap] x column-parity pair, SU / SV) therefore exist twice, 20 pairs per row
+// parity; the bank of the row at hand is in registers, the other one in a wavefront-private LDS area, swapped in place
+// (4 floats at a time) once per row: 10 ds_read_b128 + 10 ds_write_b128 against ~300 vector instructions of a row step.
+// Border rows: window rows outside the image are zero; the forward takes the blur's border-row weight sets (as the
+// forward kernels do), and the first / last two image rows add the mirror padding's share of the blur-weight sums as a
+// few extra products of their own window rows (row -1 IS row 1, ...) behind uniform branches; mirror columns are part
+// of the 8-wide rows as in the forward; raw rows are fetched mirrored.
+#pragma once
+#include "r2l_param_stream.h"
+
+#ifndef R2L_EMUL
+
+#ifndef R2L_BP_PF
+#define R2L_BP_PF 2   // rows of raw / Y' in flight
+#endif
+#ifndef R2L_BP_PFG
+#define R2L_BP_PFG 1  // rows of grad_out in flight (12 registers each)
+#endif
+#define R2L_BP_NWV 4                                  // wavefronts (work items in flight) per workgroup
+#define R2L_BP_BANK 40                                // floats of one parity bank: GAU[9], GAV[9], SU, SV as pairs
+#define R2L_BP_NT (64 * R2L_BP_NWV)
+#define R2L_BP_RED_FLOATS (32 * (R2L_BP_NT + 1) + 32 * 16)
+#define R2L_BP_SWAP_FLOATS (R2L_BP_NWV * 64 * R2L_BP_BANK)
+#define R2L_BP_LDS_FLOATS (R2L_BP_SWAP_FLOATS > R2L_BP_RED_FLOATS ? R2L_BP_SWAP_FLOATS : R2L_BP_RED_FLOATS)
+
+struct R2LBpStage {  // grad_out of one row in flight: 3 channels x the lane's 4 pixels
+  r2l_f4 g[3];
+};
+R2L_HD void r2l_bp_fetch_g(const float* gimg, unsigned plane, int y, int H, int W, int x0, R2LBpStage& s) {
+  const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+  const float* p = gimg + (size_t)yc * W + x0;
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) s.g[k] = r2l_load_f4_nt(p + (size_t)k * plane);  // read once: nontemporal (as kernel B1)
+}
+
+struct R2LBpState {
+  float v[3][6];   // V rows (slot = row mod 3)
+  float yp[6][8];  // Y' rows (slot = row mod 6)
+};
+struct R2LBpAcc {
+  r2l_p2 gau[9];    // bank of the CURRENT row parity: sum gU(p) * v_ext(p + t), halves = column parity
+  r2l_p2 gav[9];
+  r2l_p2 su, sv;
+  r2l_p2 ggam;
+};
+
+// the bank in registers <-> the bank in the wavefront's LDS area, in place, 4 floats at a time
+R2L_HD void r2l_bp_swap(R2LBpAcc& A, float* bank /* this lane's 40 floats, [chunk][lane][4] */) {
+  float* f[10];
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 10; ++c) f[c] = bank + c * 64 * 4;
+#define R2L_BP_SW(c, a, b)                      \
+  {                                             \
+    const r2l_f4 old = r2l_lds_f4(f[c]);        \
+    r2l_f4 nw;                                  \
+    nw.x = (a)[0];                              \
+    nw.y = (a)[1];                              \
+    nw.z = (b)[0];                              \
+    nw.w = (b)[1];                              \
+    *(r2l_f4*)f[c] = nw;                        \
+    (a) = r2l_mk2(old.x, old.y);                \
+    (b) = r2l_mk2(old.z, old.w);                \
+  }
+  R2L_BP_SW(0, A.gau[0], A.gau[1])
+  R2L_BP_SW(1, A.gau[2], A.gau[3])
+  R2L_BP_SW(2, A.gau[4], A.gau[5])
+  R2L_BP_SW(3, A.gau[6], A.gau[7])
+  R2L_BP_SW(4, A.gau[8], A.gav[0])
+  R2L_BP_SW(5, A.gav[1], A.gav[2])
+  R2L_BP_SW(6, A.gav[3], A.gav[4])
+  R2L_BP_SW(7, A.gav[5], A.gav[6])
+  R2L_BP_SW(8, A.gav[7], A.gav[8])
+  R2L_BP_SW(9, A.su, A.sv)
+#undef R2L_BP_SW
+}
+
+// one output row y (K = y mod 6, row parity K & 1); the windows hold V(y-1 .. y+1) and Y'(y-2 .. y+2)
+template <int K>
+R2L_HD void r2l_bp_step(const R2LBwd1Args& a, R2LBpState& st, R2LBpAcc& A, const R2LBpStage& gs, int y, bool store_ok,
+                        float* gyb, int x0, const R2LBnConsts& bc) {
+  constexpr int PY = K & 1;
+  const int H = a.H;
+  // ---- the blur's window: rows outside the image are zero; the forward takes the weight sets with the mirror padding
+  // folded in for the first / last two image rows (as the forward kernels do) -----------------------------------------
+  float yw[5][8];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 5; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 8; ++j) yw[i][j] = st.yp[(K + 4 + i) % 6][j];
+  r2l_p2 ypp[2], u[2], v[2];
+  {
+    R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, yw[2][2]));
+    const int set = (y < 2) ? y : (y - (H - 2)) + 2;
+    const __attribute__((address_space(4))) float* w25 =
+        (y >= 2 && y < H - 2) ? &F.blur[0] : &F.blur_edge[0][0] + 25 * set;
+    r2l_blur_row2w(yw, w25, ypp);
+  }
+  const float* vu = st.v[(K + 2) % 3];  // V(y-1)
+  const float* vm = st.v[K % 3];        // V(y)
+  const float* vl = st.v[(K + 1) % 3];  // V(y+1)
+  {
+    R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, ypp[1][1]));
+    r2l_fs_stencil_parity(vu, vm, vl, F.AU2[PY], u);
+    r2l_fs_stencil_parity(vu, vm, vl, F.AV2[PY], v);
+  }
+  // ---- pointwise part: forward values, BatchNorm / gamma / clip adjoints (r2l_bwd1_row) --------------------------------
+  r2l_p2 gy2[2], gu[2], gv[2];
+  {
+    R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, v[1][1]));
+    r2l_p2 grgb[3][2];
+    r2l_p2 ggam = r2l_splat2(0.f);
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      const float g[4] = {gs.g[k].x, gs.g[k].y, gs.g[k].z, gs.g[k].w};
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) {
+        r2l_p2 rgb = r2l_pmul(r2l_splat2(F.M2[k * 3]), ypp[p]);
+        rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 1]), u[p], rgb);
+        rgb = r2l_pfma(r2l_splat2(F.M2[k * 3 + 2]), v[p], rgb);
+        const r2l_p2 xc = r2l_mk2(fminf(fmaxf(rgb[0], 1e-5f), 1.0f), fminf(fmaxf(rgb[1], 1e-5f), 1.0f));
+        const r2l_p2 lg = r2l_mk2(r2l_log2(xc[0]), r2l_log2(xc[1]));
+        const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));
+        const r2l_p2 og = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
+        const r2l_p2 xhat = r2l_pmul(r2l_padd(og, r2l_splat2(-bc.mean[k])), r2l_splat2(bc.istd[k]));
+        r2l_p2 gx = r2l_padd(r2l_mk2(g[2 * p], g[2 * p + 1]), r2l_splat2(-bc.mg[k]));  // BatchNorm2d backward
+        gx = r2l_pmul(r2l_splat2(bc.istd[k]), r2l_pfma(xhat, r2l_splat2(-bc.mgx[k]), gx));
+        if (!store_ok) gx = r2l_splat2(0.f);  // lanes past the frame's last column, rows past the band's end
+        const r2l_p2 gxo = r2l_pmul(gx, og);
+        ggam = r2l_pfma(gxo, lg, ggam);
+        const r2l_p2 gc = r2l_pmul(r2l_pmul(gxo, r2l_splat2(F.inv_gamma)), r2l_mk2(r2l_rcp(xc[0]), r2l_rcp(xc[1])));
+        grgb[k][p] = r2l_mk2((rgb[0] == xc[0]) ? gc[0] : 0.f, (rgb[1] == xc[1]) ? gc[1] : 0.f);  // clip backward
+      }
+    }
+    A.ggam = r2l_padd(A.ggam, ggam);
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) {
+      gy2[p] = r2l_pfma(r2l_splat2(F.M2[6]), grgb[2][p],
+                        r2l_pfma(r2l_splat2(F.M2[3]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[0]), grgb[0][p])));
+      gu[p] = r2l_pfma(r2l_splat2(F.M2[7]), grgb[2][p],
+                       r2l_pfma(r2l_splat2(F.M2[4]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[1]), grgb[0][p])));
+      gv[p] = r2l_pfma(r2l_splat2(F.M2[8]), grgb[2][p],
+                       r2l_pfma(r2l_splat2(F.M2[5]), grgb[1][p], r2l_pmul(r2l_splat2(F.M2[2]), grgb[0][p])));
+    }
+  }
+  if (store_ok) {
+    r2l_f4 s4;
+    s4.x = gy2[0][0];
+    s4.y = gy2[0][1];
+    s4.z = gy2[1][0];
+    s4.w = gy2[1][1];
+    *(r2l_f4*)(gyb + (unsigned)y * (unsigned)a.W + (unsigned)x0) = s4;
+  }
+  // ---- folded chroma stencils of this row's parity ----------------------------------------------------------------------
+  const float* rows[3] = {vu, vm, vl};
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    r2l_p2 su = A.gau[i * 3 + j], sv = A.gav[i * 3 + j];
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) {
+      const r2l_p2 x = r2l_mk2(rows[i][2 * p + j], rows[i][2 * p + j + 1]);
+      su = r2l_pfma(gu[p], x, su);
+      sv = r2l_pfma(gv[p], x, sv);
+    }
+    A.gau[i * 3 + j] = su;
+    A.gav[i * 3 + j] = sv;
+  }
+  A.su = r2l_padd(A.su, r2l_padd(gu[0], gu[1]));
+  A.sv = r2l_padd(A.sv, r2l_padd(gv[0], gv[1]));
+}
+
+// value of global slot i (layout R2L_B1_*, r2l_common.h) held by a lane: E = the even-row bank, O = the odd-row bank
+R2L_HD float r2l_bp_slot(const R2LBpAcc& A, const float* E, const float* O, int i) {
+  if (i < R2L_B1_GAU) return 0.f;  // (the blur-weight sums: r2l_bwd1_blur_block, which runs behind this kernel)
+  if (i < R2L_B1_SU) {
+    const int tbl = (i - R2L_B1_GAU) / 36, k = (i - R2L_B1_GAU) % 36, par = k / 9, t = k % 9;
+    const float* b = (par >> 1) ? O : E;  // bank layout: gau[9] pairs, gav[9] pairs, su, sv
+    return b[(tbl * 9 + t) * 2 + (par & 1)];
+  }
+  if (i < R2L_B1_GGAM) {
+    const int tbl = (i - R2L_B1_SU) / 4, par = (i - R2L_B1_SU) % 4;
+    const float* b = (par >> 1) ? O : E;
+    return b[(18 + tbl) * 2 + (par & 1)];
+  }
+  return A.ggam[0] + A.ggam[1];
+}
+
+// lanes -> one partial per slot and workgroup, in a fixed order (R2L_BLOCK_REDUCE_F for R2L_BP_NT threads): slots
+// [0, NSLOTS) of val(i) go to partial[(slot0 + i) * nblk + bid]
+template <int NSLOTS, class VAL>
+R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int slot0, int bid, int nblk, VAL&& val) {
+  constexpr int NT = R2L_BP_NT;
+  R2L_PRAGMA_UNROLL
+  for (int base = 0; base < NSLOTS; base += 32) {
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 32; ++i)
+      if (base + i < NSLOTS) lds[i * (NT + 1) + tid] = val(base + i);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+      const int slot = tid >> 4, part = tid & 15;  // 16 lanes per slot add NT / 16 values each; 32 slots in 32 * 16 / NT passes
+      R2L_PRAGMA_UNROLL
+      for (int h = 0; h < 32 * 16 / NT; ++h) {
+        const int sl = slot + h * (NT / 16);
+        float s = 0.f;
+        if (base + sl < NSLOTS) {
+          R2L_PRAGMA_UNROLL
+          for (int j = 0; j < NT / 16; ++j) s += lds[sl * (NT + 1) + part + 16 * j];
+        }
+        lds[32 * (NT + 1) + sl * 16 + part] = s;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid < 32 && base + tid < NSLOTS) {
+      float s = 0.f;
+      R2L_PRAGMA_UNROLL
+      for (int j = 0; j < 16; ++j) s += lds[32 * (NT + 1) + tid * 16 + j];
+      r2l_store_coherent(&partial[(size_t)(slot0 + base + tid) * nblk + bid], s);
+    }
+    R2L_STORES_DONE();  // B2's last workgroups finish the reduction
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
+template <bool U16>
+R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, float* lds) {
+  constexpr int NWV = R2L_BP_NWV, NT = R2L_BP_NT;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
+  float* bank = lds + (size_t)wave * 64 * R2L_BP_BANK + lane * 4;  // [chunk][lane][4]
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 10; ++c) {
+    r2l_f4 z;
+    z.x = z.y = z.z = z.w = 0.f;
+    *(r2l_f4*)(bank + c * 64 * 4) = z;
+  }
+  R2LBpAcc A;
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 9; ++i) A.gau[i] = A.gav[i] = r2l_splat2(0.f);
+  A.su = A.sv = A.ggam = r2l_splat2(0.f);
+  R2LBnConsts bc;
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) {
+    bc.mean[k] = a.bn ? a.bn[k] : 0.f;
+    bc.istd[k] = a.bn ? a.bn[3 + k] : 1.f;
+    bc.mg[k] = a.bn_bwd ? a.bn_bwd[k] : 0.f;
+    bc.mgx[k] = a.bn_bwd ? a.bn_bwd[3 + k] : 0.f;
+  }
+  // the streaming kernels' argument block, for their raw-row fetch / convert (r2l_fa_fetch_raw, r2l_fs_convert)
+  R2LFwdStreamArgs sa;
+  sa.raw = a.raw;
+  sa.W = a.W;
+  sa.H = a.H;
+  const int nstrip = (a.W + 255) >> 8;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const int band_h = a.band_h, nband = (a.H + band_h - 1) / band_h, nitems = a.B * nband * nstrip;
+  constexpr int PF = R2L_BP_PF, PFG = R2L_BP_PFG;
+  static_assert(6 % PF == 0 && 6 % PFG == 0, "the prefetch rings are indexed by the unroll position");
+  // the registers hold the bank of EVEN rows between items (every band starts on an even row, at K = 0)
+  R2L_PRAGMA_NOUNROLL
+  for (int item = bid * NWV + wave; item < nitems; item += nblk * NWV) {
+    const int strip = item % nstrip, ib = item / nstrip;
+    const int band = ib % nband, b = ib / nband;
+    const int xs = strip * 256 + 4 * lane;
+    const bool in_w = xs < a.W;
+    const int x0 = in_w ? xs : a.W - 4;
+    const bool le = x0 == 0, re = x0 + 4 >= a.W;
+    const int y0 = band * band_h;  // a multiple of 6
+    const int y1 = (y0 + band_h < a.H) ? y0 + band_h : a.H;
+    const size_t img = (size_t)b * plane;
+    const float* ypimg = a.yp + img;
+    const float* gimg = a.gout + (size_t)b * 3 * plane;
+    float* gyb = a.gypp + img;
+    R2LBpState st;
+    R2LFsStage pf[PF];   // raw row q + 1
+    R2LFaStage pfy[PF];  // Y' row q + 2
+    R2LBpStage pfg[PFG];  // grad_out row q
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < PF; ++i) {
+      r2l_fa_fetch_raw<U16>(sa, img, r2l_mirror(y0 - 3 + i, a.H), x0, le, re, lane, pf[(2 + i) % PF]);
+      r2l_fa_fetch(ypimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
+    }
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < PFG; ++i) r2l_bp_fetch_g(gimg, plane, y0 + i, a.H, a.W, x0, pfg[i % PFG]);  // (first used at K = 0)
+#define R2L_BP_LOAD_STEP(K, q)                                                                          \
+  r2l_fs_convert<U16>(sa, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3]);                                \
+  r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, st.yp[((K) + 2) % 6]);       \
+  r2l_fa_fetch_raw<U16>(sa, img, r2l_mirror((q) + 1 + PF, a.H), x0, le, re, lane, pf[(K) % PF]);        \
+  r2l_fa_fetch(ypimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);
+    R2L_BP_LOAD_STEP(2, y0 - 4)
+    R2L_BP_LOAD_STEP(3, y0 - 3)
+    R2L_BP_LOAD_STEP(4, y0 - 2)
+    R2L_BP_LOAD_STEP(5, y0 - 1)
+    // every group of 6 steps runs in full (rows past the band's end: clamped fetches, zero cotangent, nothing stored);
+    // 6 is even, so the banks are back in place at the end of a group
+    for (int qb = y0; qb < y1; qb += 6) {
+#define R2L_BP_STEP(K)                                                                                  \
+  {                                                                                                     \
+    const int q = qb + K;                                                                               \
+    R2L_BP_LOAD_STEP(K, q)                                                                              \
+    const R2LBpStage g_ = pfg[(K) % PFG];                                                               \
+    r2l_bp_fetch_g(gimg, plane, q + PFG, a.H, a.W, x0, pfg[(K) % PFG]);                                 \
+    if (K) r2l_bp_swap(A, bank); /* the bank of this row's parity into the registers */                 \
+    if (r2l_opaque_true()) r2l_bp_step<K>(a, st, A, g_, q, in_w && q < y1, gyb, x0, bc);                \
+  }
+      R2L_BP_STEP(0)
+      R2L_BP_STEP(1)
+      R2L_BP_STEP(2)
+      R2L_BP_STEP(3)
+      R2L_BP_STEP(4)
+      R2L_BP_STEP(5)
+      r2l_bp_swap(A, bank);  // (K = 5 was an odd row)
+#undef R2L_BP_STEP
+    }
+#undef R2L_BP_LOAD_STEP
+  }
+  // ---- lanes -> one partial per slot and workgroup, fixed order (R2L_BLOCK_REDUCE_F for NT threads) ----------------------
+  float E[R2L_BP_BANK], O[R2L_BP_BANK];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 9; ++i) {
+    E[2 * i] = A.gau[i][0];
+    E[2 * i + 1] = A.gau[i][1];
+    E[18 + 2 * i] = A.gav[i][0];
+    E[18 + 2 * i + 1] = A.gav[i][1];
+  }
+  E[36] = A.su[0];
+  E[37] = A.su[1];
+  E[38] = A.sv[0];
+  E[39] = A.sv[1];
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 10; ++c) {
+    const r2l_f4 o4 = r2l_lds_f4(bank + c * 64 * 4);
+    O[4 * c] = o4.x;
+    O[4 * c + 1] = o4.y;
+    O[4 * c + 2] = o4.z;
+    O[4 * c + 3] = o4.w;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
+  r2l_bp_block_reduce<R2L_B1_NACC>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return r2l_bp_slot(A, E, O, i); });
+}
+
+// ---- second pass: the 25 blur-weight sums  d/d gaussian_blur.weight[i][j] = sum_p gY''(p) * Y'_ext(p + (i-2, j-2)) from
+// the dL/dY'' plane the first pass wrote and the kept Y' plane --------------------------------------------------------
+struct R2LBbStage {
+  r2l_f4 g;  // dL/dY'' of the lane's 4 pixels
+};
+template <int K>
+R2L_HD void r2l_bb_step(const R2LBwd1Args& a, const float yp[6][8], r2l_p2 blur[25], const R2LBbStage& gs, int y,
+                        bool ok) {
+  const int H = a.H;
+  float yw[5][8];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 5; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 8; ++j) yw[i][j] = yp[(K + 4 + i) % 6][j];
+  r2l_p2 gy2[2];
+  gy2[0] = r2l_mk2(ok ? gs.g.x : 0.f, ok ? gs.g.y : 0.f);  // (lanes past the last column, rows past the band's end)
+  gy2[1] = r2l_mk2(ok ? gs.g.z : 0.f, ok ? gs.g.w : 0.f);
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 5; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 5; ++j) {
+    r2l_p2 s = blur[i * 5 + j];
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) s = r2l_pfma(gy2[p], r2l_mk2(yw[i][2 * p + j], yw[i][2 * p + j + 1]), s);
+    blur[i * 5 + j] = s;
+  }
+  // ... and the mirror padding's share on the first / last two image rows (window rows outside the image are zero): row
+  // -1 IS row 1 (window row 2 of y = 1, 3 of y = 0), row -2 is row 2 (window row 4 of y = 0); row H is row H-2, row H+1
+  // is row H-3 likewise.  src = the window row that holds the mirrored row, dst = the window row it stands in for.
+#define R2L_BP_MIRROR(dst, src)                                                                          \
+  R2L_PRAGMA_UNROLL                                                                                      \
+  for (int j = 0; j < 5; ++j) {                                                                          \
+    r2l_p2 s = blur[(dst) * 5 + j];                                                                      \
+    R2L_PRAGMA_UNROLL                                                                                    \
+    for (int p = 0; p < 2; ++p) s = r2l_pfma(gy2[p], r2l_mk2(yw[src][2 * p + j], yw[src][2 * p + j + 1]), s); \
+    blur[(dst) * 5 + j] = s;                                                                             \
+  }
+  if (y < 2 || y >= H - 2) {  // uniform
+    if (y == 0) {
+      R2L_BP_MIRROR(0, 4)
+      R2L_BP_MIRROR(1, 3)
+    }
+    if (y == 1) R2L_BP_MIRROR(0, 2)
+    if (y == H - 2) R2L_BP_MIRROR(4, 2)
+    if (y == H - 1) {
+      R2L_BP_MIRROR(3, 1)
+      R2L_BP_MIRROR(4, 0)
+    }
+  }
+#undef R2L_BP_MIRROR
+}
+#ifndef R2L_BB_PF
+#define R2L_BB_PF 2
+#endif
+R2L_BLOCKFN void r2l_bwd1_blur_block(const R2LBwd1Args& a, int bid, int nblk, float* lds) {
+  constexpr int NWV = R2L_BP_NWV;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  r2l_p2 blur[25];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 25; ++i) blur[i] = r2l_splat2(0.f);
+  const int nstrip = (a.W + 255) >> 8;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const int band_h = a.band_h, nband = (a.H + band_h - 1) / band_h, nitems = a.B * nband * nstrip;
+  constexpr int PF = R2L_BB_PF;
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  R2L_PRAGMA_NOUNROLL
+  for (int item = bid * NWV + wave; item < nitems; item += nblk * NWV) {
+    const int strip = item % nstrip, ib = item / nstrip;
+    const int band = ib % nband, b = ib / nband;
+    const int xs = strip * 256 + 4 * lane;
+    const bool in_w = xs < a.W;
+    const int x0 = in_w ? xs : a.W - 4;
+    const bool le = x0 == 0, re = x0 + 4 >= a.W;
+    const int y0 = band * band_h;  // a multiple of 6
+    const int y1 = (y0 + band_h < a.H) ? y0 + band_h : a.H;
+    const size_t img = (size_t)b * plane;
+    const float* ypimg = a.yp + img;
+    const float* gimg = a.gypp + img;
+    float yp[6][8];
+    R2LFaStage pfy[PF];  // Y' row q + 2
+    R2LBbStage pfg[PF];  // dL/dY'' row q
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < PF; ++i) {
+      r2l_fa_fetch(ypimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
+      const int yc = (y0 + i < a.H) ? y0 + i : a.H - 1;
+      pfg[i % PF].g = r2l_stream_load_f4(gimg + (size_t)yc * a.W + x0);
+    }
+#define R2L_BB_LOAD_STEP(K, q)                                                                          \
+  r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, yp[((K) + 2) % 6]);          \
+  r2l_fa_fetch(ypimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);
+    R2L_BB_LOAD_STEP(2, y0 - 4)
+    R2L_BB_LOAD_STEP(3, y0 - 3)
+    R2L_BB_LOAD_STEP(4, y0 - 2)
+    R2L_BB_LOAD_STEP(5, y0 - 1)
+    for (int qb = y0; qb < y1; qb += 6) {
+#define R2L_BB_STEP(K)                                                                                  \
+  {                                                                                                     \
+    const int q = qb + K;                                                                               \
+    R2L_BB_LOAD_STEP(K, q)                                                                              \
+    const R2LBbStage g_ = pfg[(K) % PF];                                                                \
+    {                                                                                                   \
+      const int yc = (q + PF < a.H) ? q + PF : a.H - 1;                                                 \
+      pfg[(K) % PF].g = r2l_stream_load_f4(gimg + (size_t)yc * a.W + x0);                               \
+    }                                                                                                   \
+    if (r2l_opaque_true()) r2l_bb_step<K>(a, yp, blur, g_, q, in_w && q < y1);                          \
+  }
+      R2L_BB_STEP(0)
+      R2L_BB_STEP(1)
+      R2L_BB_STEP(2)
+      R2L_BB_STEP(3)
+      R2L_BB_STEP(4)
+      R2L_BB_STEP(5)
+#undef R2L_BB_STEP
+    }
+#undef R2L_BB_LOAD_STEP
+  }
+  r2l_bp_block_reduce<R2L_B1_GAU>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return blur[i][0] + blur[i][1]; });
+}
+
+#endif  // !R2L_EMUL

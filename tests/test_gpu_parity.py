@@ -470,6 +470,52 @@ def test_backward_reads_the_luma_plane_the_forward_kept(shape, dev):
             assert e <= lim, (shape, bn, n, e, lim)
 
 
+@pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256), (5, 18, 8),
+                                   (2, 514, 512), (3, 4, 4), (2, 6, 1024), (4, 256, 256), (2, 8, 256), (9, 64, 64)], ids=str)
+def test_backward_kernel_b1_as_passes_over_planes(shape, dev):
+    """Kernel B1 as two passes of independent wavefronts over the raw / Y' / grad_out planes (r2l_param_plane_bwd.h:
+    pointwise adjoints + dL/dY'' + chroma / gamma sums, then the 25 blur-weight sums from dL/dY'' and Y') against the LDS
+    tile kernel of the diagnostic build (R2L_BWD1_TILED): all 132 gradients, float32 and 16-bit frames, with and without
+    train-mode BatchNorm, every band height and grid (one wavefront takes everything ... one item each), frames of 4 rows
+    (every row a border row of the blur) -- and, through the golden / frame-shape / fuzz suites, against the oracle."""
+    import os
+    B, H, W = shape
+    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+    P.perturb(19)
+    u = np.rint(orc.synth_raw(B, H, W, seed=2 * H + W, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
+    cot = torch.from_numpy(np.random.default_rng(H + 2).standard_normal((B, 3, H, W)).astype(np.float32)).to(dev)
+    for bn in (True, False):
+        case = dict(camera='drone', track=False, additive=False, training=True, bn=bn)
+
+        def run(env, frames):
+            m = pc.make_module(case, P, dev)
+            if frames == 'u16':
+                m.raw_bits = 12
+                raw = torch.from_numpy(u).to(dev)
+            else:
+                raw = torch.from_numpy(u.astype(np.float32) / np.float32(4095)).to(dev)
+            os.environ.update(env)
+            try:
+                with pc.launch_shape_overrides(dev):
+                    (m(raw) * cot).sum().backward()
+            finally:
+                for k in env:
+                    del os.environ[k]
+            return {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
+
+        ref = run({'R2L_BWD1_TILED': '1'}, 'f32')
+        worst = 0.0
+        for env, frames in (({}, 'f32'), ({}, 'u16'), ({'R2L_BP_BAND': '6'}, 'f32'), ({'R2L_BP_BAND': '12', 'R2L_GRID_BWD1': '1'}, 'f32'),
+                            ({'R2L_BP_BAND': '1000', 'R2L_GRID_BWD1': '3'}, 'u16'), ({'R2L_GRID_BWD1': '7'}, 'f32')):
+            g = run(env, frames)
+            for n, r in ref.items():
+                e = np.abs(g[n] - r).max()
+                lim = 2e-4 * (np.abs(r).max() + 1e-6)
+                worst = max(worst, e / lim)
+                assert e <= lim, (shape, bn, env, frames, n, e, lim)
+        pc.report(f'bwd1-planes/{shape}/bn={bn}/all gradients vs tile kernel (fraction of 2e-4 relative)', worst, 1.0)
+
+
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
                                    (5, 18, 8), (2, 514, 512), (3, 4, 4), (2, 6, 1024), (4, 256, 256)], ids=str)
 def test_apply_pass_reads_the_luma_plane_the_statistics_pass_kept(shape, dev):
