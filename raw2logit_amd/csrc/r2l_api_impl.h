@@ -241,9 +241,15 @@ R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
 #ifndef R2L_EMUL
 // kernel B1 as two passes over planes (r2l_param_plane_bwd.h): where the forward kept Y' and no epilogue / additive layer
-R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<false>)
-R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_u16, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<true>)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<false, false>)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_u16, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<true, false>)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_epi, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<false, true>)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_epi_u16, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<true, true>)
 R2L_KERNEL_NT_LDS(r2l_launch_bwd1_blur, R2LBwd1Args, R2L_BP_NT, R2L_BP_RED_FLOATS, 3, r2l_bwd1_blur_block)
+// kernel B2 likewise: the blur's adjoint into a plane, then the sums + the final reduction and unfold
+R2L_KERNEL_NT_LDS(r2l_launch_bwd2_hp, R2LBwd2Args, R2L_BP_NT, 4, 4, r2l_bwd2_hp_block)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd2_sums, R2LBwd2Args, R2L_B2S_NT, R2L_B2S_LDS_FLOATS, 3, r2l_bwd2_sums_block<false>)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd2_sums_u16, R2LBwd2Args, R2L_B2S_NT, R2L_B2S_LDS_FLOATS, 3, r2l_bwd2_sums_block<true>)
 #endif
 R2L_KERNEL_V(r2l_launch_bwd2, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bwd2_block<GBwd2, false>)
 R2L_KERNEL_V(r2l_launch_fwd_u16, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, true>)
@@ -398,6 +404,7 @@ struct R2LWorkspace {
   unsigned* counters;  // [1 + R2L_MAX_GROUPS] arrival counters: zeroed by the fold kernel, zero after every launch
   float* gypp;
   float* yp;     // (B,H,W): the sharpened luma Y' of the forward, for kernel B1 (R2L_F_KEEP_LUMA)
+  float* hp;     // (B,H,W): the blur's adjoint of dL/dY'' (plane passes of kernel B2, r2l_param_plane_bwd.h)
   float* debug;  // 3 x [R2L_MAX_BLOCKS][8] floats: per-phase cycle stamps of diagnostic builds (fwd, bwd1, bwd2)
   // step block (r2l_isp_step_fwd / _bwd): what one training step keeps between its launches
   float* packed;    // [R2L_P_COUNT] the parameter values the forward saw
@@ -445,6 +452,8 @@ static R2LWorkspace r2l_carve(void* base, int B, int H, int W) {
   w.gypp = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * (size_t)B * H * W);
   w.yp = (float*)(p + off);
+  off += r2l_align_up(sizeof(float) * (size_t)B * H * W);
+  w.hp = (float*)(p + off);
   off += r2l_align_up(sizeof(float) * (size_t)B * H * W);
   w.total = off;
   return w;
@@ -803,7 +812,7 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
   int g1p = 0;  // workgroups of the plane passes, when they run
 #ifndef R2L_EMUL
-  if (saved && !a1.ep.on && !r2l_env_int("R2L_BWD1_TILED", 0)) {
+  if (saved && !r2l_env_int("R2L_BWD1_TILED", 0)) {
     // persistent workgroups of 4 independent wavefronts, two per CU (<= 256 VGPRs), not more workgroups than kernel B2
     // runs (its last workgroups reduce both kernels' partials); band height as for the forward's plane passes
     const long nstrip = (W + 255) / 256, slots = 256L * 4 * 2;
@@ -829,7 +838,8 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   int e1;
   if (g1p) {
 #ifndef R2L_EMUL
-    e1 = raw.u16 ? r2l_launch_bwd1_plane_u16(a1, g1p, stream) : r2l_launch_bwd1_plane(a1, g1p, stream);
+    e1 = a1.ep.on ? (raw.u16 ? r2l_launch_bwd1_plane_epi_u16(a1, g1p, stream) : r2l_launch_bwd1_plane_epi(a1, g1p, stream))
+                  : (raw.u16 ? r2l_launch_bwd1_plane_u16(a1, g1p, stream) : r2l_launch_bwd1_plane(a1, g1p, stream));
     if (!e1) e1 = r2l_launch_bwd1_blur(a1, g1p, stream);
 #else
     e1 = 0;
@@ -861,6 +871,44 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   // 132 gradients; if B1 ran MORE workgroups than B2 (R2L_GRID_* overrides of diagnostic builds) three tiny
   // launches do it
   const int g1w = g1p ? g1p : g1;  // workgroups that wrote B1's partials
+#ifndef R2L_EMUL
+  if (g1p && !r2l_env_int("R2L_BWD2_TILED", 0)) {
+    // kernel B2 as two passes over planes (r2l_param_plane_bwd.h)
+    const long nstrip = (W + 255) / 256;
+    auto band_rows = [&](long slots, const char* env) {
+      int bh = 6;
+      long best = -1;
+      for (int c = 6; c <= 48; c += 6) {
+        const long items = (long)B * nstrip * ((H + c - 1) / c);
+        const long cost = ((items + slots - 1) / slots) * (10L * c + 32);
+        if (best < 0 || cost < best) {
+          best = cost;
+          bh = c;
+        }
+      }
+      return (r2l_env_int(env, bh) + 5) / 6 * 6;
+    };
+    a2.hp = ws.hp;
+    a2.band_h = band_rows(256L * 4 * 4, "R2L_HP_BAND");
+    const long hitems = (long)B * nstrip * ((H + a2.band_h - 1) / a2.band_h);
+    a2.tree = R2LTree{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    a2.params = nullptr;
+    a2.grad_params = nullptr;
+    a2.asym = 0;
+    if (int e = r2l_launch_bwd2_hp(a2, (int)((hitems + R2L_BP_NWV - 1) / R2L_BP_NWV), stream)) return e;
+    a2.band_h = band_rows(256L * 4 * 3, "R2L_B2S_BAND");
+    const long sitems = (long)B * nstrip * ((H + a2.band_h - 1) / a2.band_h);
+    long gs = (sitems + R2L_B2S_NWV - 1) / R2L_B2S_NWV;
+    const long cap = r2l_env_int("R2L_GRID_BWD2", 512);
+    if (gs > cap) gs = cap;
+    if (gs < g1w) gs = g1w;  // its last workgroups add B1's partials too: not fewer workgroups than wrote those
+    if (gs > R2L_MAX_BLOCKS) gs = R2L_MAX_BLOCKS;
+    a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, ws.counters, R2L_B1_NACC, g1w};
+    a2.params = params;
+    a2.grad_params = grad_params;
+    return raw.u16 ? r2l_launch_bwd2_sums_u16(a2, (int)gs, stream) : r2l_launch_bwd2_sums(a2, (int)gs, stream);
+  }
+#endif
   const bool in_kernel = g1w <= g2;
   a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, in_kernel ? ws.counters : nullptr, R2L_B1_NACC, g1w};
   a2.params = params;

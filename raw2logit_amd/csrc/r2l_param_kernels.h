@@ -1671,6 +1671,8 @@ struct R2LBwd2Args {
   const float* params;  // packed parameters (for the unfold)
   float* grad_params;   // [R2L_P_NTRAIN]
   int asym;             // r2l_walk_init: uneven tile shares for the two workgroups of a CU (0 = even)
+  float* hp;            // plane passes (r2l_param_plane_bwd.h): (B,H,W) the blur's adjoint of dL/dY''
+  int band_h;           // plane passes: rows per work item (a multiple of 6)
 };
 
 enum { R2L_L2_GSHARP = 0, R2L_L2_GAY = 9, R2L_L2_SY = 27, R2L_L2_NACC = 29 };
@@ -1999,6 +2001,9 @@ R2L_BLOCKFN void r2l_bwd2_block(const R2LBwd2Args& a, int bid, int nblk, float* 
     R2L_STAMP(5)
     R2L_STAMP_FLUSH(a.debug, bid)
     if (!last_) return;
+#if defined(R2L_TEST_HOOKS) && !defined(R2L_EMUL)
+    if (a.debug && threadIdx.x < R2L_NSUMS) ((double*)a.debug)[threadIdx.x] = sums[threadIdx.x];  // (tests: the 155 totals)
+#endif
     r2l_unfold_phases(a.params, sums, tg, pl, a.grad_params);
     R2L_STAMP(6)
     R2L_STAMP_FLUSH(a.debug, bid)

@@ -39,8 +39,16 @@
 struct R2LBpStage {  // grad_out of one row in flight: 3 channels x the lane's 4 pixels
   r2l_f4 g[3];
 };
-R2L_HD void r2l_bp_fetch_g(const float* gimg, unsigned plane, int y, int H, int W, int x0, R2LBpStage& s) {
+template <bool EPI>
+R2L_HD void r2l_bp_fetch_g(const float* gimg, unsigned plane, int y, int H, int W, int x0, const R2LEpi& ep,
+                           R2LBpStage& s) {
   const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+  if (EPI) {  // grad_out arrives in the augmented layout the forward's epilogue wrote: element s0 + sr y + sc x (R2LEpi)
+    const float* p = gimg + (ep.s0 + ep.sr * yc + ep.sc * x0);
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 3; ++k) s.g[k] = r2l_epi_load4(p + (size_t)k * plane, ep.sc);
+    return;
+  }
   const float* p = gimg + (size_t)yc * W + x0;
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) s.g[k] = r2l_load_f4_nt(p + (size_t)k * plane);  // read once: nontemporal (as kernel B1)
@@ -201,9 +209,8 @@ R2L_HD float r2l_bp_slot(const R2LBpAcc& A, const float* E, const float* O, int 
 
 // lanes -> one partial per slot and workgroup, in a fixed order (R2L_BLOCK_REDUCE_F for R2L_BP_NT threads): slots
 // [0, NSLOTS) of val(i) go to partial[(slot0 + i) * nblk + bid]
-template <int NSLOTS, class VAL>
+template <int NSLOTS, int NT = R2L_BP_NT, class VAL>
 R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int slot0, int bid, int nblk, VAL&& val) {
-  constexpr int NT = R2L_BP_NT;
   R2L_PRAGMA_UNROLL
   for (int base = 0; base < NSLOTS; base += 32) {
     R2L_PRAGMA_UNROLL
@@ -211,16 +218,18 @@ R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int sl
       if (base + i < NSLOTS) lds[i * (NT + 1) + tid] = val(base + i);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {
-      const int slot = tid >> 4, part = tid & 15;  // 16 lanes per slot add NT / 16 values each; 32 slots in 32 * 16 / NT passes
+      const int slot = tid >> 4, part = tid & 15;  // 16 lanes per slot add NT / 16 values each; NT / 16 slots per pass
       R2L_PRAGMA_UNROLL
-      for (int h = 0; h < 32 * 16 / NT; ++h) {
+      for (int h = 0; h < (32 * 16 + NT - 1) / NT; ++h) {
         const int sl = slot + h * (NT / 16);
-        float s = 0.f;
-        if (base + sl < NSLOTS) {
-          R2L_PRAGMA_UNROLL
-          for (int j = 0; j < NT / 16; ++j) s += lds[sl * (NT + 1) + part + 16 * j];
+        if (sl < 32) {
+          float s = 0.f;
+          if (base + sl < NSLOTS) {
+            R2L_PRAGMA_UNROLL
+            for (int j = 0; j < NT / 16; ++j) s += lds[sl * (NT + 1) + part + 16 * j];
+          }
+          lds[32 * (NT + 1) + sl * 16 + part] = s;
         }
-        lds[32 * (NT + 1) + sl * 16 + part] = s;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -235,7 +244,7 @@ R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int sl
   }
 }
 
-template <bool U16>
+template <bool U16, bool EPI>
 R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, float* lds) {
   constexpr int NWV = R2L_BP_NWV, NT = R2L_BP_NT;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -294,7 +303,7 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
       r2l_fa_fetch(ypimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
     }
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < PFG; ++i) r2l_bp_fetch_g(gimg, plane, y0 + i, a.H, a.W, x0, pfg[i % PFG]);  // (first used at K = 0)
+    for (int i = 0; i < PFG; ++i) r2l_bp_fetch_g<EPI>(gimg, plane, y0 + i, a.H, a.W, x0, a.ep, pfg[i % PFG]);  // (first used at K = 0)
 #define R2L_BP_LOAD_STEP(K, q)                                                                          \
   r2l_fs_convert<U16>(sa, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3]);                                \
   r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, st.yp[((K) + 2) % 6]);       \
@@ -312,7 +321,7 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
     const int q = qb + K;                                                                               \
     R2L_BP_LOAD_STEP(K, q)                                                                              \
     const R2LBpStage g_ = pfg[(K) % PFG];                                                               \
-    r2l_bp_fetch_g(gimg, plane, q + PFG, a.H, a.W, x0, pfg[(K) % PFG]);                                 \
+    r2l_bp_fetch_g<EPI>(gimg, plane, q + PFG, a.H, a.W, x0, a.ep, pfg[(K) % PFG]);                      \
     if (K) r2l_bp_swap(A, bank); /* the bank of this row's parity into the registers */                 \
     if (r2l_opaque_true()) r2l_bp_step<K>(a, st, A, g_, q, in_w && q < y1, gyb, x0, bc);                \
   }
@@ -349,7 +358,7 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
     O[4 * c + 3] = o4.w;
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
-  r2l_bp_block_reduce<R2L_B1_NACC>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return r2l_bp_slot(A, E, O, i); });
+  r2l_bp_block_reduce<R2L_B1_NACC, R2L_BP_NT>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return r2l_bp_slot(A, E, O, i); });
 }
 
 // ---- second pass: the 25 blur-weight sums  d/d gaussian_blur.weight[i][j] = sum_p gY''(p) * Y'_ext(p + (i-2, j-2)) from
@@ -468,7 +477,419 @@ R2L_BLOCKFN void r2l_bwd1_blur_block(const R2LBwd1Args& a, int bid, int nblk, fl
     }
 #undef R2L_BB_LOAD_STEP
   }
-  r2l_bp_block_reduce<R2L_B1_GAU>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return blur[i][0] + blur[i][1]; });
+  r2l_bp_block_reduce<R2L_B1_GAU, R2L_BP_NT>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return blur[i][0] + blur[i][1]; });
+}
+
+// ================================================================================================
+// Kernel B2 (r2l_bwd2_block) as two passes over planes, the same way:
+//   r2l_bwd2_hp_block    dL/dY''  -> HP = adjoint of the 5x5 blur with mirror padding (a plane in the workspace)
+//   r2l_bwd2_sums_block  HP + raw -> the sharpen's adjoint (zero padding), d/d sharpening_filter.weight, d/d luma stencil
+//                                    sums; its last workgroups finish the reduction of B1's and B2's partials and unfold
+// The adjoint of a mirror-padded correlation: HP(q) = sum_t blur[t] g0(q - t) (g0 = dL/dY'' extended with zeros) for every
+// position, and an in-image position adds the values of its out-of-image mirror images -- rows {1, 2, H-3, H-2} those
+// of rows {-1, -2, H+1, H}, columns likewise, corners both (r2l_fold_mirror of the tile kernel).  Here an out-of-image
+// row's value is a few more products of the window rows at hand (row -1 only sees g rows 0 and 1, ...), added behind a
+// uniform branch on those four rows; an out-of-image column's value involves the lane's own first / last two columns
+// only and is carried along as one extra pair per side, used by the lanes at the image's edges.
+struct R2LHpAcc {
+  r2l_p2 h[2];  // HP of the lane's 4 columns
+  r2l_p2 el;    // (HP(-2), HP(-1)): out-of-image columns left of the image (lanes with x0 == 0)
+  r2l_p2 er;    // (HP(W), HP(W+1))
+};
+// one window row (8 wide: columns x0-2 .. x0+5, zero outside the image) against blur row i, taps in adjoint order
+template <class WT>
+R2L_HD void r2l_hp_row(R2LHpAcc& A, const float g[8], WT blur, int i) {
+  float bf[5];  // bf[s] = blur[i][4 - s]: HP(x) += bf[s] * g(x + s - 2)
+  R2L_PRAGMA_UNROLL
+  for (int s_ = 0; s_ < 5; ++s_) bf[s_] = blur[i * 5 + 4 - s_];
+  r2l_p2 P[4], O[3];
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 4; ++k) P[k] = r2l_mk2(g[2 * k], g[2 * k + 1]);
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) O[k] = r2l_straddle(P[k], P[k + 1]);
+  R2L_PRAGMA_UNROLL
+  for (int s_ = 0; s_ < 5; ++s_) {
+    const r2l_p2 w = r2l_splat2(bf[s_]);
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) A.h[p] = r2l_pfma(w, (s_ & 1) ? O[p + s_ / 2] : P[p + s_ / 2], A.h[p]);
+  }
+  // columns -2, -1 see the image's columns 0, 1 only; columns W, W+1 its last two (the lane's c0 .. c3 = g[2 .. 5])
+  A.el = r2l_pfma(r2l_mk2(bf[4], bf[3]), r2l_splat2(g[2]), A.el);
+  A.el = r2l_pfma(r2l_mk2(0.f, bf[4]), r2l_splat2(g[3]), A.el);
+  A.er = r2l_pfma(r2l_splat2(bf[0]), r2l_mk2(g[4], g[5]), A.er);
+  A.er = r2l_pfma(r2l_mk2(bf[1], 0.f), r2l_splat2(g[5]), A.er);
+}
+// staged row -> 8 values, columns x0-2 .. x0+5, ZERO outside the image (r2l_fa_build mirrors)
+R2L_HD void r2l_hp_build(const R2LFaStage& s, bool rin, bool le, bool re, float o[8]) {
+  const float c0 = rin ? s.c.x : 0.f, c1 = rin ? s.c.y : 0.f, c2 = rin ? s.c.z : 0.f, c3 = rin ? s.c.w : 0.f;
+  const float e0 = rin ? s.e.x : 0.f, e1 = rin ? s.e.y : 0.f;
+  const float l2 = r2l_wshr(c2, e0), l1 = r2l_wshr(c3, e1);
+  const float r1 = r2l_wshl(c0, e0), r2 = r2l_wshl(c1, e1);
+  o[0] = le ? 0.f : l2;
+  o[1] = le ? 0.f : l1;
+  o[2] = c0;
+  o[3] = c1;
+  o[4] = c2;
+  o[5] = c3;
+  o[6] = re ? 0.f : r1;
+  o[7] = re ? 0.f : r2;
+}
+template <int K>
+R2L_HD void r2l_hp_step(const R2LBwd2Args& a, const float gw[6][8], int q, bool le, bool re, bool store_ok, float* hpb,
+                        int x0) {
+  const int H = a.H;
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, gw[(K + 2) % 6][2]));
+  R2LHpAcc A;
+  A.h[0] = A.h[1] = A.el = A.er = r2l_splat2(0.f);
+  // window rows q-2 .. q+2 sit in ring slots K+4 .. K+8; window row r holds g(q - 2 + r) and meets blur row 4 - r
+  R2L_PRAGMA_UNROLL
+  for (int r = 0; r < 5; ++r) r2l_hp_row(A, gw[(K + 4 + r) % 6], F.blur, 4 - r);
+  if (q < 3 || q >= H - 3) {  // uniform: the rows whose mirror images lie outside the image
+    // row -1 (mirror image of row 1) sees g rows 1 and 0 = window rows 2 and 1 of q = 1 through blur rows 0 and 1; ...
+    if (q == 1) {
+      r2l_hp_row(A, gw[(K + 4 + 2) % 6], F.blur, 0);
+      r2l_hp_row(A, gw[(K + 4 + 1) % 6], F.blur, 1);
+    }
+    if (q == 2) r2l_hp_row(A, gw[(K + 4 + 0) % 6], F.blur, 0);  // row -2: g row 0 = window row 0 through blur row 0
+    if (q == H - 2) {  // row H: g rows H-1, H-2 = window rows 3, 2 through blur rows 3, 4
+      r2l_hp_row(A, gw[(K + 4 + 3) % 6], F.blur, 3);
+      r2l_hp_row(A, gw[(K + 4 + 2) % 6], F.blur, 4);
+    }
+    if (q == H - 3) r2l_hp_row(A, gw[(K + 4 + 4) % 6], F.blur, 4);  // row H+1: g row H-1 = window row 4, blur row 4
+  }
+  float h0 = A.h[0][0], h1 = A.h[0][1], h2 = A.h[1][0], h3 = A.h[1][1];
+  // columns 1, 2 add columns -1, -2; columns W-2, W-3 add columns W, W+1 (a lane at the right edge holds W-4 .. W-1)
+  h1 += le ? A.el[1] : 0.f;
+  h2 += le ? A.el[0] : 0.f;
+  h2 += re ? A.er[0] : 0.f;
+  h1 += re ? A.er[1] : 0.f;
+  if (store_ok) {
+    r2l_f4 s4;
+    s4.x = h0;
+    s4.y = h1;
+    s4.z = h2;
+    s4.w = h3;
+    *(r2l_f4*)(hpb + (unsigned)q * (unsigned)a.W + (unsigned)x0) = s4;
+  }
+}
+#ifndef R2L_HP_PF
+#define R2L_HP_PF 2
+#endif
+R2L_BLOCKFN void r2l_bwd2_hp_block(const R2LBwd2Args& a, int bid, int nblk, float* lds) {
+  (void)lds;
+  (void)nblk;
+  constexpr int NWV = R2L_BP_NWV;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int nstrip = (a.W + 255) >> 8;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const int band_h = a.band_h, nband = (a.H + band_h - 1) / band_h, nitems = a.B * nband * nstrip;
+  const int item = bid * NWV + wave;  // one item per wavefront
+  if (item >= nitems) return;
+  const int strip = item % nstrip, ib = item / nstrip;
+  const int band = ib % nband, b = ib / nband;
+  const int xs = strip * 256 + 4 * lane;
+  const bool in_w = xs < a.W;
+  const int x0 = in_w ? xs : a.W - 4;
+  const bool le = x0 == 0, re = x0 + 4 >= a.W;
+  const int y0 = band * band_h;  // a multiple of 6
+  const int y1 = (y0 + band_h < a.H) ? y0 + band_h : a.H;
+  const float* gimg = a.gypp + (size_t)b * plane;
+  float* hpb = a.hp + (size_t)b * plane;
+  float gw[6][8];
+  constexpr int PF = R2L_HP_PF;
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  R2LFaStage pf[PF];  // g row q + 2
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i) r2l_fa_fetch(gimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pf[(2 + i) % PF]);
+#define R2L_HP_LOAD_STEP(K, q)                                                                          \
+  r2l_hp_build(pf[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, gw[((K) + 2) % 6]);           \
+  r2l_fa_fetch(gimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pf[(K) % PF]);
+  R2L_HP_LOAD_STEP(2, y0 - 4)
+  R2L_HP_LOAD_STEP(3, y0 - 3)
+  R2L_HP_LOAD_STEP(4, y0 - 2)
+  R2L_HP_LOAD_STEP(5, y0 - 1)
+  for (int qb = y0; qb < y1; qb += 6) {
+#define R2L_HP_STEP(K)                                                                                  \
+  {                                                                                                     \
+    const int q = qb + K;                                                                               \
+    R2L_HP_LOAD_STEP(K, q)                                                                              \
+    r2l_hp_step<K>(a, gw, q, le, re, in_w && q < y1, hpb, x0);                                          \
+  }
+    R2L_HP_STEP(0)
+    R2L_HP_STEP(1)
+    R2L_HP_STEP(2)
+    R2L_HP_STEP(3)
+    R2L_HP_STEP(4)
+    R2L_HP_STEP(5)
+#undef R2L_HP_STEP
+  }
+#undef R2L_HP_LOAD_STEP
+}
+
+// ---- second pass of B2: HP + raw -> gY = sharpen^T(HP) (zero padding), the sums  d/d sharpening_filter.weight[t] =
+// sum gY'(p) Y0(p + t)  (gY' = HP, Y0 = luma extended with zeros) and  GAY[parity][t] = sum gY(p) v(p + t), SY ---------
+#define R2L_B2S_NWV 6                      // 2 workgroups per CU = 3 wavefronts per SIMD
+#define R2L_B2S_NT (64 * R2L_B2S_NWV)
+#define R2L_B2S_BANK 20                    // floats of one row-parity bank: GAY[9] pairs, SY pair
+#define R2L_B2S_LDS_FLOATS (32 * (R2L_B2S_NT + 1) + 32 * 16)  // reduction scratch (>= the bank areas and the tree's scratch)
+struct R2LSumStage {  // one HP row in flight: the lane's 4 values + the neighbour beyond the strip edge
+  r2l_f4 c;
+  float e;
+};
+R2L_HD void r2l_b2s_fetch_hp(const float* hpimg, int r, int H, int W, int x0, bool le, bool re, int lane, R2LSumStage& s) {
+  const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);
+  const float* p = hpimg + (size_t)rc * W + x0;
+  const int eo = (lane < 32) ? (le ? 0 : -1) : (re ? 3 : 4);
+  s.c = r2l_stream_load_f4(p);
+  s.e = p[eo];
+}
+// staged row -> 6 values, columns x0-1 .. x0+4, zero outside the image (the sharpen's zero padding has no adjoint there)
+R2L_HD void r2l_b2s_build_hp(const R2LSumStage& s, bool rin, bool le, bool re, float o[6]) {
+  const float c0 = rin ? s.c.x : 0.f, c1 = rin ? s.c.y : 0.f, c2 = rin ? s.c.z : 0.f, c3 = rin ? s.c.w : 0.f;
+  const float e = rin ? s.e : 0.f;
+  const float l = r2l_wshr(c3, e), r = r2l_wshl(c0, e);
+  o[0] = le ? 0.f : l;
+  o[1] = c0;
+  o[2] = c1;
+  o[3] = c2;
+  o[4] = c3;
+  o[5] = re ? 0.f : r;
+}
+struct R2LSumState {
+  float v[3][6];     // V rows (slot = row mod 3), columns x0-1 .. x0+4
+  r2l_p2 xp[3][3];   // the inputs of the luma stencil's extra pair (r2l_fl_convert)
+  float y[3][6];     // Y rows, zero outside the image
+  float hp[3][6];    // HP rows, zero outside the image
+};
+struct R2LSumAcc {
+  r2l_p2 gsh[9];  // sum gY'(p) * Y0(p + t); halves = column parity, added at the end
+  r2l_p2 gay[9];  // bank of the CURRENT row parity: sum gY(p) * v(p + t), halves = column parity
+  r2l_p2 sy;
+};
+R2L_HD void r2l_b2s_swap(R2LSumAcc& A, float* bank /* [chunk][lane][4], 5 chunks */) {
+#define R2L_B2S_SW(c, a, b)                     \
+  {                                             \
+    const r2l_f4 old = r2l_lds_f4(bank + (c) * 64 * 4); \
+    r2l_f4 nw;                                  \
+    nw.x = (a)[0];                              \
+    nw.y = (a)[1];                              \
+    nw.z = (b)[0];                              \
+    nw.w = (b)[1];                              \
+    *(r2l_f4*)(bank + (c) * 64 * 4) = nw;       \
+    (a) = r2l_mk2(old.x, old.y);                \
+    (b) = r2l_mk2(old.z, old.w);                \
+  }
+  R2L_B2S_SW(0, A.gay[0], A.gay[1])
+  R2L_B2S_SW(1, A.gay[2], A.gay[3])
+  R2L_B2S_SW(2, A.gay[4], A.gay[5])
+  R2L_B2S_SW(3, A.gay[6], A.gay[7])
+  R2L_B2S_SW(4, A.gay[8], A.sy)
+#undef R2L_B2S_SW
+}
+// Y(t) from V(t-1 .. t+1) (the luma stencil of the forward, r2l_fl_step), zero outside the image; K = t mod 6
+template <int K>
+R2L_HD void r2l_b2s_luma(const R2LBwd2Args& a, R2LSumState& st, int t, bool le, bool re) {
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, st.v[(K + 1) % 3][2]));
+  constexpr int PY = K & 1;
+  float* yq = st.y[K % 3];
+  r2l_p2 o[2];
+  r2l_fs_stencil_parity(st.v[(K + 2) % 3], st.v[K % 3], st.v[(K + 1) % 3], F.AY2[PY], o);  // V(t-1), V(t), V(t+1)
+  r2l_p2 e = r2l_splat2(0.f);  // (Y(x0+4), Y(x0-1)): the columns beyond the lane's four
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j)
+    e = r2l_pfma(r2l_mk2(F.AY2[PY][i * 3 + j][0], F.AY2[PY][i * 3 + j][1]), st.xp[(K + 2 + i) % 3][j], e);
+  const bool qin = (unsigned)t < (unsigned)a.H;
+  yq[0] = (qin && !le) ? e[1] : 0.f;
+  yq[1] = qin ? o[0][0] : 0.f;
+  yq[2] = qin ? o[0][1] : 0.f;
+  yq[3] = qin ? o[1][0] : 0.f;
+  yq[4] = qin ? o[1][1] : 0.f;
+  yq[5] = (qin && !re) ? e[0] : 0.f;
+}
+// the sums of step t: GAY / SY of row t (bank of parity K & 1 in the registers), sharpen-weight sums of row t - 1
+template <int K, bool ROW_T = true>
+R2L_HD void r2l_b2s_sums(const R2LBwd2Args& a, R2LSumState& st, R2LSumAcc& A, bool ok_t, bool ok_tm1) {
+  if (ROW_T) {
+    R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, st.hp[(K + 1) % 3][2]));
+    // gY(c) = sum_{i,j} sharp[i][j] * HP(t - (i-1), c - (j-1)): window rows HP(t-1), HP(t), HP(t+1) = slots K+2, K, K+1
+    r2l_p2 gy[2];
+    gy[0] = gy[1] = r2l_splat2(0.f);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      const r2l_p2 w = r2l_splat2(F.sharp[i * 3 + j]);
+      const float* hr = st.hp[(K + 2 + (2 - i)) % 3];  // window row 2 - i
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) gy[p] = r2l_pfma(w, r2l_mk2(hr[2 * p + 2 - j], hr[2 * p + 3 - j]), gy[p]);
+    }
+    if (!ok_t) gy[0] = gy[1] = r2l_splat2(0.f);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      const float* vr = st.v[(K + 2 + i) % 3];  // V(t - 1 + i)
+      r2l_p2 sacc = A.gay[i * 3 + j];
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) sacc = r2l_pfma(gy[p], r2l_mk2(vr[2 * p + j], vr[2 * p + j + 1]), sacc);
+      A.gay[i * 3 + j] = sacc;
+    }
+    A.sy = r2l_padd(A.sy, r2l_padd(gy[0], gy[1]));
+  }
+  {
+    // d/d sharpening_filter.weight[i][j] += gY'(p) * Y0(p + (i-1, j-1)), row t - 1: gY' = HP(t-1) = slot K+2;
+    // Y rows t-2, t-1, t = slots K+1, K+2, K
+    const float* hc = st.hp[(K + 2) % 3];
+    r2l_p2 gp[2];
+    gp[0] = r2l_mk2(ok_tm1 ? hc[1] : 0.f, ok_tm1 ? hc[2] : 0.f);
+    gp[1] = r2l_mk2(ok_tm1 ? hc[3] : 0.f, ok_tm1 ? hc[4] : 0.f);
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 3; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      const float* yr = st.y[(K + 1 + i) % 3];
+      r2l_p2 sacc = A.gsh[i * 3 + j];
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) sacc = r2l_pfma(gp[p], r2l_mk2(yr[2 * p + j], yr[2 * p + j + 1]), sacc);
+      A.gsh[i * 3 + j] = sacc;
+    }
+  }
+}
+// value of B2's global slot i (layout R2L_B2_*) held by a lane: E = even-row bank, O = odd-row bank (gay[9] pairs, sy)
+R2L_HD float r2l_b2s_slot(const R2LSumAcc& A, const float* E, const float* O, int i) {
+  if (i < R2L_B2_GAY) return A.gsh[i][0] + A.gsh[i][1];
+  if (i < R2L_B2_SY) {
+    const int k = i - R2L_B2_GAY, par = k / 9, t = k % 9;
+    return ((par >> 1) ? O : E)[t * 2 + (par & 1)];
+  }
+  const int par = i - R2L_B2_SY;
+  return ((par >> 1) ? O : E)[18 + (par & 1)];
+}
+#ifndef R2L_B2S_PF
+#define R2L_B2S_PF 2
+#endif
+template <bool U16>
+R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk, float* lds) {
+  constexpr int NWV = R2L_B2S_NWV, NT = R2L_B2S_NT;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
+  float* bank = lds + (size_t)wave * 64 * R2L_B2S_BANK + lane * 4;  // [chunk][lane][4]
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 5; ++c) {
+    r2l_f4 z;
+    z.x = z.y = z.z = z.w = 0.f;
+    *(r2l_f4*)(bank + c * 64 * 4) = z;
+  }
+  R2LSumAcc A;
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 9; ++i) A.gsh[i] = A.gay[i] = r2l_splat2(0.f);
+  A.sy = r2l_splat2(0.f);
+  R2LFwdStreamArgs sa;  // for the streaming kernels' raw-row fetch / convert
+  sa.raw = a.raw;
+  sa.W = a.W;
+  sa.H = a.H;
+  const int nstrip = (a.W + 255) >> 8;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const int band_h = a.band_h, nband = (a.H + band_h - 1) / band_h, nitems = a.B * nband * nstrip;
+  constexpr int PF = R2L_B2S_PF;
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  // the registers hold the bank of EVEN rows between items (bands start on even rows, at K = 0)
+  R2L_PRAGMA_NOUNROLL
+  for (int item = bid * NWV + wave; item < nitems; item += nblk * NWV) {
+    const int strip = item % nstrip, ib = item / nstrip;
+    const int band = ib % nband, b = ib / nband;
+    const int xs = strip * 256 + 4 * lane;
+    const bool in_w = xs < a.W;
+    const int x0 = in_w ? xs : a.W - 4;
+    const bool le = x0 == 0, re = x0 + 4 >= a.W;
+    const int y0 = band * band_h;  // a multiple of 6
+    const int y1 = (y0 + band_h < a.H) ? y0 + band_h : a.H;
+    const size_t img = (size_t)b * plane;
+    const float* hpimg = a.hp + img;
+    R2LSumState st;
+    R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 6; ++j) st.y[1][j] = 0.f;  // Y(y0 - 2): only ever meets a zero cotangent, but must be finite
+    R2LFlStage pf[PF];    // raw row t + 1
+    R2LSumStage pfh[PF];  // HP row t + 1
+    // step t: V(t+1) and HP(t+1) arrive; Y(t); GAY / SY of row t; sharpen-weight sums of row t - 1.  Warm-up: t = y0-3
+    // (V(y0-2)), y0-2 (V(y0-1), HP(y0-1)), y0-1 (V(y0), HP(y0), Y(y0-1)) = K 3 .. 5; one more step behind the band's last
+    // row finishes the sharpen-weight sums of that row.
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < PF; ++i) {
+      r2l_fl_fetch<U16>(sa, img, r2l_mirror(y0 - 2 + i, a.H), x0, le, re, lane, pf[(3 + i) % PF]);
+      r2l_b2s_fetch_hp(hpimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfh[(3 + i) % PF]);
+    }
+#define R2L_B2S_LOAD_STEP(K, t)                                                                               \
+  r2l_fl_convert<U16>(sa, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3], st.xp[((K) + 1) % 3]);                \
+  r2l_b2s_build_hp(pfh[(K) % PF], (unsigned)((t) + 1) < (unsigned)a.H, le, re, st.hp[((K) + 1) % 3]);         \
+  r2l_fl_fetch<U16>(sa, img, r2l_mirror((t) + 1 + PF, a.H), x0, le, re, lane, pf[(K) % PF]);                  \
+  r2l_b2s_fetch_hp(hpimg, (t) + 1 + PF, a.H, a.W, x0, le, re, lane, pfh[(K) % PF]);
+    R2L_B2S_LOAD_STEP(3, y0 - 3)
+    R2L_B2S_LOAD_STEP(4, y0 - 2)
+    R2L_B2S_LOAD_STEP(5, y0 - 1)
+    if (r2l_opaque_true()) r2l_b2s_luma<5>(a, st, y0 - 1, le, re);
+    for (int qb = y0; qb < y1; qb += 6) {  // (a last group that runs past y1 also takes the step t = y1, see below)
+#define R2L_B2S_STEP(K)                                                                                       \
+  {                                                                                                           \
+    const int t = qb + K;                                                                                     \
+    R2L_B2S_LOAD_STEP(K, t)                                                                                   \
+    if (K) r2l_b2s_swap(A, bank); /* the bank of this row's parity into the registers */                      \
+    if (r2l_opaque_true()) {                                                                                  \
+      r2l_b2s_luma<K>(a, st, t, le, re);                                                                      \
+      r2l_b2s_sums<K>(a, st, A, in_w && t < y1, in_w && t - 1 >= y0 && t - 1 < y1);                           \
+    }                                                                                                         \
+  }
+      R2L_B2S_STEP(0)
+      R2L_B2S_STEP(1)
+      R2L_B2S_STEP(2)
+      R2L_B2S_STEP(3)
+      R2L_B2S_STEP(4)
+      R2L_B2S_STEP(5)
+      r2l_b2s_swap(A, bank);  // (K = 5 was an odd row)
+#undef R2L_B2S_STEP
+    }
+    // the sharpen-weight sums of the band's last row want Y(y1): one more step, t = y1, unless the last group ran past it
+    if ((y1 - y0) % 6 == 0) {
+      r2l_fl_convert<U16>(sa, F, pf[0], le, re, st.v[1], st.xp[1]);  // V(y1 + 1): K = 0
+      if (r2l_opaque_true()) {
+        r2l_b2s_luma<0>(a, st, y1, le, re);
+        r2l_b2s_sums<0, false>(a, st, A, false, in_w);
+      }
+    }
+#undef R2L_B2S_LOAD_STEP
+  }
+  // ---- lanes -> one partial per slot and workgroup; then the tree over B1's and B2's partials and the unfold --------------
+  float E[R2L_B2S_BANK], O[R2L_B2S_BANK];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 9; ++i) {
+    E[2 * i] = A.gay[i][0];
+    E[2 * i + 1] = A.gay[i][1];
+  }
+  E[18] = A.sy[0];
+  E[19] = A.sy[1];
+  R2L_PRAGMA_UNROLL
+  for (int c = 0; c < 5; ++c) {
+    const r2l_f4 o4 = r2l_lds_f4(bank + c * 64 * 4);
+    O[4 * c] = o4.x;
+    O[4 * c + 1] = o4.y;
+    O[4 * c + 2] = o4.z;
+    O[4 * c + 3] = o4.w;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
+  r2l_bp_block_reduce<R2L_B2_NACC, NT>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return r2l_b2s_slot(A, E, O, i); });
+  if (a.tree.counters) {
+    double* sums = (double*)(lds + 4);
+    double* tg = sums + R2L_NSUMS;
+    float* pl = (float*)(tg + R2L_UNFOLD_TG);
+    if (!r2l_tree_finish<R2L_NSUMS, NT>(a.tree, bid, nblk, lds, sums, (double*)(lds + 1024), (R2L_B2S_LDS_FLOATS - 1024) / 2))
+      return;
+#ifdef R2L_TEST_HOOKS
+    if (a.debug && tid < R2L_NSUMS) ((double*)a.debug)[tid] = sums[tid];  // (tests: the 155 totals, slot by slot)
+#endif
+    r2l_unfold_phases<NT>(a.params, sums, tg, pl, a.grad_params);
+  }
 }
 
 #endif  // !R2L_EMUL

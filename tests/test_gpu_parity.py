@@ -472,12 +472,14 @@ def test_backward_reads_the_luma_plane_the_forward_kept(shape, dev):
 
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256), (5, 18, 8),
                                    (2, 514, 512), (3, 4, 4), (2, 6, 1024), (4, 256, 256), (2, 8, 256), (9, 64, 64)], ids=str)
-def test_backward_kernel_b1_as_passes_over_planes(shape, dev):
-    """Kernel B1 as two passes of independent wavefronts over the raw / Y' / grad_out planes (r2l_param_plane_bwd.h:
-    pointwise adjoints + dL/dY'' + chroma / gamma sums, then the 25 blur-weight sums from dL/dY'' and Y') against the LDS
-    tile kernel of the diagnostic build (R2L_BWD1_TILED): all 132 gradients, float32 and 16-bit frames, with and without
-    train-mode BatchNorm, every band height and grid (one wavefront takes everything ... one item each), frames of 4 rows
-    (every row a border row of the blur) -- and, through the golden / frame-shape / fuzz suites, against the oracle."""
+def test_backward_kernels_as_passes_over_planes(shape, dev):
+    """Kernels B1 and B2 as passes of independent wavefronts over planes (r2l_param_plane_bwd.h: pointwise adjoints +
+    dL/dY'' + chroma / gamma sums; the 25 blur-weight sums from dL/dY'' and Y'; the blur's mirror-padding adjoint into a
+    plane; the sharpen's adjoint + sharpen / luma-stencil sums + final reduction and unfold) against the LDS tile kernels
+    of the diagnostic build (R2L_BWD1_TILED, which takes both back; R2L_BWD2_TILED): all 132 gradients, float32 and
+    16-bit frames, with and without train-mode BatchNorm, every band height and grid (one wavefront takes everything ...
+    one item each), frames of 4 rows (every row a border row of the blur and of its adjoint) -- and, through the golden /
+    frame-shape / fuzz suites, against the oracle."""
     import os
     B, H, W = shape
     P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
@@ -505,8 +507,10 @@ def test_backward_kernel_b1_as_passes_over_planes(shape, dev):
 
         ref = run({'R2L_BWD1_TILED': '1'}, 'f32')
         worst = 0.0
-        for env, frames in (({}, 'f32'), ({}, 'u16'), ({'R2L_BP_BAND': '6'}, 'f32'), ({'R2L_BP_BAND': '12', 'R2L_GRID_BWD1': '1'}, 'f32'),
-                            ({'R2L_BP_BAND': '1000', 'R2L_GRID_BWD1': '3'}, 'u16'), ({'R2L_GRID_BWD1': '7'}, 'f32')):
+        for env, frames in (({}, 'f32'), ({}, 'u16'), ({'R2L_BP_BAND': '6', 'R2L_HP_BAND': '12', 'R2L_B2S_BAND': '6'}, 'f32'),
+                            ({'R2L_BP_BAND': '12', 'R2L_GRID_BWD1': '1', 'R2L_GRID_BWD2': '1', 'R2L_B2S_BAND': '18'}, 'f32'),
+                            ({'R2L_BP_BAND': '1000', 'R2L_GRID_BWD1': '3', 'R2L_HP_BAND': '1000', 'R2L_B2S_BAND': '1000'}, 'u16'),
+                            ({'R2L_GRID_BWD1': '7', 'R2L_GRID_BWD2': '5'}, 'f32'), ({'R2L_BWD2_TILED': '1'}, 'f32')):
             g = run(env, frames)
             for n, r in ref.items():
                 e = np.abs(g[n] - r).max()
