@@ -899,7 +899,7 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
     a2.band_h = band_rows(256L * 4 * 3, "R2L_B2S_BAND");
     const long sitems = (long)B * nstrip * ((H + a2.band_h - 1) / a2.band_h);
     long gs = (sitems + R2L_B2S_NWV - 1) / R2L_B2S_NWV;
-    const long cap = r2l_env_int("R2L_GRID_BWD2", 512);
+    const long cap = r2l_env_int("R2L_GRID_BWD2", 768);  // 3 workgroups of 4 wavefronts per CU
     if (gs > cap) gs = cap;
     if (gs < g1w) gs = g1w;  // its last workgroups add B1's partials too: not fewer workgroups than wrote those
     if (gs > R2L_MAX_BLOCKS) gs = R2L_MAX_BLOCKS;

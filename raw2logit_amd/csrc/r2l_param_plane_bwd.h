@@ -628,7 +628,8 @@ R2L_BLOCKFN void r2l_bwd2_hp_block(const R2LBwd2Args& a, int bid, int nblk, floa
 
 // ---- second pass of B2: HP + raw -> gY = sharpen^T(HP) (zero padding), the sums  d/d sharpening_filter.weight[t] =
 // sum gY'(p) Y0(p + t)  (gY' = HP, Y0 = luma extended with zeros) and  GAY[parity][t] = sum gY(p) v(p + t), SY ---------
-#define R2L_B2S_NWV 6                      // 2 workgroups per CU = 3 wavefronts per SIMD
+#define R2L_B2S_NWV 4                      // one wavefront per SIMD and workgroup, 3 workgroups per CU (6-wavefront workgroups
+                                           // spread 2-2-1-1 over the SIMDs: a second one only fits if it lands 1-1-2-2)
 #define R2L_B2S_NT (64 * R2L_B2S_NWV)
 #define R2L_B2S_BANK 20                    // floats of one row-parity bank: GAY[9] pairs, SY pair
 #define R2L_B2S_LDS_FLOATS (32 * (R2L_B2S_NT + 1) + 32 * 16)  // reduction scratch (>= the bank areas and the tree's scratch)
@@ -774,6 +775,9 @@ template <bool U16>
 R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk, float* lds) {
   constexpr int NWV = R2L_B2S_NWV, NT = R2L_B2S_NT;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#ifdef R2L_EXP_STAMPS
+  const unsigned long long tl0_ = __builtin_amdgcn_s_memrealtime();
+#endif
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   float* bank = lds + (size_t)wave * 64 * R2L_B2S_BANK + lane * 4;  // [chunk][lane][4]
   R2L_PRAGMA_UNROLL
@@ -877,6 +881,12 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk, fl
     O[4 * c + 2] = o4.z;
     O[4 * c + 3] = o4.w;
   }
+#ifdef R2L_EXP_STAMPS
+  if (a.debug && bid < 2048 && tid == 0) {  // (start, end of the item loop) of every workgroup: tests/timeline_fwd.py
+    ((unsigned long long*)a.debug)[2 * bid] = tl0_;
+    ((unsigned long long*)a.debug)[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
   r2l_bp_block_reduce<R2L_B2_NACC, NT>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return r2l_b2s_slot(A, E, O, i); });
   if (a.tree.counters) {

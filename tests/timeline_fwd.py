@@ -85,3 +85,22 @@ if os.environ.get('R2L_FORCE_SPLIT'):
         st = (d[:, 0] - d[:, 0].min()).double() / 100
         print(f'luma pass {mode}, no prologue kernel: {len(d)} workgroups, last start {st.max():.1f} us; start quantiles',
               [round(x, 1) for x in st.quantile(q).tolist()])
+
+# ---- the sums pass of kernel B2 (r2l_bwd2_sums_block): start / end of every workgroup's item loop
+if os.environ.get('R2L_TL_BWD'):
+    cot = torch.randn_like(y)
+    for _ in range(3):
+        y = m(raw)
+        (y * cot).sum().backward()
+    torch.cuda.synchronize()
+    d = y.grad_fn.ws if y.grad_fn is not None else None
+    ws = m(raw).grad_fn.ws if d is None else d
+    tlb = ws[off + 4 * 16 * 2048:off + 4 * 16 * 2048 + 8 * 4096].view(torch.int64).cpu().view(-1, 2)
+    tlb = tlb[(tlb[:, 1] > tlb[:, 0]) & (tlb[:, 1] - tlb[:, 0] < 100000000)]   # (the area also holds older float records)
+    tlb = tlb[(tlb[:, 0] - tlb[:, 0].median()).abs() < 100000000]
+    tlb = tlb[tlb[:, 0] > tlb[:, 0].max() - 10000]          # the last launch (records of earlier, larger grids may linger)
+    st, en = (tlb[:, 0] - tlb[:, 0].min()).double() / 100, (tlb[:, 1] - tlb[:, 0].min()).double() / 100
+    dur = en - st
+    print(f'bwd2 sums: {len(tlb)} workgroups; last start {st.max():.1f} us; first end {en.min():.1f}, last end {en.max():.1f}; '
+          f'duration min {dur.min():.1f} median {dur.median():.1f} max {dur.max():.1f} us')
+    print('   end quantiles', [round(x, 1) for x in en.quantile(q).tolist()])
