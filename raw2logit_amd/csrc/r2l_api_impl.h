@@ -812,7 +812,10 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
   int g1p = 0;  // workgroups of the plane passes, when they run
 #ifndef R2L_EMUL
-  if (saved && !r2l_env_int("R2L_BWD1_TILED", 0)) {
+  // ... where there is enough work for their eight launch tails: 128x256x256 (8.4 Mpx) 124 us against the tile kernels' 132,
+  // 64x256x256 (4.2 Mpx) 99 against 85 (profiles/r03_z_bench.json, small_shapes)
+  const bool planes = r2l_env_int("R2L_BWD_PLANES", 0) || (size_t)B * H * W >= ((size_t)6 << 20);
+  if (saved && planes && !r2l_env_int("R2L_BWD1_TILED", 0)) {
     // persistent workgroups of 4 independent wavefronts, two per CU (<= 256 VGPRs), not more workgroups than kernel B2
     // runs (its last workgroups reduce both kernels' partials); band height as for the forward's plane passes
     const long nstrip = (W + 255) / 256, slots = 256L * 4 * 2;

@@ -489,17 +489,23 @@ def test_backward_kernels_as_passes_over_planes(shape, dev):
     for bn in (True, False):
         case = dict(camera='drone', track=False, additive=False, training=True, bn=bn)
 
-        def run(env, frames):
+        def run(env, frames, epilogue=None):
             m = pc.make_module(case, P, dev)
             if frames == 'u16':
                 m.raw_bits = 12
                 raw = torch.from_numpy(u).to(dev)
             else:
                 raw = torch.from_numpy(u.astype(np.float32) / np.float32(4095)).to(dev)
+            env = dict(env, R2L_BWD_PLANES='1')      # (the default only for batches of >= 6 Mpx)
             os.environ.update(env)
             try:
                 with pc.launch_shape_overrides(dev):
-                    (m(raw) * cot).sum().backward()
+                    if epilogue is not None:
+                        from raw2logit_amd import augmentation as aug
+                        m.__dict__['_epilogue'] = epilogue
+                        (m(raw) * aug.flip_rot(cot, *epilogue)).sum().backward()
+                    else:
+                        (m(raw) * cot).sum().backward()
             finally:
                 for k in env:
                     del os.environ[k]
@@ -518,6 +524,12 @@ def test_backward_kernels_as_passes_over_planes(shape, dev):
                 worst = max(worst, e / lim)
                 assert e <= lim, (shape, bn, env, frames, n, e, lim)
         pc.report(f'bwd1-planes/{shape}/bn={bn}/all gradients vs tile kernel (fraction of 2e-4 relative)', worst, 1.0)
+        if not bn:   # the output epilogue through the plane pass's fetch: the same sums from the same numbers, bit for bit
+            plain = run({}, 'f32')
+            for epilogue in ((True, False, 0), (False, True, 2)) + (((True, True, 1),) if H == W else ()):
+                ge = run({}, 'f32', epilogue)
+                for n in plain:
+                    assert np.array_equal(ge[n], plain[n]), (shape, epilogue, n)
 
 
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
