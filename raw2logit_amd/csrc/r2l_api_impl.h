@@ -175,8 +175,10 @@ R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GF
 #ifndef R2L_FS_MINBAND
 #define R2L_FS_MINBAND 16  // rows: shortest band of the row-streaming forward (7 halo rows of luma per band)
 #endif
+// (8 wavefronts side by side -- frames 1024 < W <= 2048 -- need 99 KB of LDS: one workgroup per CU, 2 wavefronts per SIMD)
+#define R2L_FS_OCC_NW(NW) ((NW) == 8 ? 2 : R2L_FS_OCC)
 #define R2L_FS_KERNEL(name, NW, U16)                                                                    \
-  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC, r2l_fwd_stream_block<NW, U16>)
+  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC_NW(NW), r2l_fwd_stream_block<NW, U16>)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w1, 1, false)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w2, 2, false)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w4, 4, false)
@@ -187,7 +189,7 @@ R2L_FS_KERNEL(r2l_launch_fwd_stream_w4_u16, 4, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w8_u16, 8, true)
 // ... with the output epilogue (flip / flip / rot90 of the output planes as part of the stores, R2LEpi)
 #define R2L_FS_KERNEL_EPI(name, NW, U16)                                                                \
-  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC, r2l_fwd_stream_block<NW, U16, true>)
+  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC_NW(NW), r2l_fwd_stream_block<NW, U16, true>)
 R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w1, 1, false)
 R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w2, 2, false)
 R2L_FS_KERNEL_EPI(r2l_launch_fwd_stream_epi_w4, 4, false)
