@@ -61,6 +61,14 @@ def golden():
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """achieved error of every parity check next to its limit (tests/parity_checks.py: report())"""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            terminalreporter.write_line(
+                'note: this run has no GPU -- the host emulation covers the tile forms of the kernels; the row-streaming '
+                'forward, the passes over planes and the static stream / chain kernels only run under `-m gpu`')
+    except Exception:
+        pass
     pc = sys.modules.get('parity_checks')
     if pc is None:
         return
