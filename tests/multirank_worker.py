@@ -27,6 +27,7 @@ CASES = (
     ('staged_f32', (4, 24, 40), 'f32', 'staged', 'drone'),        # track_stages=True: the stage-by-stage kernels
     ('staged_u16', (2, 16, 24), 'u16', 'staged', 'drone'),
     ('config5_shard', (128, 256, 256), 'f32', 'fused', 'drone'),  # BASELINE config 5's per-GPU share (64 x 256 x 256) x 2
+    ('planes_shard', (48, 512, 512), 'f32', 'fused', 'drone'),    # 24 x 512 x 512 per rank = 6 Mpx: the backward as passes over planes
 )
 
 
@@ -35,7 +36,7 @@ def case_inputs(name, shape, frames):
     from oracle import isp_oracle as orc
     B, H, W = shape
     seed = sum(map(ord, name))
-    u = np.rint(orc.synth_raw(B, H, W, seed=seed % 97, kind='scene' if B < 64 else 'uniform').astype(np.float64)
+    u = np.rint(orc.synth_raw(B, H, W, seed=seed % 97, kind='scene' if B < 40 else 'uniform').astype(np.float64)
                 * 4095).astype(np.uint16)
     cot = np.random.default_rng(seed).standard_normal((B, 3, H, W)).astype(np.float32)
     raw = u.astype(np.int16) if frames == 'u16' else u.astype(np.float32) / np.float32(4095)
