@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 for r in 1 2; do
 for envs in "$@"; do
   [ "$envs" = "-" ] && envs="R2L_NOTHING=1"
-  env $envs python bench.py --steps 5 --warmup 2 --no-roofline --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
+  env $envs python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-static-c3 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 for r in d['small_shapes']:
