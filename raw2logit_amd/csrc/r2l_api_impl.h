@@ -363,6 +363,7 @@ R2L_KERNEL(r2l_launch_pconv_fwd, R2LStageArgs, r2l_pconv_fwd_block, 4)
 R2L_KERNEL(r2l_launch_pconv_bwd, R2LStageArgs, r2l_pconv_bwd_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_point, R2LPointArgs, r2l_point_block, R2L_RED_FLOATS)
 R2L_KERNEL(r2l_launch_aug, R2LAugArgs, r2l_aug_block, 4)
+R2L_KERNEL(r2l_launch_aug_tiled, R2LAugTiledArgs, r2l_aug_tiled_block, R2L_AUG_LDS_FLOATS)
 R2L_KERNEL(r2l_launch_axpy, R2LAxpyArgs, r2l_axpy_block, 4)
 R2L_KERNEL(r2l_launch_philox_noise, R2LPhiloxArgs, r2l_philox_noise_block, 4)
 R2L_KERNEL(r2l_launch_ssim, R2LSsimArgs, r2l_ssim_block, R2L_SSIM_LDS_FLOATS)
@@ -1603,6 +1604,30 @@ int r2l_stage_point(int op, const float* x, const float* g, const float* w, cons
 int r2l_augment(const float* x, float* y, int N, int H, int W, int hflip, int vflip, int k, int inverse,
                 void* stream) {
   if (!x || !y || N < 1 || H < 1 || W < 1) return r2l_fail(-1, "r2l_augment: null pointer / bad dimensions");
+  if ((H & 3) == 0 && (W & 3) == 0 && (hflip || vflip || (k & 3))) {
+    // 16 bytes at a time, transposes through LDS tiles (r2l_aug_tiled_block)
+    const int Wo = (k & 1) ? H : W;
+    int r0, c0, r1, c1, r2, c2;
+    r2l_aug_map(H, W, hflip != 0, vflip != 0, k & 3, 0, 0, r0, c0);
+    r2l_aug_map(H, W, hflip != 0, vflip != 0, k & 3, 1, 0, r1, c1);
+    r2l_aug_map(H, W, hflip != 0, vflip != 0, k & 3, 0, 1, r2, c2);
+    R2LAugTiledArgs t;
+    t.x = x;
+    t.y = y;
+    t.N = N;
+    t.H = H;
+    t.W = W;
+    t.s0 = r0 * Wo + c0;
+    t.sr = (r1 * Wo + c1) - t.s0;
+    t.sc = (r2 * Wo + c2) - t.s0;
+    t.odd = k & 1;
+    t.inverse = inverse != 0;
+    t.ntr = (H + R2L_AUG_TS - 1) / R2L_AUG_TS;
+    t.ntc = (W + R2L_AUG_TS - 1) / R2L_AUG_TS;
+    size_t nt = (size_t)N * t.ntr * t.ntc;
+    if (nt > (size_t)1 << 30) return r2l_fail(-1, "r2l_augment: batch too large");
+    return r2l_launch_aug_tiled(t, (int)(nt < 4096 ? nt : 4096), stream);
+  }
   R2LAugArgs a{x, y, N, H, W, hflip != 0, vflip != 0, k & 3, inverse != 0};
   size_t g = ((size_t)N * H * W + R2L_NT - 1) / R2L_NT;
   if (g > 8192) g = 8192;

@@ -368,6 +368,119 @@ R2L_BLOCKFN void r2l_aug_block(const R2LAugArgs& a, int bid, int nblk, float* ld
   }
   R2L_PHASE_END
 }
+// The same permutation 16 bytes at a time (H % 4 == 0 and W % 4 == 0): the map is affine, element (r, c) of an input plane
+// goes to element s0 + sr r + sc c of the output plane.  Even k: sc = +-1, a thread moves 4 consecutive columns as one
+// vector (reversed for sc = -1).  Odd k: sr = +-1 -- a TRANSPOSE, through a 64 x 64 tile in LDS: rows of the source are
+// read as vectors, columns of the tile leave as vectors along the destination's rows.  (The element-wise kernel above
+// reads or writes 4-byte elements at a stride of a whole row there: 0.63 ms per pass on 64 x 3 x 512 x 512 against 0.1.)
+struct R2LAugTiledArgs {
+  const float* x;
+  float* y;
+  int N, H, W;     // input-shape plane size
+  int s0, sr, sc;  // forward map (r2l_aug_map)
+  int odd, inverse;
+  int ntr, ntc;    // tiles per plane
+};
+#define R2L_AUG_TS 64
+#define R2L_AUG_LDS_FLOATS (R2L_AUG_TS * (R2L_AUG_TS + 1))
+R2L_HD r2l_f4 r2l_rev4(const r2l_f4& v) {
+  r2l_f4 o;
+  o.x = v.w;
+  o.y = v.z;
+  o.z = v.y;
+  o.w = v.x;
+  return o;
+}
+R2L_BLOCKFN void r2l_aug_tiled_block(const R2LAugTiledArgs& a, int bid, int nblk, float* lds) {
+  constexpr int TS = R2L_AUG_TS, LS = TS + 1, RPP = R2L_NT / (TS / 4);  // tile rows per pass of the workgroup
+  const size_t hw = (size_t)a.H * a.W;
+  const int ntiles = a.N * a.ntr * a.ntc;
+  for (int tile = bid; tile < ntiles; tile += nblk) {
+    const int pl = tile / (a.ntr * a.ntc), tr = (tile / a.ntc) % a.ntr, tc = tile % a.ntc;
+    const int r0 = tr * TS, c0 = tc * TS;
+    const float* xb = a.x + (size_t)pl * hw;
+    float* yb = a.y + (size_t)pl * hw;
+    if (!a.odd) {
+      // a row goes to a row: no transpose, no LDS
+      R2L_PHASE_BEGIN
+      for (int i = 0; i < TS / RPP; ++i) {
+        const int r = r0 + tid / (TS / 4) + RPP * i, c = c0 + 4 * (tid % (TS / 4));
+        if (r < a.H && c < a.W) {
+          const long o = (long)a.s0 + (long)a.sr * r + (long)a.sc * c;  // augmented position of (r, c)
+          const long ov = a.sc == 1 ? o : o - 3;                         // ... of the vector's first element
+          if (!a.inverse) {
+            const r2l_f4 v = *(const r2l_f4*)(xb + (size_t)r * a.W + c);
+            *(r2l_f4*)(yb + ov) = a.sc == 1 ? v : r2l_rev4(v);
+          } else {
+            const r2l_f4 v = *(const r2l_f4*)(xb + ov);
+            *(r2l_f4*)(yb + (size_t)r * a.W + c) = a.sc == 1 ? v : r2l_rev4(v);
+          }
+        }
+      }
+      R2L_PHASE_END
+      continue;
+    }
+    // odd k: input-shape element (r, c) <-> augmented element s0 + sr r + sc c with sr = +-1: along an augmented row the
+    // input ROW index runs.  lds[(r - r0) * LS + (c - c0)] holds input-shape element (r, c).
+    R2L_PHASE_BEGIN
+    for (int i = 0; i < TS / RPP; ++i) {
+      if (!a.inverse) {  // input rows in as vectors
+        const int rl = tid / (TS / 4) + RPP * i, cl = 4 * (tid % (TS / 4));
+        const int r = r0 + rl, c = c0 + cl;
+        if (r < a.H && c < a.W) {
+          const r2l_f4 v = *(const r2l_f4*)(xb + (size_t)r * a.W + c);
+          float* d = lds + rl * LS + cl;
+          d[0] = v.x;
+          d[1] = v.y;
+          d[2] = v.z;
+          d[3] = v.w;
+        }
+      } else {  // augmented rows in as vectors: fixed c, 4 consecutive r
+        const int cl = tid / (TS / 4) + RPP * i, rl = 4 * (tid % (TS / 4));
+        const int r = r0 + rl, c = c0 + cl;
+        if (r < a.H && c < a.W) {
+          const long o = (long)a.s0 + (long)a.sr * r + (long)a.sc * c;
+          r2l_f4 v = *(const r2l_f4*)(xb + (a.sr == 1 ? o : o - 3));
+          if (a.sr != 1) v = r2l_rev4(v);
+          lds[(rl + 0) * LS + cl] = v.x;
+          lds[(rl + 1) * LS + cl] = v.y;
+          lds[(rl + 2) * LS + cl] = v.z;
+          lds[(rl + 3) * LS + cl] = v.w;
+        }
+      }
+    }
+    R2L_PHASE_END
+    R2L_PHASE_BEGIN
+    for (int i = 0; i < TS / RPP; ++i) {
+      if (!a.inverse) {  // tile columns out as vectors along the augmented rows
+        const int cl = tid / (TS / 4) + RPP * i, rl = 4 * (tid % (TS / 4));
+        const int r = r0 + rl, c = c0 + cl;
+        if (r < a.H && c < a.W) {
+          r2l_f4 v;
+          v.x = lds[(rl + 0) * LS + cl];
+          v.y = lds[(rl + 1) * LS + cl];
+          v.z = lds[(rl + 2) * LS + cl];
+          v.w = lds[(rl + 3) * LS + cl];
+          const long o = (long)a.s0 + (long)a.sr * r + (long)a.sc * c;
+          *(r2l_f4*)(yb + (a.sr == 1 ? o : o - 3)) = a.sr == 1 ? v : r2l_rev4(v);
+        }
+      } else {  // input rows out as vectors
+        const int rl = tid / (TS / 4) + RPP * i, cl = 4 * (tid % (TS / 4));
+        const int r = r0 + rl, c = c0 + cl;
+        if (r < a.H && c < a.W) {
+          const float* d = lds + rl * LS + cl;
+          r2l_f4 v;
+          v.x = d[0];
+          v.y = d[1];
+          v.z = d[2];
+          v.w = d[3];
+          *(r2l_f4*)(yb + (size_t)r * a.W + c) = v;
+        }
+      }
+    }
+    R2L_PHASE_END
+  }
+}
 // ---- AddGaussianNoise (utils/augmentation.py:17-31): y = x + noise * std, noise drawn by the caller ------
 struct R2LAxpyArgs {
   const float* x;

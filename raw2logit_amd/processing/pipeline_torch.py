@@ -299,8 +299,12 @@ class ParametrizedProcessing(nn.Module):
             from ..staged import staged_forward
             rgb = staged_forward(self, raw)
         else:
+            # (90-degree rotations: the stores of a row-walking kernel land one element per row of the rotated output --
+            # 1.16 ms per step at 64x512x512 -- while the permutation kernel transposes through LDS tiles: 0.40 + 2 x 0.1 ms;
+            # `fuse_rot90 = True` on the module takes the kernels' own path, square frames only)
+            odd = bool(epilogue is not None and (epilogue[2] & 1))
             fuse = epilogue is not None and F_.epilogue_supported(raw, self) and \
-                not ((epilogue[2] & 1) and raw.shape[-1] != raw.shape[-2])
+                (not odd or (getattr(self, 'fuse_rot90', False) and raw.shape[-1] == raw.shape[-2]))
             rgb = self._fused_forward(raw, epilogue if fuse else None)
             d['stages'] = _LazyStages(self, raw)
             if fuse:

@@ -11,6 +11,8 @@ for B, S in ((64, 512), (128, 256), (64, 256)):
     cot = torch.randn((B, 3, S, S), device=dev)
     m = ParametrizedProcessing(cameras.DRONE, batch_norm_output=True).to(dev).train()
     params = list(m.parameters())
+    m.fuse_rot90 = True     # 'epilogue' = the kernels' own stores for rotations too (the module's default sends them to the
+                            # permutation kernel, which transposes through LDS tiles: the 'separate' column)
     for (h, v, k) in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 0, 2), (0, 0, 1), (1, 0, 3)):
         res = []
         for mode in ('separate', 'epilogue'):

@@ -627,6 +627,7 @@ def check_output_epilogue(device):
                         m1, m2 = make_module(case, P, device), make_module(case, P, device)
                         m1.raw_bits = m2.raw_bits = 12
                         y1 = aug.flip_rot(m1(raw), h, v, k)
+                        m2.fuse_rot90 = True                               # (the kernels' own path for rotations too)
                         m2.__dict__['_epilogue'] = (h, v, k)
                         y2 = m2(raw)
                         assert '_epilogue' not in m2.__dict__                      # one shot

@@ -502,6 +502,7 @@ def test_backward_kernels_as_passes_over_planes(shape, dev):
                 with pc.launch_shape_overrides(dev):
                     if epilogue is not None:
                         from raw2logit_amd import augmentation as aug
+                        m.fuse_rot90 = True                 # (rotations too through the kernels' own stores / fetches)
                         m.__dict__['_epilogue'] = epilogue
                         (m(raw) * aug.flip_rot(cot, *epilogue)).sum().backward()
                     else:
@@ -561,6 +562,7 @@ def test_apply_pass_reads_the_luma_plane_the_statistics_pass_kept(shape, dev):
         try:
             with pc.launch_shape_overrides(dev):
                 if epilogue is not None:
+                    m.fuse_rot90 = True                 # (rotations too through the kernels' own stores / fetches)
                     m.__dict__['_epilogue'] = epilogue
                 y = m(raw)
                 (y * (cot if epilogue is None else aug.flip_rot(cot, *epilogue))).sum().backward()
