@@ -49,3 +49,13 @@ for rnd in range(3):
             res[(k, b)].append(run(f))
 for (k, b), v in res.items():
     print('%-10s bands %-3s median us per round: %s   %6.1f GB/s' % (k, b, ' '.join('%7.1f' % x for x in v), 16.0 * n / min(v) / 1e3))
+# the builds must agree bit for bit (same arithmetic, different loops): compare every output with the first build's
+ref = None
+for k, f in fns.items():
+    out.fill_(-7.0)
+    assert f(raw.data_ptr(), out.data_ptr(), B, S, S, cam, deb, 0, 0, 2.2, None, 0, stream) == 0
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = out.clone()
+    else:
+        print('%-10s max |out - %s| = %.3e' % (k, next(iter(fns)), float((out - ref).abs().max())))
