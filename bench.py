@@ -110,8 +110,8 @@ def parse():
     ap.add_argument('--quick', action='store_true',
                     help='the headline workload only: no cpu_baseline leg, no static_c3 / small_shapes sub-records (A/B runs)')
     ap.add_argument('--graph', action='store_true',
-                    help='replay forward and backward as HIP graphs (torch.cuda.make_graphed_callables): the step costs the '
-                         'host two graph launches instead of two C-ABI calls + autograd; matters below ~8 Mpix per step, '
+                    help='replay the whole step as ONE HIP graph (raw2logit_amd/graphs.py: StepGraph): the step costs the '
+                         'host one graph launch instead of two C-ABI calls + autograd; matters below ~8 Mpix per step, '
                          'where the host is the bound (single GPU)')
     ap.add_argument('--no-small-shapes', action='store_true',
                     help="skip the small_shapes sub-records (the datasets' 256x256 tiles: BASELINE configs 4 / 5 per GPU)")
@@ -390,8 +390,9 @@ def static_records(torch, lib, clock, dev):
 
 def small_shape_records(torch, lib, clock, dev, cameras, ParametrizedProcessing):
     """the step at the reference's real tile size (dataset.py:92: 256 x 256): BASELINE config 5's share per GPU
-    (64 frames) and config 4's ISP share (128 frames) -- eager (two C-ABI calls through autograd) and replayed as HIP
-    graphs, plus the kernels' own time from the HIP-event pass."""
+    (64 frames) and config 4's ISP share (128 frames) -- eager (two C-ABI calls through autograd) and the whole step
+    replayed as one HIP graph, plus the kernels' own time from the HIP-event pass."""
+    from raw2logit_amd.graphs import StepGraph
     recs = []
     for B, S in ((64, 256), (128, 256)):
         gen = torch.Generator(dev).manual_seed(0)
@@ -401,12 +402,13 @@ def small_shape_records(torch, lib, clock, dev, cameras, ParametrizedProcessing)
         for mode in ('eager', 'graph'):
             model = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True).to(dev).train()
             params = list(model.parameters())
-            fwd = torch.cuda.make_graphed_callables(model, (raw,)) if mode == 'graph' else model
-
-            def step():
-                for p in params:
-                    p.grad = None
-                fwd(raw).backward(cot)
+            if mode == 'graph':                      # the whole step as ONE HIP graph (raw2logit_amd/graphs.py)
+                step = StepGraph(model, raw, cot).replay
+            else:
+                def step():
+                    for p in params:
+                        p.grad = None
+                    model(raw).backward(cot)
             clock.preroll(step, None, 0.05)
             dt = clock.time_steps(step, 50, 10)
             rec['ms_per_step' + ('_graph' if mode == 'graph' else '')] = round(1e3 * dt / 50, 4)
@@ -600,7 +602,8 @@ def main():
     if args.graph:
         if world > 1:
             raise SystemExit('bench.py: --graph is a single-GPU option (the statistics exchange splits the step calls)')
-        fwd = torch.cuda.make_graphed_callables(model, (raw,))
+        from raw2logit_amd.graphs import StepGraph
+        graph_step = StepGraph(model, raw, cot)
 
     pending = []
 
@@ -608,8 +611,11 @@ def main():
         while pending:                               # nothing needs the sum before the optimiser / the next forward
             pending.pop().wait()
 
-    def step():
+    def step(eager=False):
         finish()
+        if args.graph and not eager:                 # the whole step as ONE HIP graph (raw2logit_amd/graphs.py)
+            graph_step.replay()
+            return
         for p in params:
             p.grad = None
         y = fwd(raw)
@@ -634,7 +640,8 @@ def main():
     if not args.no_roofline:
         # instrumented pass of the same K steps with the library's per-kernel HIP-event hooks switched on
         F_.CommTimer.enable(world > 1)
-        kernels = kernel_times(lib, clock, step, args.steps, finish)
+        # (a replayed graph makes no library calls: the per-kernel hooks see the same kernels through the eager step)
+        kernels = kernel_times(lib, clock, (lambda: step(True)) if args.graph else step, args.steps, finish)
         comm_us = F_.CommTimer.report() if world > 1 else None
         F_.CommTimer.enable(False)
 
@@ -701,7 +708,7 @@ def main():
             # instrumented pass): the two small all-gathers sit inside the step, the gradient all-reduce overlaps
             out['comm_us'] = comm_us
         if args.graph:
-            out['config']['step'] += ' (forward and backward replayed as HIP graphs)'
+            out['config']['step'] += ' (the whole step replayed as one HIP graph)'
         if small is not None:
             out['small_shapes'] = small
         if static_c3 is not None:

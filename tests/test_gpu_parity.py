@@ -259,6 +259,51 @@ def test_survives_hip_graph_capture(dev):
             assert torch.equal(p.grad, q.grad)
 
 
+def test_whole_step_as_one_hip_graph(dev):
+    """raw2logit_amd.graphs.StepGraph: forward + backward + gradient accumulation + BatchNorm's running statistics
+    captured as ONE graph; every replay reproduces the eager step bit for bit, on new contents of the static buffers too."""
+    import copy
+    from raw2logit_amd.graphs import StepGraph
+    B, S = 6, 96
+    raws = [torch.from_numpy(orc.synth_raw(B, S, S, seed=50 + i, kind='scene')).to(dev) for i in range(3)]
+    cots = [torch.randn((B, 3, S, S), device=dev, generator=torch.Generator(dev).manual_seed(7 + i)) for i in range(3)]
+    m = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).to(dev).train()
+    m2 = copy.deepcopy(m)
+    raw, cot = raws[0].clone(), cots[0].clone()
+    g = StepGraph(m2, raw, cot)
+    # the warm-up steps inside StepGraph moved m2's running statistics: start both modules from the same state again
+    m2.load_state_dict(m.state_dict())
+    for i in range(3):
+        raw.copy_(raws[i])
+        cot.copy_(cots[i])
+        for p in m.parameters():
+            p.grad = None
+        y0 = m(raws[i])
+        y0.backward(cots[i])
+        y1 = g.replay()
+        assert torch.equal(y0, y1)
+        for p, q in zip(m.parameters(), m2.parameters()):
+            assert torch.equal(p.grad, q.grad)
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, m2.state_dict()[k]), k
+    # with a loss behind the processor (a small classifier head, captured with it)
+    head = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten()).to(dev)
+    head2 = copy.deepcopy(head)
+    target = torch.tensor([0, 1, 2, 3, 0, 1], device=dev)
+    m3 = copy.deepcopy(m)
+    g3 = StepGraph(m3, raw, None, loss=lambda rgb: torch.nn.functional.cross_entropy(head2(rgb), target), loss_modules=(head2,))
+    m3.load_state_dict(m.state_dict())
+    for p in list(m.parameters()) + list(head.parameters()):
+        p.grad = None
+    torch.nn.functional.cross_entropy(head(m(raws[2])), target).backward()
+    for _ in range(2):              # (replays overwrite the gradients: the second one must not accumulate)
+        g3.replay()
+    for p, q in zip(m.parameters(), m3.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6)   # (the head's MIOpen kernels may differ under capture)
+    for p, q in zip(head.parameters(), head2.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-7)
+
+
 def test_static_per_image_wrappers(golden, dev):
     pc.check_static_wrappers(golden, dev)
 
