@@ -82,6 +82,12 @@ while time.time() - t0 < budget:
     if r_out > (1.0 if kind == 'midtone' else 3.0):
         marginal.append(('out', r_out / (1.0 if kind == 'midtone' else 3.0), (B, H, W, bn, kind, u16)))
     worst['out'] = max(worst['out'], r_out)
+    if r_out > float(os.environ.get('REPORT_OUT', 'inf')):    # where, and how far the float32 ORACLE is from float64 there
+        i = np.unravel_index(int(np.argmax(eo / tol)), eo.shape)
+        o32 = np.asarray(c32['out'] if 'out' in c32 else orc.parametrized_forward(raw_np, P, bn=obn)[0], dtype=np.float64)
+        print('  out ratio %.2f at %s: got %.7g oracle64 %.7g oracle32 %.7g  pre-gamma %.4g  tol %.3g  |o32-o64| max over the frame / tol %.2f  %s'
+              % (r_out, i, float(y.detach().cpu().numpy()[i]), float(o[i]), float(o32[i]), float(cache['rgb'][i]), float(tol[i]),
+                 float((np.abs(o32 - o) / tol).max()), (B, H, W, bn, kind, u16, bool(additive))), flush=True)
     for k in g:
         got = pc.NAME2ATTR[k](m).grad.detach().cpu().numpy().reshape(np.asarray(g[k]).shape)
         flip = max(np.abs(np.asarray(glo[k]) - g[k]).max(), np.abs(np.asarray(ghi[k]) - g[k]).max())
