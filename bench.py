@@ -46,6 +46,7 @@ ALGO_BYTES_PER_PX = (
     ('r2l_launch_fwd', 16.0),        # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0 -- or Y', 4, when the
                                      # backward / the apply pass will read it); tile or row-streaming
     ('r2l_launch_bwd1_plane', 24.0),  # plane pass of kernel B1: raw 4 + Y' 4 + grad_out 12 in, dL/dY'' 4 out
+    ('r2l_launch_bwd1_blur_hp', 12.0),  # B1's second pass + B2's first in one: dL/dY'' 4 + Y' 4 in, the blur's adjoint 4 out
     ('r2l_launch_bwd1_blur', 8.0),   # its second pass (blur-weight sums): dL/dY'' 4 + Y' 4 in
     ('r2l_launch_bwd2_hp', 8.0),     # plane passes of kernel B2: dL/dY'' 4 in, the blur's adjoint 4 out ...
     ('r2l_launch_bwd2_sums', 8.0),   # ... that plane 4 + raw 4 in

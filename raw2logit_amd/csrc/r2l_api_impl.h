@@ -248,6 +248,7 @@ R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_u16, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_
 R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_epi, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<false, true>)
 R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_epi_u16, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<true, true>)
 R2L_KERNEL_NT_LDS(r2l_launch_bwd1_blur, R2LBwd1Args, R2L_BP_NT, R2L_BP_RED_FLOATS, 3, r2l_bwd1_blur_block)
+R2L_KERNEL_NT_LDS(r2l_launch_bwd1_blur_hp, R2LBwd1Args, R2L_BP_NT, R2L_BP_RED_FLOATS, R2L_HB_OCC, r2l_bwd1_blur_hp_block)
 // kernel B2 likewise: the blur's adjoint into a plane, then the sums + the final reduction and unfold
 R2L_KERNEL_NT_LDS(r2l_launch_bwd2_hp, R2LBwd2Args, R2L_BP_NT, 4, 4, r2l_bwd2_hp_block)
 R2L_KERNEL_NT_LDS(r2l_launch_bwd2_sums, R2LBwd2Args, R2L_B2S_NT, R2L_B2S_LDS_FLOATS, 3, r2l_bwd2_sums_block<false>)
@@ -811,9 +812,12 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   a1.yp = saved ? ws.yp : nullptr;
   a1.ep = (ep && ep->on) ? *ep : R2LEpi{0, 0, 0, 0};
   a1.band_h = 0;
+  a1.hp = nullptr;
+  a1.band_hb = 0;
   if (a1.ep.on && additive) return r2l_fail(-3, "r2l_isp_bwd: no output epilogue with an additive layer");
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
   int g1p = 0;  // workgroups of the plane passes, when they run
+  bool blur_hp = false;  // ... with r2l_bwd1_blur_hp_block doing kernel B2's first pass
 #ifndef R2L_EMUL
   // ... where there is enough work for their eight launch tails: 128x256x256 (8.4 Mpx) 124 us against the tile kernels' 132,
   // 64x256x256 (4.2 Mpx) 99 against 85 (profiles/r03_z_bench.json, small_shapes)
@@ -846,7 +850,25 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
 #ifndef R2L_EMUL
     e1 = a1.ep.on ? (raw.u16 ? r2l_launch_bwd1_plane_epi_u16(a1, g1p, stream) : r2l_launch_bwd1_plane_epi(a1, g1p, stream))
                   : (raw.u16 ? r2l_launch_bwd1_plane_u16(a1, g1p, stream) : r2l_launch_bwd1_plane(a1, g1p, stream));
-    if (!e1) e1 = r2l_launch_bwd1_blur(a1, g1p, stream);
+    // its second pass (the blur-weight sums) and kernel B2's first (the blur's adjoint) read the same plane: one pass
+    // when B2 runs as plane passes too
+    blur_hp = !r2l_env_int("R2L_BWD2_TILED", 0) && !r2l_env_int("R2L_BWD_SPLIT_BLUR", 0);
+    a1.hp = ws.hp;
+    {  // (its own band height: R2L_HB_OCC wavefronts per SIMD; not more workgroups than wrote the first pass's partials)
+      const long slots_hb = 256L * 4 * R2L_HB_OCC;
+      int bh = 6;
+      long best = -1;
+      for (int c = 6; c <= 48; c += 6) {
+        const long items = (long)B * ((W + 255) / 256) * ((H + c - 1) / c);
+        const long cost = ((items + slots_hb - 1) / slots_hb) * (10L * c + 32);
+        if (best < 0 || cost < best) {
+          best = cost;
+          bh = c;
+        }
+      }
+      a1.band_hb = (r2l_env_int("R2L_HB_BAND", bh) + 5) / 6 * 6;
+    }
+    if (!e1) e1 = blur_hp ? r2l_launch_bwd1_blur_hp(a1, g1p, stream) : r2l_launch_bwd1_blur(a1, g1p, stream);
 #else
     e1 = 0;
 #endif
@@ -901,7 +923,8 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
     a2.params = nullptr;
     a2.grad_params = nullptr;
     a2.asym = 0;
-    if (int e = r2l_launch_bwd2_hp(a2, (int)((hitems + R2L_BP_NWV - 1) / R2L_BP_NWV), stream)) return e;
+    if (!blur_hp)
+      if (int e = r2l_launch_bwd2_hp(a2, (int)((hitems + R2L_BP_NWV - 1) / R2L_BP_NWV), stream)) return e;
     a2.band_h = band_rows(256L * 4 * 3, "R2L_B2S_BAND");
     const long sitems = (long)B * nstrip * ((H + a2.band_h - 1) / a2.band_h);
     long gs = (sitems + R2L_B2S_NWV - 1) / R2L_B2S_NWV;

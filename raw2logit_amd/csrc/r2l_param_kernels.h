@@ -1111,6 +1111,8 @@ struct R2LBwd1Args {
   const float* yp;      // (B,H,W) or null: the sharpened luma Y' the forward kept (SAVED instantiations)
   R2LEpi ep;            // ep.on: grad_out arrives in the augmented layout the forward's epilogue wrote (R2LEpi)
   int band_h;           // r2l_bwd1_plane_block: rows per work item (a multiple of 6)
+  float* hp;            // r2l_bwd1_blur_hp_block: (B,H,W) the blur's adjoint of dL/dY'' (kernel B2's plane)
+  int band_hb;          // r2l_bwd1_blur_hp_block: rows per work item (a multiple of 6)
 };
 
 // per-thread accumulators of B1, as pairs: element h of a pair belongs to the pixels in the even (h = 0) or

@@ -534,8 +534,8 @@ R2L_HD void r2l_hp_build(const R2LFaStage& s, bool rin, bool le, bool re, float 
   o[6] = re ? 0.f : r1;
   o[7] = re ? 0.f : r2;
 }
-template <int K>
-R2L_HD void r2l_hp_step(const R2LBwd2Args& a, const float gw[6][8], int q, bool le, bool re, bool store_ok, float* hpb,
+template <int K, class ArgsT>
+R2L_HD void r2l_hp_step(const ArgsT& a, const float gw[6][8], int q, bool le, bool re, bool store_ok, float* hpb,
                         int x0) {
   const int H = a.H;
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, gw[(K + 2) % 6][2]));
@@ -624,6 +624,177 @@ R2L_BLOCKFN void r2l_bwd2_hp_block(const R2LBwd2Args& a, int bid, int nblk, floa
 #undef R2L_HP_STEP
   }
 #undef R2L_HP_LOAD_STEP
+}
+
+// ---- B1's second pass and B2's first pass as ONE pass.  Both walk the dL/dY'' plane with a 5-row window of it: the fused
+// pass reads dL/dY'' once -- 12 B/px (4 dL/dY'' + 4 Y' in, 4 HP out) instead of 8 + 8 -- and needs no Y' window: the
+// blur-weight sums are taken the adjoint's way round,
+//   d/d gaussian_blur.weight[i][j] = sum_p g(p) Y'_ext(p + t) = sum_q Y'_ext(q) g0(q - t),   t = (i-2, j-2),
+// over the positions q of the MIRROR-EXTENDED image (g0 = dL/dY'' extended with zeros): every in-image q is a pixel of the
+// row at hand against the window the adjoint uses anyway (window row r meets weight row 4 - r), and the out-of-image
+// rows / columns are the virtual rows / columns of the adjoint -- the same extra (window row, weight row) calls on rows
+// {1, 2, H-3, H-2}, and for the lanes at the image's left / right edge the two virtual columns' few products, whose Y'
+// values are the lane's own columns 1, 2 / W-2, W-3.  (The sums group differently from r2l_bwd1_blur_block's: equal to
+// round-off, not bit for bit; HP is r2l_hp_row's arithmetic unchanged.)
+struct R2LBsY {      // Y' of the row at hand: the lane's 4 pixels as pairs, and the virtual columns' values
+  r2l_p2 y01, y23;
+  float yl1, yl2;    // Y'(1), Y'(2) in the lanes at the left edge (virtual columns -1, -2), else 0
+  float yr2, yr1;    // Y'(W-2), Y'(W-3) in the lanes at the right edge (virtual columns W, W+1), else 0
+};
+// one window row of dL/dY'' (columns x0-2 .. x0+5, zero outside the image) against weight row i: HP as r2l_hp_row, and
+// the 5 blur-weight sums of that row
+template <class WT>
+R2L_HD void r2l_hb_row(R2LHpAcc& A, r2l_p2 blur[25], const R2LBsY& y, const float g[8], WT bw, int i) {
+  float bf[5];  // bf[s] = blur[i][4 - s]: HP(x) += bf[s] * g(x + s - 2)
+  R2L_PRAGMA_UNROLL
+  for (int s_ = 0; s_ < 5; ++s_) bf[s_] = bw[i * 5 + 4 - s_];
+  r2l_p2 P[4], O[3];
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 4; ++k) P[k] = r2l_mk2(g[2 * k], g[2 * k + 1]);
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) O[k] = r2l_straddle(P[k], P[k + 1]);
+  R2L_PRAGMA_UNROLL
+  for (int s_ = 0; s_ < 5; ++s_) {
+    const r2l_p2 w = r2l_splat2(bf[s_]);
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) A.h[p] = r2l_pfma(w, (s_ & 1) ? O[p + s_ / 2] : P[p + s_ / 2], A.h[p]);
+  }
+  A.el = r2l_pfma(r2l_mk2(bf[4], bf[3]), r2l_splat2(g[2]), A.el);
+  A.el = r2l_pfma(r2l_mk2(0.f, bf[4]), r2l_splat2(g[3]), A.el);
+  A.er = r2l_pfma(r2l_splat2(bf[0]), r2l_mk2(g[4], g[5]), A.er);
+  A.er = r2l_pfma(r2l_mk2(bf[1], 0.f), r2l_splat2(g[5]), A.er);
+  // weight column j meets g(x + 2 - j): the pairs (g[4-j], g[5-j]) and (g[6-j], g[7-j]) -- P for even j, O for odd j
+  R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 5; ++j) {
+    const int k = (4 - j) >> 1;
+    r2l_p2 s_ = blur[i * 5 + j];
+    s_ = r2l_pfma(y.y01, (j & 1) ? O[k] : P[k], s_);
+    s_ = r2l_pfma(y.y23, (j & 1) ? O[k + 1] : P[k + 1], s_);
+    blur[i * 5 + j] = s_;
+  }
+  // virtual columns: -1 (= column 1) sees g columns 0, 1 through weight columns 1, 0; -2 (= column 2) sees column 0 through
+  // weight column 0; W (= W-2) sees columns W-1, W-2 through weight columns 3, 4; W+1 (= W-3) sees W-1 through 4
+  blur[i * 5 + 1][0] = fmaf(y.yl1, g[2], blur[i * 5 + 1][0]);
+  blur[i * 5 + 0][0] = fmaf(y.yl1, g[3], fmaf(y.yl2, g[2], blur[i * 5 + 0][0]));
+  blur[i * 5 + 3][1] = fmaf(y.yr2, g[5], blur[i * 5 + 3][1]);
+  blur[i * 5 + 4][1] = fmaf(y.yr2, g[4], fmaf(y.yr1, g[5], blur[i * 5 + 4][1]));
+}
+template <int K>
+R2L_HD void r2l_hb_step(const R2LBwd1Args& a, const float gw[6][8], r2l_p2 blur[25], const r2l_f4& yrow, int q, bool le,
+                        bool re, bool ok, float* hpb, int x0) {
+  const int H = a.H;
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, gw[(K + 2) % 6][2]));
+  R2LHpAcc A;
+  A.h[0] = A.h[1] = A.el = A.er = r2l_splat2(0.f);
+  R2LBsY y;  // (lanes past the last column and rows past the band's end contribute nothing)
+  const float y0 = ok ? yrow.x : 0.f, y1 = ok ? yrow.y : 0.f, y2 = ok ? yrow.z : 0.f, y3 = ok ? yrow.w : 0.f;
+  y.y01 = r2l_mk2(y0, y1);
+  y.y23 = r2l_mk2(y2, y3);
+  y.yl1 = le ? y1 : 0.f;
+  y.yl2 = le ? y2 : 0.f;
+  y.yr2 = re ? y2 : 0.f;
+  y.yr1 = re ? y1 : 0.f;
+  // window rows q-2 .. q+2 sit in ring slots K+4 .. K+8; window row r holds g(q - 2 + r) and meets weight row 4 - r
+  R2L_PRAGMA_UNROLL
+  // (one window row at a time: left alone the scheduler interleaves the five rows' independent chains and holds all their
+  // pairs at once -- 256 registers and scratch)
+  for (int r = 0; r < 5; ++r) {
+    r2l_hb_row(A, blur, y, gw[(K + 4 + r) % 6], F.blur, 4 - r);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (q < 3 || q >= H - 3) {  // uniform: the rows whose mirror images lie outside the image (as r2l_hp_step)
+    if (q == 1) {
+      r2l_hb_row(A, blur, y, gw[(K + 4 + 2) % 6], F.blur, 0);
+      r2l_hb_row(A, blur, y, gw[(K + 4 + 1) % 6], F.blur, 1);
+    }
+    if (q == 2) r2l_hb_row(A, blur, y, gw[(K + 4 + 0) % 6], F.blur, 0);
+    if (q == H - 2) {
+      r2l_hb_row(A, blur, y, gw[(K + 4 + 3) % 6], F.blur, 3);
+      r2l_hb_row(A, blur, y, gw[(K + 4 + 2) % 6], F.blur, 4);
+    }
+    if (q == H - 3) r2l_hb_row(A, blur, y, gw[(K + 4 + 4) % 6], F.blur, 4);
+  }
+  float h0 = A.h[0][0], h1 = A.h[0][1], h2 = A.h[1][0], h3 = A.h[1][1];
+  h1 += le ? A.el[1] : 0.f;
+  h2 += le ? A.el[0] : 0.f;
+  h2 += re ? A.er[0] : 0.f;
+  h1 += re ? A.er[1] : 0.f;
+  if (ok) {
+    r2l_f4 s4;
+    s4.x = h0;
+    s4.y = h1;
+    s4.z = h2;
+    s4.w = h3;
+    *(r2l_f4*)(hpb + (unsigned)q * (unsigned)a.W + (unsigned)x0) = s4;
+  }
+}
+#ifndef R2L_HB_OCC
+#define R2L_HB_OCC 2
+#endif
+R2L_BLOCKFN void r2l_bwd1_blur_hp_block(const R2LBwd1Args& a, int bid, int nblk, float* lds) {
+  constexpr int NWV = R2L_BP_NWV;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  r2l_p2 blur[25];
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 25; ++i) blur[i] = r2l_splat2(0.f);
+  const int nstrip = (a.W + 255) >> 8;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const int band_h = a.band_hb, nband = (a.H + band_h - 1) / band_h, nitems = a.B * nband * nstrip;
+  constexpr int PF = R2L_BB_PF;
+  static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+  R2L_PRAGMA_NOUNROLL
+  for (int item = bid * NWV + wave; item < nitems; item += nblk * NWV) {
+    const int strip = item % nstrip, ib = item / nstrip;
+    const int band = ib % nband, b = ib / nband;
+    const int xs = strip * 256 + 4 * lane;
+    const bool in_w = xs < a.W;
+    const int x0 = in_w ? xs : a.W - 4;
+    const bool le = x0 == 0, re = x0 + 4 >= a.W;
+    const int y0 = band * band_h;  // a multiple of 6
+    const int y1 = (y0 + band_h < a.H) ? y0 + band_h : a.H;
+    const size_t img = (size_t)b * plane;
+    const float* ypimg = a.yp + img;
+    const float* gimg = a.gypp + img;
+    float* hpb = a.hp + img;
+    float gw[6][8];      // dL/dY'' rows, zero outside the image (slot = row mod 6)
+    R2LFaStage pfg[PF];  // dL/dY'' row q + 2
+    r2l_f4 pfy[PF];      // Y' row q
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < PF; ++i) {
+      r2l_fa_fetch(gimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfg[(2 + i) % PF]);
+      const int yc = (y0 + i < a.H) ? y0 + i : a.H - 1;
+      pfy[i % PF] = r2l_stream_load_f4(ypimg + (size_t)yc * a.W + x0);
+    }
+#define R2L_BH_LOAD_STEP(K, q)                                                                          \
+  r2l_hp_build(pfg[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, gw[((K) + 2) % 6]);          \
+  r2l_fa_fetch(gimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pfg[(K) % PF]);
+    R2L_BH_LOAD_STEP(2, y0 - 4)
+    R2L_BH_LOAD_STEP(3, y0 - 3)
+    R2L_BH_LOAD_STEP(4, y0 - 2)
+    R2L_BH_LOAD_STEP(5, y0 - 1)
+    for (int qb = y0; qb < y1; qb += 6) {
+#define R2L_BH_STEP(K)                                                                                  \
+  {                                                                                                     \
+    const int q = qb + K;                                                                               \
+    R2L_BH_LOAD_STEP(K, q)                                                                              \
+    const r2l_f4 y_ = pfy[(K) % PF];                                                                    \
+    {                                                                                                   \
+      const int yc = (q + PF < a.H) ? q + PF : a.H - 1;                                                 \
+      pfy[(K) % PF] = r2l_stream_load_f4(ypimg + (size_t)yc * a.W + x0);                                \
+    }                                                                                                   \
+    if (r2l_opaque_true()) r2l_hb_step<K>(a, gw, blur, y_, q, le, re, in_w && q < y1, hpb, x0);         \
+  }
+      R2L_BH_STEP(0)
+      R2L_BH_STEP(1)
+      R2L_BH_STEP(2)
+      R2L_BH_STEP(3)
+      R2L_BH_STEP(4)
+      R2L_BH_STEP(5)
+#undef R2L_BH_STEP
+    }
+#undef R2L_BH_LOAD_STEP
+  }
+  r2l_bp_block_reduce<R2L_B1_GAU, R2L_BP_NT>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return blur[i][0] + blur[i][1]; });
 }
 
 // ---- second pass of B2: HP + raw -> gY = sharpen^T(HP) (zero padding), the sums  d/d sharpening_filter.weight[t] =

@@ -519,8 +519,9 @@ def test_backward_reads_the_luma_plane_the_forward_kept(shape, dev):
                                    (2, 514, 512), (3, 4, 4), (2, 6, 1024), (4, 256, 256), (2, 8, 256), (9, 64, 64)], ids=str)
 def test_backward_kernels_as_passes_over_planes(shape, dev):
     """Kernels B1 and B2 as passes of independent wavefronts over planes (r2l_param_plane_bwd.h: pointwise adjoints +
-    dL/dY'' + chroma / gamma sums; the 25 blur-weight sums from dL/dY'' and Y'; the blur's mirror-padding adjoint into a
-    plane; the sharpen's adjoint + sharpen / luma-stencil sums + final reduction and unfold) against the LDS tile kernels
+    dL/dY'' + chroma / gamma sums; the 25 blur-weight sums and the blur's mirror-padding adjoint in one pass over dL/dY''
+    -- or as the two passes they were first, R2L_BWD_SPLIT_BLUR --; the sharpen's adjoint + sharpen / luma-stencil sums +
+    final reduction and unfold) against the LDS tile kernels
     of the diagnostic build (R2L_BWD1_TILED, which takes both back; R2L_BWD2_TILED): all 132 gradients, float32 and
     16-bit frames, with and without train-mode BatchNorm, every band height and grid (one wavefront takes everything ...
     one item each), frames of 4 rows (every row a border row of the blur and of its adjoint) -- and, through the golden /
@@ -559,10 +560,13 @@ def test_backward_kernels_as_passes_over_planes(shape, dev):
 
         ref = run({'R2L_BWD1_TILED': '1'}, 'f32')
         worst = 0.0
-        for env, frames in (({}, 'f32'), ({}, 'u16'), ({'R2L_BP_BAND': '6', 'R2L_HP_BAND': '12', 'R2L_B2S_BAND': '6'}, 'f32'),
-                            ({'R2L_BP_BAND': '12', 'R2L_GRID_BWD1': '1', 'R2L_GRID_BWD2': '1', 'R2L_B2S_BAND': '18'}, 'f32'),
-                            ({'R2L_BP_BAND': '1000', 'R2L_GRID_BWD1': '3', 'R2L_HP_BAND': '1000', 'R2L_B2S_BAND': '1000'}, 'u16'),
-                            ({'R2L_GRID_BWD1': '7', 'R2L_GRID_BWD2': '5'}, 'f32'), ({'R2L_BWD2_TILED': '1'}, 'f32')):
+        for env, frames in (({}, 'f32'), ({}, 'u16'),
+                            ({'R2L_BP_BAND': '6', 'R2L_HB_BAND': '12', 'R2L_B2S_BAND': '6'}, 'f32'),
+                            ({'R2L_BP_BAND': '12', 'R2L_HB_BAND': '6', 'R2L_GRID_BWD1': '1', 'R2L_GRID_BWD2': '1', 'R2L_B2S_BAND': '18'}, 'f32'),
+                            ({'R2L_BP_BAND': '1000', 'R2L_GRID_BWD1': '3', 'R2L_HB_BAND': '1000', 'R2L_B2S_BAND': '1000'}, 'u16'),
+                            ({'R2L_GRID_BWD1': '7', 'R2L_GRID_BWD2': '5'}, 'f32'), ({'R2L_BWD2_TILED': '1'}, 'f32'),
+                            # B1's blur-weight sums and B2's blur adjoint as two passes (r2l_bwd1_blur_block, r2l_bwd2_hp_block)
+                            ({'R2L_BWD_SPLIT_BLUR': '1'}, 'f32'), ({'R2L_BWD_SPLIT_BLUR': '1', 'R2L_HP_BAND': '12'}, 'u16')):
             g = run(env, frames)
             for n, r in ref.items():
                 e = np.abs(g[n] - r).max()
