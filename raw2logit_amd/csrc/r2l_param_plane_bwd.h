@@ -9,6 +9,8 @@
 // Two kernels because one does not fit: windows (66 registers) + prefetch (36) + all 46 accumulator pairs (92) +
 // the pointwise part's temporaries need more than the 256 registers of two wavefronts per SIMD (125 spilled registers);
 // without the 25 blur pairs the first pass takes 211.  The second pass re-reads dL/dY'' (4 B/px) and Y' (4 B/px).
+// When kernel B2 runs as plane passes too, the second pass is r2l_bwd1_blur_hp_block instead (below): the blur-weight sums
+// AND kernel B2's first pass (the blur's adjoint) in one walk over dL/dY''.
 //
 // What the tile kernel's threads did not have to handle: a lane sees BOTH row parities.  The parity-indexed sums (folded
 // chroma stencils GAU / GAV [row parity][tap] x column-parity pair, SU / SV) therefore exist twice, 20 pairs per row
