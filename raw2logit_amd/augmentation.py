@@ -194,6 +194,11 @@ class ComposeState:
         Returns False (and arms nothing) for transform lists that hold anything but flips / rot90, or an order of them
         that does not commute into one permutation.  ``processor.buffer['processed_rgb']`` of an armed call holds the
         augmented output."""
+        self._armed = None
+        # only a processor that pops `_epilogue` itself may be armed (ParametrizedProcessing declares it); RawToRGB,
+        # NNProcessing, nn.Identity (train.py:173-202) get the separate permutation kernel in __call__ as before
+        if not getattr(processor, 'supports_output_epilogue', False):
+            return False
         if not all(hasattr(t, 'decide') for t in self.transforms):
             return False
         state = (torch.random.get_rng_state(), np.random.get_state(), random.getstate(), self.seed)
@@ -207,13 +212,17 @@ class ComposeState:
                 self.seed = state[3]
                 return False
         processor.__dict__['_epilogue'] = (pending.hflip, pending.vflip, pending.k)
-        self._armed = True
+        self._armed = processor
         return True
 
     def __call__(self, x, retain_state=False, mask_transform=False):
-        if getattr(self, '_armed', False) and not mask_transform:
-            self._armed = False             # the processor's epilogue already applied this call's moves
-            return x
+        armed = getattr(self, '_armed', None)
+        if armed is not None and not mask_transform:
+            self._armed = None
+            # consumed: the processor's epilogue already applied this call's moves.  Still there (the processor raised
+            # before its pop, or was never called): the draws are made, apply them here so that image and mask agree
+            left = armed.__dict__.pop('_epilogue', None)
+            return x if left is None else flip_rot(x, *left)
         self._enter(retain_state)
         transforms = self.transforms if not mask_transform else self.mask_transforms
         pending = _Pending()

@@ -165,10 +165,33 @@ class CommTimer:
         return {k: {'calls': n, 'avg_us': round(t / n, 1)} for k, (n, t) in acc.items()}
 
 
+_HOST_STAGED = {}      # process group -> does its backend for DEVICE tensors move host memory only (gloo)?
+
+
 def _host_staged(group, t):
     """gloo moves host memory: device tensors of a gloo group (several ranks sharing one GPU -- the functional
-    multi-rank check on a one-GPU box) cross through a host copy.  RCCL ("nccl") takes device pointers as they are."""
-    return t.is_cuda and 'gloo' in str(dist.get_backend(group))
+    multi-rank check on a one-GPU box) cross through a host copy.  RCCL ("nccl") takes device pointers as they are.
+    The backend that serves the tensor's DEVICE decides ("cpu:gloo,cuda:nccl" groups hand device tensors to RCCL)."""
+    if not t.is_cuda:
+        return False
+    key = id(group) if group is not None else None
+    staged = _HOST_STAGED.get(key)
+    if staged is None:
+        name = str(dist.get_backend(group))
+        if ',' in name or ':' in name:                   # "cpu:gloo,cuda:nccl": the entry of the cuda device type
+            per = dict(part.split(':', 1) for part in name.split(',') if ':' in part)
+            name = per.get('cuda', name)
+        staged = _HOST_STAGED[key] = (name.strip().lower() == 'gloo')
+    return staged
+
+
+def split_single_rank(group):
+    """test hook (R2L_SPLIT_SINGLE_RANK=1): let a group of ONE rank take the N > 1 code path -- both step calls split
+    around real all-gathers, the gradient all-reduce issued -- so that a one-GPU box runs (and captures into a HIP
+    graph) the RCCL collectives of the multi-GPU step.  Off unless set; has no effect without an initialised group."""
+    import os
+    return group is not None and dist.is_available() and dist.is_initialized() and \
+        os.environ.get('R2L_SPLIT_SINGLE_RANK') == '1'
 
 
 def gather_ranks(vec, group=None, what='gather'):
@@ -176,7 +199,7 @@ def gather_ranks(vec, group=None, what='gather'):
     RCCL/xGMI.  The kernels that consume it add the rows in rank order, so every rank computes bit-identical
     results, equal to the single-GPU result for the global batch."""
     n = _group_size(group)
-    if n == 1:
+    if n == 1 and not split_single_rank(group):
         return vec, 1
     tok = CommTimer.begin(what, vec)
     if _host_staged(group, vec):
@@ -206,7 +229,7 @@ class GradAllReduce:
         self.n = _group_size(group)
         self.work = self.flat = self.host = None
         self.average = average
-        if self.n == 1 or not self.params:
+        if (self.n == 1 and not split_single_rank(group)) or not self.params:
             return
         self.tok = CommTimer.begin('grad all-reduce', self.params[0].grad)
         self.flat = torch.cat([p.grad.reshape(-1) for p in self.params])
@@ -356,7 +379,8 @@ class _IspFused(torch.autograd.Function):
                                            bn_mode, ptr(rm), ptr(rv), ptr(nbt), float(eps), mom, ptr(out), ptr(ws),
                                            nws, B, H, W, nranks, phase | keep | epi, ptr(gathered), stream),
                       'r2l_isp_step_fwd')
-        if nranks == 1:
+        split = nranks > 1 or (bn_mode == BN_TRAIN and split_single_rank(group))
+        if not split:
             call(_STEP_ALL, None)
         else:
             call(_STEP_A, None)
@@ -368,6 +392,7 @@ class _IspFused(torch.autograd.Function):
         ctx.keep = keep | epi
         ctx.group = group
         ctx.nranks = nranks
+        ctx.split = split
         ctx.denom = denom
         ctx.off_sums = off_sums
         ctx.has_additive = additive is not None
@@ -398,7 +423,7 @@ class _IspFused(torch.autograd.Function):
                                            ptr(out), ptr(gp), ptr(gadd), ctx.bn_mode, ptr(ws), nws, B, H, W,
                                            ctx.nranks, phase | ctx.keep, ptr(gathered), stream), 'r2l_isp_step_bwd')
         if need_p or need_a:
-            if ctx.nranks == 1:
+            if not ctx.split:
                 call(_STEP_ALL, None)
             else:
                 call(_STEP_A, None)

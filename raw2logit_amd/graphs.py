@@ -15,25 +15,42 @@ and backward as two graphs around static-buffer copies, is SLOWER than eager on 
     g = StepGraph(processor, raw, None, loss=lambda rgb: criterion(head(rgb), target), loss_modules=(head,))
 
 The processor must not have run on another stream before (its AccumulateGrad nodes are created by the warm-up here, on
-the capture's side stream); single-GPU or eval-mode / static processors only: a train-mode BatchNorm exchange between
-ranks splits the step's calls on the host (functional.py).
+the capture's side stream).
+
+Several ranks (`process_group`): the two small all-gathers that split the step's calls under train-mode BatchNorm and the
+flat all-reduce of the parameter gradients are issued on the capture stream and become nodes of the graph -- RCCL
+collectives (backend "nccl") are capturable; a gloo group moves host memory and is refused.  One replay is then the whole
+data-parallel step of the processor: statistics of the GLOBAL batch, gradients summed (or averaged) over the ranks.
 """
 import torch
 
 
 class StepGraph:
-    def __init__(self, model, raw, cotangent, loss=None, loss_modules=(), warmup=3):
+    def __init__(self, model, raw, cotangent, loss=None, loss_modules=(), warmup=3, process_group=None,
+                 average_grads=False):
         """loss: optional callable out -> scalar (then `cotangent` is ignored and loss(out).backward() is captured);
         loss_modules: the modules `loss` runs (a classifier head ...): their parameters' gradients belong to the graph
-        too -- like the processor's they are written by every replay into tensors the capture allocated, so do not set
-        them to None afterwards (zero_grad(set_to_none=False) or nothing at all: a replay overwrites them)"""
+        too -- like the processor's they are written by every replay into tensors the capture allocated; replay()
+        re-attaches those tensors to `p.grad`, so optimizer.zero_grad(set_to_none=True) between replays is harmless.
+        process_group: data-parallel ranks (one process per GPU over RCCL): sets `model.process_group` and captures the
+        gradient all-reduce of the processor's parameters behind the backward (average_grads: divide by the ranks)."""
+        from . import functional as F_
         self.model, self.raw, self.cotangent = model, raw, cotangent
         self.params = [p for m in (model,) + tuple(loss_modules) for p in m.parameters() if p.requires_grad]
+        self._isp_params = [p for p in model.parameters() if p.requires_grad]
         self._loss = loss
+        self._group, self._average = process_group, average_grads
+        self._collectives = False
+        if process_group is not None:
+            if F_._host_staged(process_group, raw):
+                raise RuntimeError('StepGraph: a gloo group moves its vectors through host memory, which a HIP graph cannot '
+                                   'capture -- use the eager step with gloo, or an RCCL ("nccl") group')
+            model.process_group = process_group
+            self._collectives = F_._group_size(process_group) > 1 or F_.split_single_rank(process_group)
         side = torch.cuda.Stream(device=raw.device)
         side.wait_stream(torch.cuda.current_stream(raw.device))
-        with torch.cuda.stream(side):                     # warm-up off the default stream (allocator, autograd nodes)
-            for _ in range(warmup):
+        with torch.cuda.stream(side):                     # warm-up off the default stream (allocator, autograd nodes,
+            for _ in range(warmup):                       # and the communicator's own first-call set-up)
                 self._step()
         torch.cuda.current_stream(raw.device).wait_stream(side)
         torch.cuda.synchronize(raw.device)
@@ -42,6 +59,7 @@ class StepGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._step()
+        self._grads = [p.grad for p in self.params]       # tensors of the graph's pool: every replay writes them
 
     def _step(self):
         out = self.model(self.raw)
@@ -49,9 +67,18 @@ class StepGraph:
             self._loss(out).backward()
         else:
             out.backward(self.cotangent)
+        if self._collectives:
+            # the data-parallel sum of the processor's 132-float gradient: one flat all-reduce on this stream
+            from .functional import GradAllReduce
+            GradAllReduce(self._isp_params, self._group, average=self._average).wait()
         return out
 
     def replay(self):
-        """one hipGraphLaunch: gradients are OVERWRITTEN (the captured step starts from grad = None), not accumulated"""
+        """one hipGraphLaunch: gradients are OVERWRITTEN (the captured step starts from grad = None), not accumulated.
+        `p.grad` is pointed back at the captured tensors first: a zero_grad(set_to_none=True) since the last replay
+        would otherwise leave the optimiser without gradients while the graph keeps writing the old ones."""
+        for p, g in zip(self.params, self._grads):
+            if p.grad is not g:
+                p.grad = g
         self.graph.replay()
         return self.out

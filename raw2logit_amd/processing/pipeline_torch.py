@@ -79,9 +79,9 @@ class RawToRGB(nn.Module):
 
 
 class NNProcessing(nn.Module):
-    """reference :83-126.  Only the raw2rgb front end is on this library's hot path; the U-Net++ body
-    is the third-party segmentation_models_pytorch model the reference uses (SURVEY.md section 8a, a12:
-    out of scope) and must be installed for this class to be constructed."""
+    """reference :83-126 (mode `neural_network`).  Only its `raw2rgb` front end is on this library's hot path
+    (SURVEY.md section 8a, a12); the body is segmentation_models_pytorch's UnetPlusPlus, a third-party model that is
+    out of scope and absent from the image, so constructing this class without it raises."""
 
     raw_bits = 16
 
@@ -91,38 +91,27 @@ class NNProcessing(nn.Module):
             import segmentation_models_pytorch as smp
         except ImportError as e:  # pragma: no cover - smp is absent from the build image
             raise ImportError('NNProcessing needs segmentation_models_pytorch (reference :11, :97)') from e
-        self.stages = None
-        self.buffer = None
-        self.track_stages = track_stages
-        self.model = smp.UnetPlusPlus(
-            encoder_name='resnet34',
-            encoder_depth=3,
-            decoder_channels=[256, 128, 64],
-            in_channels=3,
-            classes=3,
-        )
-        self.batch_norm = None if not batch_norm_output else nn.BatchNorm2d(3, affine=False)
+        self.stages, self.buffer, self.track_stages = None, None, track_stages
         self.normalize_mosaic = normalize_mosaic
+        self.model = smp.UnetPlusPlus(encoder_name='resnet34', encoder_depth=3, decoder_channels=[256, 128, 64],
+                                      in_channels=3, classes=3)          # reference :97-103
+        self.batch_norm = nn.BatchNorm2d(3, affine=False) if batch_norm_output else None
+
+    def front_end(self, raw):
+        """the part of forward() this library serves: packed 3-channel mosaic (+ normalize_mosaic), reference :111-114"""
+        rgb = F_.raw2rgb_bits(raw, bits=self.raw_bits)
+        return self.normalize_mosaic(rgb) if self.normalize_mosaic else rgb
 
     def forward(self, raw):
-        self.stages = {}
-        self.buffer = {}
-
-        rgb = F_.raw2rgb_bits(raw, bits=self.raw_bits)
-        if self.normalize_mosaic:
-            rgb = self.normalize_mosaic(rgb)
-        self.stages['demosaic'] = rgb
-        rgb = self.model(rgb)
+        self.stages = {'demosaic': self.front_end(raw)}
+        rgb = self.model(self.stages['demosaic'])
         if self.batch_norm is not None:
             rgb = self.batch_norm(rgb)
         self.stages['rgb'] = rgb
-
         if self.track_stages and raw.requires_grad:
             for stage in self.stages.values():
                 stage.retain_grad()
-
-        self.buffer['processed_rgb'] = rgb
-
+        self.buffer = {'processed_rgb': rgb}
         return rgb
 
 
@@ -225,9 +214,12 @@ class ParametrizedProcessing(nn.Module):
     RCCL so that every rank normalises with the statistics of the GLOBAL batch, which is what the
     single-GPU reference computes for that batch.  ``raw_bits`` -- frames given as
     uint16 / int16 tensors (the sensor's 16-bit containers) are divided by 2**raw_bits - 1 inside the kernels,
-    bit-identically to the host-side normalisation of the reference's datasets (dataset.py:86-87)."""
+    bit-identically to the host-side normalisation of the reference's datasets (dataset.py:86-87).
+    ``supports_output_epilogue`` -- this class pops the one-shot `_epilogue` an augmentation armed (ComposeState.arm)
+    in its forward; processors without the attribute are never armed."""
 
     raw_bits = 16
+    supports_output_epilogue = True
 
     def __init__(self, camera_parameters=None, track_stages=False, batch_norm_output=True):
         super().__init__()

@@ -84,7 +84,58 @@ def run_case(case, dev, lo, hi, group):
     out = {'y': y.detach().cpu().numpy(), 'g': flat, 'g_local': local,
            'rm': m.batch_norm.running_mean.cpu().numpy(), 'rv': m.batch_norm.running_var.cpu().numpy(),
            'nbt': np.asarray(int(m.batch_norm.num_batches_tracked)), 'y2_equal': np.asarray(bool(torch.equal(y2, y)))}
+    if os.environ.get('R2L_TEST_GRAPH') == '1' and path == 'fused':
+        out.update(graph_step(case, dev, raw, cot, group, y, flat))
     return out
+
+
+def graph_step(case, dev, raw, cot, group, y_eager, g_eager):
+    """the same step -- both calls split around their all-gathers, the gradient all-reduce behind the backward -- captured
+    into ONE HIP graph with its RCCL collectives (raw2logit_amd/graphs.py: StepGraph(process_group=...)): output and
+    all-reduced gradient of a replay against the eager step's, the collectives the eager step issued, and both timings"""
+    import time
+    import torch
+    from raw2logit_amd import functional as F_
+    from raw2logit_amd.graphs import StepGraph
+    name, shape, frames, path, camera = case
+    me = make_module(path, camera, dev)
+    me.process_group = group
+    pe = list(me.parameters())
+
+    def eager():
+        for p in pe:
+            p.grad = None
+        me(raw).backward(cot)
+        F_.GradAllReduce(pe, group).wait()
+    F_.CommTimer.enable(True)
+    eager()
+    torch.cuda.synchronize()
+    comm = F_.CommTimer.report()
+    F_.CommTimer.enable(False)
+    mg = make_module(path, camera, dev)
+    sg = StepGraph(mg, raw, cot, process_group=group)
+    sg.replay()
+    for p in mg.parameters():
+        p.grad = None                       # (what optimizer.zero_grad() does: the next replay re-attaches the tensors)
+    yg = sg.replay()
+    gg = torch.cat([p.grad.reshape(-1) for p in mg.parameters()]).cpu().numpy()
+    res = {'graph_y_equal': np.asarray(bool(np.array_equal(yg.detach().cpu().numpy(), y_eager.detach().cpu().numpy()))),
+           'graph_g_equal': np.asarray(bool(np.array_equal(gg, g_eager))),
+           'graph_g_maxdiff': np.asarray(float(np.abs(gg - g_eager).max())),
+           'comm_names': np.asarray(sorted(comm)), 'comm_calls': np.asarray([comm[k]['calls'] for k in sorted(comm)]),
+           'comm_us': np.asarray([comm[k]['avg_us'] for k in sorted(comm)])}
+    import torch.distributed as dist
+    for tag, fn in (('eager', eager), ('graph', sg.replay)):
+        for _ in range(10):
+            fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        res[f'ms_{tag}'] = np.asarray(1e3 * (time.perf_counter() - t0) / 50)
+    return res
 
 
 def main():

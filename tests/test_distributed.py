@@ -82,3 +82,54 @@ def test_two_rank_shard_equals_single_process(emulation, tmp_path):
     for k in range(world):
         np.testing.assert_allclose(r[k]['rm'], m.batch_norm.running_mean.numpy(), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(r[k]['rv'], m.batch_norm.running_var.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def _single_rank_worker(rank, world, port, emul_path, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['R2L_SPLIT_SINGLE_RANK'] = '1'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import emul_hook
+    emul_hook.enable(emul_path)
+    from oracle import isp_oracle as orc
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+    from raw2logit_amd import functional as F_
+    B, H, W = 3, 24, 40
+    raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=3, kind='scene'))
+    cot = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 3, H, W)).astype(np.float32))
+    m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).train()
+    m.process_group = dist.group.WORLD
+    F_.CommTimer.enable(True)
+    y = m(raw)
+    (y * cot).sum().backward()
+    F_.GradAllReduce(m.parameters(), dist.group.WORLD).wait()
+    comm = F_.CommTimer.report()
+    np.savez(os.path.join(out_dir, 'single.npz'), y=y.detach().numpy(),
+             g=torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy(), comm=np.asarray(sorted(comm)),
+             rm=m.batch_norm.running_mean.numpy(), rv=m.batch_norm.running_var.numpy())
+    dist.destroy_process_group()
+
+
+def test_single_rank_takes_the_split_path_when_asked(emulation, tmp_path):
+    """R2L_SPLIT_SINGLE_RANK=1 (functional.split_single_rank): a world of ONE rank runs the N > 1 code -- phase A / B calls
+    around real all-gathers of one row, r2l_bn_finalize / r2l_bn_bwd_means as launches, the gradient all-reduce -- which
+    is how tests/test_gpu_multirank.py runs (and graph-captures) the RCCL collectives on a one-GPU box."""
+    from oracle import isp_oracle as orc
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+    import conftest
+    mp.spawn(_single_rank_worker, args=(1, _free_port(), conftest.EMUL_LIB, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(os.path.join(str(tmp_path), 'single.npz'))
+    assert list(r['comm']) == ['bn statistics all-gather', 'bn-bwd sums all-gather', 'grad all-reduce']
+    B, H, W = 3, 24, 40
+    raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=3, kind='scene'))
+    cot = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 3, H, W)).astype(np.float32))
+    m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).train()
+    y = m(raw)
+    (y * cot).sum().backward()
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()
+    assert np.abs(r['y'] - y.detach().numpy()).max() < 2e-5
+    assert np.abs(r['g'] - g).max() <= 2e-4 * (np.abs(g).max() + 1e-6)
+    np.testing.assert_allclose(r['rm'], m.batch_norm.running_mean.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r['rv'], m.batch_norm.running_var.numpy(), rtol=1e-5, atol=1e-7)

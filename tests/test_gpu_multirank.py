@@ -40,8 +40,8 @@ def _free_port():
     return p
 
 
-def _spawn(world, out_dir, backend, cases=None, timeout=900):
-    env = dict(os.environ, R2L_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
+def _spawn(world, out_dir, backend, cases=None, timeout=900, extra_env=None):
+    env = dict(os.environ, R2L_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', **(extra_env or {}))
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
     if cases:
@@ -168,6 +168,51 @@ def test_two_rccl_ranks_one_per_gpu(dev, tmp_path):
         pytest.skip('needs two GPUs')
     ranks = _spawn(2, str(tmp_path), 'nccl')
     _check(ranks, dev, 'rccl x2')
+
+
+GRAPH_CASES = ('w1_f32', 'w2_u16', 'tiles_bands_f32', 'config5_shard')
+
+
+def _check_graph(ranks, tag):
+    import json
+    rec = {}
+    for name in GRAPH_CASES:
+        for r, res in enumerate(ranks):
+            assert bool(res[f'{name}/graph_y_equal']), (name, r, 'replayed output differs from the eager step')
+            assert bool(res[f'{name}/graph_g_equal']), (name, r, float(res[f'{name}/graph_g_maxdiff']))
+            names = [str(x) for x in res[f'{name}/comm_names']]
+            assert names == ['bn statistics all-gather', 'bn-bwd sums all-gather', 'grad all-reduce'], names
+            assert all(int(c) == 1 for c in res[f'{name}/comm_calls'])
+        rec[name] = {'ms_per_step_eager': round(float(max(r[f'{name}/ms_eager'] for r in ranks)), 4),
+                     'ms_per_step_graph': round(float(max(r[f'{name}/ms_graph'] for r in ranks)), 4),
+                     'comm_us_eager': dict(zip([str(x) for x in ranks[0][f'{name}/comm_names']],
+                                               [float(x) for x in ranks[0][f'{name}/comm_us']]))}
+        pc.report(f'multirank[{tag}]/{name}: step graph with its collectives vs eager (bits differing)', 0.0, 0.0)
+    out_dir = os.path.join(REPO, 'gpurun_out')
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f'step_graph_{tag.replace(" ", "_")}.json'), 'w') as f:
+            json.dump({'what': 'the data-parallel step (phase A / B calls around two RCCL all-gathers + the gradient '
+                               'all-reduce) eager and as ONE HIP graph; per-rank batch = global batch / ranks',
+                       'ranks': len(ranks), 'cases': rec}, f, indent=1)
+
+
+def test_step_graph_captures_the_rccl_collectives_on_one_gpu(dev, tmp_path):
+    """StepGraph(process_group=...) on the one-GPU box: a world of ONE rank over RCCL with R2L_SPLIT_SINGLE_RANK=1 takes the
+    N > 1 code path -- both step calls split in phases A / B around real RCCL all-gathers (of one row), r2l_bn_finalize /
+    r2l_bn_bwd_means as their own launches, the flat gradient all-reduce -- eagerly and captured into one HIP graph:
+    replays are bit-identical to the eager step, which equals the plain single-process step to round-off (_check)."""
+    ranks = _spawn(1, str(tmp_path), 'nccl', cases=GRAPH_CASES,
+                   extra_env={'R2L_SPLIT_SINGLE_RANK': '1', 'R2L_TEST_GRAPH': '1'})
+    _check(ranks, dev, 'rccl x1 (split path forced)')
+    _check_graph(ranks, 'rccl x1')
+
+
+def test_step_graph_two_rccl_ranks(dev, tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    ranks = _spawn(2, str(tmp_path), 'nccl', cases=GRAPH_CASES, extra_env={'R2L_TEST_GRAPH': '1'})
+    _check(ranks, dev, 'rccl x2 (graph cases)')
+    _check_graph(ranks, 'rccl x2')
 
 
 def test_bench_two_gloo_ranks_on_the_device(dev):

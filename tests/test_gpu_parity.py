@@ -48,6 +48,115 @@ def test_frame_shapes_around_tile_boundaries(dev):
     pc.check_frame_shapes(dev)
 
 
+# ---- the plane-pass backward (r2l_param_plane_bwd.h: bwd1_plane, bwd1_blur_hp | bwd1_blur + bwd2_hp, bwd2_sums) -- the
+# kernels behind the headline number -- DIRECTLY against the float64 oracle, the reference's golden float32 gradients and
+# its own float64 run (grad64).  The shipped library takes them at B*H*W >= 6 Mi px only, so the small cases run on the
+# diagnostic build with R2L_BWD_PLANES=1 (same source); test_plane_backward_at_the_dispatch_threshold runs the shipped one.
+PLANE_MODES = {'fused-middle-pass': {'R2L_BWD_PLANES': '1'},
+               'split-blur': {'R2L_BWD_PLANES': '1', 'R2L_BWD_SPLIT_BLUR': '1'}}
+PLANE_PARAM_CASES = [c for c in PARAM_CASES if not c['additive'] and c['shape'][2] % 4 == 0]
+PLANE_KERNELS = {'fused-middle-pass': ('r2l_launch_bwd1_plane_kernel', 'r2l_launch_bwd1_blur_hp_kernel',
+                                       'r2l_launch_bwd2_sums_kernel'),
+                 'split-blur': ('r2l_launch_bwd1_plane_kernel', 'r2l_launch_bwd1_blur_kernel', 'r2l_launch_bwd2_hp_kernel',
+                                'r2l_launch_bwd2_sums_kernel')}
+
+
+@pytest.mark.parametrize('mode', list(PLANE_MODES))
+@pytest.mark.parametrize('case', PLANE_PARAM_CASES, ids=[c['name'] for c in PLANE_PARAM_CASES])
+def test_plane_backward_golden_cases(case, mode, golden, dev):
+    """check_param_case (float64 oracle, golden float32 gradients, grad64 pin) with the backward as passes over planes;
+    the launch record proves which kernels produced the gradients.  Reference: pipeline_torch.py:187-217 under autograd."""
+    from raw2logit_amd import _lib
+    with pc.env_overrides(dev, PLANE_MODES[mode]):
+        lib = _lib.device_library()
+        _, names = pc.kernels_launched(lib, lambda: pc.check_param_case(case, golden, dev))
+    for k in PLANE_KERNELS[mode]:
+        assert names.get(k, 0) >= 1, (mode, k, sorted(names))
+    assert not any('bwd1_saved' in n or n.startswith('r2l_launch_bwd2_kernel') for n in names), sorted(names)
+
+
+@pytest.mark.parametrize('mode', list(PLANE_MODES))
+def test_plane_backward_frame_shapes(mode, dev):
+    """check_frame_shapes (every gradient within 3e-5 of its scale of the float64 oracle on well-conditioned frames) on the
+    plane passes: image edges at every distance from a strip / band boundary, 4- and 6-row frames (every row a border row of
+    the blur and of its adjoint), several strips, partially filled last strip."""
+    from raw2logit_amd import _lib
+    with pc.env_overrides(dev, PLANE_MODES[mode]):
+        lib = _lib.device_library()
+        worst, names = pc.kernels_launched(lib, lambda: pc.check_frame_shapes(dev, shapes=pc.FRAME_SHAPES_PLANES, conditioning=True))
+    for k in PLANE_KERNELS[mode]:
+        assert names.get(k, 0) >= len(pc.FRAME_SHAPES_PLANES), (mode, k, names)
+    assert not any('bwd1_saved' in n or n.startswith('r2l_launch_bwd2_kernel') for n in names), sorted(names)
+    pc.report(f'plane-backward/{mode}/frame shapes: worst gradient error (fraction of its limit)', worst, 1.0)
+    # ... and at other band heights / one wavefront taking everything
+    for env in ({'R2L_BP_BAND': '6', 'R2L_HB_BAND': '12', 'R2L_B2S_BAND': '6', 'R2L_HP_BAND': '6'},
+                {'R2L_BP_BAND': '1000', 'R2L_HB_BAND': '1000', 'R2L_B2S_BAND': '1000', 'R2L_HP_BAND': '1000',
+                 'R2L_GRID_BWD1': '1', 'R2L_GRID_BWD2': '1'}):
+        with pc.env_overrides(dev, dict(PLANE_MODES[mode], **env)):
+            w2 = pc.check_frame_shapes(dev, shapes=pc.FRAME_SHAPES_PLANES[:6], conditioning=True)
+        pc.report(f'plane-backward/{mode}/{sorted(env.items())[0]}: worst gradient error (fraction of its limit)', w2, 1.0)
+
+
+def test_plane_backward_at_the_dispatch_threshold(dev):
+    """The SHIPPED library at its own dispatch threshold: 24 x 512 x 512 = 6 Mi px is the smallest batch whose backward
+    runs as plane passes (r2l_api_impl.h: `planes`).  BatchNorm in eval mode decouples the frames, the cotangent is zero
+    except on frames 0 and 23 (the first and the last band items of the launch), so all 132 gradients equal the float64
+    oracle's on those two frames: DEFAULT_GRAD_RTOL of the gradient's scale + the clip-flip allowance.  Also without
+    BatchNorm and from 16-bit containers (bit-identical).  Reference: pipeline_torch.py:187-217 under autograd."""
+    from raw2logit_amd import _lib
+    B, H, W = 24, 512, 512
+    lib = _lib.device_library()
+    assert lib.path == _lib.LIB_PATH
+    u = np.rint(orc.synth_raw(B, H, W, seed=4, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
+    raw_np = u.astype(np.float32) / np.float32(4095)
+    P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
+    P.perturb(23)
+    sel = [0, B - 1]
+    cot_np = np.zeros((B, 3, H, W), np.float32)
+    cot_np[sel] = np.random.default_rng(5).standard_normal((2, 3, H, W)).astype(np.float32)
+    cot = torch.from_numpy(cot_np).to(dev)
+    P64 = P.astype(np.float64)
+    for bn in (True, False):
+        case = dict(camera='drone', track=False, additive=False, training=False, bn=bn)
+        grads = {}
+        for frames in ('f32', 'u16'):
+            m = pc.make_module(case, P, dev)
+            if frames == 'u16':
+                m.raw_bits = 12
+            raw = torch.from_numpy(u if frames == 'u16' else raw_np).to(dev)
+
+            def step():
+                y = m(raw)
+                y.backward(cot)
+                return y.detach()
+            y, names = pc.kernels_launched(lib, step)
+            for k in PLANE_KERNELS['fused-middle-pass']:
+                k16 = k.replace('_kernel', '_u16_kernel')
+                assert names.get(k, 0) + names.get(k16, 0) == 1, (k, sorted(names))
+            grads[frames] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
+            if frames == 'f32':
+                y_sel = y[sel].cpu().numpy()
+        for n in grads['f32']:
+            assert np.array_equal(grads['f32'][n], grads['u16'][n]), (bn, n, '16-bit containers')
+        o, _, c = orc.parametrized_forward(raw_np[sel], P64, bn=pc.oracle_bn(case))
+        tol = pc.out_tolerance(c, bn)
+        err = np.abs(y_sel - o)
+        w = np.unravel_index((err / tol).argmax(), err.shape)
+        pc.report(f'threshold-24x512x512/bn={bn}/out (frames 0, 23) vs float64 oracle', err[w], tol[w])
+        assert np.all(err <= tol), (bn, err.max())
+        og, _, _ = orc.parametrized_backward(P64, c, cot_np[sel])
+        lo, _, _ = orc.parametrized_backward(P64, c, cot_np[sel], clip_shift=1e-6)
+        hi, _, _ = orc.parametrized_backward(P64, c, cot_np[sel], clip_shift=-1e-6)
+        for k, ref in og.items():
+            ref = np.asarray(ref)
+            got = grads['f32'][k].reshape(ref.shape)
+            flip = max(np.abs(np.asarray(lo[k]) - ref).max(), np.abs(np.asarray(hi[k]) - ref).max())
+            lim = pc.DEFAULT_GRAD_RTOL * (np.abs(ref).max() + 1e-6) + flip
+            e = np.abs(got - ref).max()
+            pc.report(f'threshold-24x512x512/bn={bn}/grad {k} vs float64 oracle (plane passes, shipped library)', e, lim)
+            assert e <= lim, (bn, k, e, lim)
+
+
 def test_cpu_tensor_is_refused(dev):
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     from raw2logit_amd import _lib
