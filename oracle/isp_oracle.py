@@ -236,6 +236,11 @@ def _pad_vjp(gp, p, mode):
     return g
 
 
+# test aid: accumulate the taps of conv2d in reverse order -- the same sums, rounded differently in float32 (a second,
+# independent float32 evaluation of the reference's formulas: the control sample of tests/fuzz_gpu.py)
+REVERSE_TAP_ORDER = False
+
+
 def conv2d(x, w, pad_mode):
     """cross-correlation like nn.Conv2d(bias=False): x (B,Ci,H,W), w (Co,Ci,K,K), 'same' size."""
     K = w.shape[-1]
@@ -243,8 +248,9 @@ def conv2d(x, w, pad_mode):
     xp = _pad(x, p, pad_mode)
     B, Ci, H, W = x.shape
     out = np.zeros((B, w.shape[0], H, W), dtype=x.dtype)
-    for i in range(K):
-        for j in range(K):
+    taps = range(K - 1, -1, -1) if REVERSE_TAP_ORDER else range(K)
+    for i in taps:
+        for j in taps:
             patch = xp[:, :, i:i + H, j:j + W]                       # (B,Ci,H,W)
             out += np.einsum('bchw,kc->bkhw', patch, w[:, :, i, j])
     return out

@@ -185,7 +185,9 @@ R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc
                                 r2l_log2(fminf(fmaxf(rgb[1], 1e-5f), 1.0f)));
       const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));                    // :209
       x[p] = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
-      if (STATS == 1 && a.stat_partial && store_ok) {
+      // (every lane accumulates: a lane past the frame's last column walks valid pixels of the clamped strip and its sums
+      // are dropped as a whole in r2l_fs_lane_sums -- a per-step `store_ok` here costs 24 v_cndmask per row step)
+      if (STATS == 1 && a.stat_partial) {
         if (p == 0) piv[k] = (y == y0) ? x[0][0] : piv[k];
         const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-piv[k]));
         acc[k] = r2l_padd(acc[k], d);
@@ -393,8 +395,8 @@ R2L_HD void r2l_fs_lane_sums(const r2l_p2* acc, const float* piv, double npx, bo
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
     // from the lane's pivot p to the common pivot 0.5:  x - .5 = (x - p) + dp
-    const double s1 = (double)acc[k][0] + (double)acc[k][1];
-    const double s2 = (double)acc[3 + k][0] + (double)acc[3 + k][1];
+    const double s1 = ok ? (double)acc[k][0] + (double)acc[k][1] : 0.0;
+    const double s2 = ok ? (double)acc[3 + k][0] + (double)acc[3 + k][1] : 0.0;
     const double dp = ok ? (double)piv[k] - 0.5 : 0.0;
     double v1 = fma(npx, dp, s1), v2 = fma(dp, fma(npx, dp, 2.0 * s1), s2);
     R2L_PRAGMA_UNROLL

@@ -16,7 +16,7 @@ budget = float(os.environ.get('SECONDS', '90'))
 t0 = time.time()
 n = 0
 worst = {'out': 0.0, 'grad': 0.0}
-marginal = []      # limits are heuristics (conditioning): a real defect shows up as a ratio >> 1
+failures = []      # (FUZZ_KEEP_GOING=1: collect instead of stopping at the first one -- calibration runs)
 while time.time() - t0 < budget:
     B = int(rng.integers(1, 4))
     H = 2 * int(rng.integers(2, 90))
@@ -70,39 +70,63 @@ while time.time() - t0 < budget:
     Pm = P.astype(np.float64)
     o, _, cache = orc.parametrized_forward(raw_np, Pm, bn=obn)
     g, _, _ = orc.parametrized_backward(Pm, cache, cot)
-    glo, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=1e-5)
-    ghi, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=-1e-5)
+    # torch.clip's gradient is a step: a pixel whose pre-clip value is within float32 round-off of a threshold may land on
+    # either side.  What that can move: the oracle's gradient with the pass band narrowed / widened by 1e-6 .. 1e-5 (the
+    # effect is not monotonic in the shift -- pixels of opposite sign join in -- so the largest of the three counts)
+    shifted = [orc.parametrized_backward(Pm, cache, cot, clip_shift=sgn * sh)[0]
+               for sh in (1e-6, 3e-6, 1e-5) for sgn in (1.0, -1.0)]
     # conditioning: the same oracle in float32 arithmetic (the reference's precision).  Near the lower clip
     # threshold d/dx x**(1/gamma) ~ 1e5, so float32 round-off of the linear part moves some gradients by percents
-    _, _, c32 = orc.parametrized_forward(raw_np, P, bn=obn)
+    o32, _, c32 = orc.parametrized_forward(raw_np, P, bn=obn)
     g32, _, _ = orc.parametrized_backward(P, c32, cot)
     tol = pc.out_tolerance(cache, bn != 'none')
     eo = np.abs(y.detach().cpu().numpy() - o)
-    r_out = float((eo / tol).max())
-    if r_out > (1.0 if kind == 'midtone' else 3.0):
-        marginal.append(('out', r_out / (1.0 if kind == 'midtone' else 3.0), (B, H, W, bn, kind, u16)))
+    # THE criterion (no marginal bands; parity_checks.sigma_limit): at every pixel |mine - oracle64| <= max(tol, 6 sigma32),
+    # sigma32 = the float32 oracle's own local error level pushed through the power law and BatchNorm.  Next to it the
+    # LITERAL per-pixel form  max(tol, 2 x |oracle32 - oracle64| over the 3x3 neighbourhood)  is evaluated for the kernels
+    # AND for a control: a second float32 evaluation of the oracle (taps accumulated in reverse order) -- how often
+    # float32 arithmetic itself leaves that 9-sample envelope
+    o32 = np.asarray(o32, dtype=np.float64)
+    orc.REVERSE_TAP_ORDER = True
+    try:
+        o32b = np.asarray(orc.parametrized_forward(raw_np, P, bn=(dict(obn, running_mean=np.array(obn['running_mean'], dtype=float),
+                                                                      running_var=np.array(obn['running_var'], dtype=float))
+                                                                  if obn else None))[0], dtype=np.float64)
+    finally:
+        orc.REVERSE_TAP_ORDER = False
+    lim_px = pc.sigma_limit(tol, P, cache, c32, bn != 'none')
+    lim_lit = pc.pixel_limit(tol, o32, o)
+    eb = np.abs(o32b - o)
+    r_out = float((eo / lim_px).max())
     worst['out'] = max(worst['out'], r_out)
-    if r_out > float(os.environ.get('REPORT_OUT', 'inf')):    # where, and how far the float32 ORACLE is from float64 there
-        i = np.unravel_index(int(np.argmax(eo / tol)), eo.shape)
-        o32 = np.asarray(c32['out'] if 'out' in c32 else orc.parametrized_forward(raw_np, P, bn=obn)[0], dtype=np.float64)
-        print('  out ratio %.2f at %s: got %.7g oracle64 %.7g oracle32 %.7g  pre-gamma %.4g  tol %.3g  |o32-o64| max over the frame / tol %.2f  %s'
+    worst['out_tol'] = max(worst.get('out_tol', 0.0), float((eo / tol).max()))
+    worst['ctrl'] = max(worst.get('ctrl', 0.0), float((eb / lim_px).max()))
+    lit, lit_c = float((eo / lim_lit).max()), float((eb / lim_lit).max())
+    worst['lit'] = max(worst.get('lit', 0.0), lit)
+    worst['lit_ctrl'] = max(worst.get('lit_ctrl', 0.0), lit_c)
+    worst['n_lit'] = worst.get('n_lit', 0) + (lit > 1.0)
+    worst['n_lit_ctrl'] = worst.get('n_lit_ctrl', 0) + (lit_c > 1.0)
+    if r_out > 1.0:
+        i = np.unravel_index(int(np.argmax(eo / lim_px)), eo.shape)
+        print('FAIL out: ratio %.2f at %s: got %.7g oracle64 %.7g oracle32 %.7g  pre-gamma %.4g  tol %.3g  limit %.3g  %s'
               % (r_out, i, float(y.detach().cpu().numpy()[i]), float(o[i]), float(o32[i]), float(cache['rgb'][i]), float(tol[i]),
-                 float((np.abs(o32 - o) / tol).max()), (B, H, W, bn, kind, u16, bool(additive))), flush=True)
+                 float(lim_px[i]), (B, H, W, bn, kind, u16, bool(additive))), flush=True)
+        if not os.environ.get('FUZZ_KEEP_GOING'):
+            raise SystemExit(1)
+        failures.append(('out', r_out, (B, H, W, bn, kind, u16)))
     for k in g:
         got = pc.NAME2ATTR[k](m).grad.detach().cpu().numpy().reshape(np.asarray(g[k]).shape)
-        flip = max(np.abs(np.asarray(glo[k]) - g[k]).max(), np.abs(np.asarray(ghi[k]) - g[k]).max())
+        flip = max(np.abs(np.asarray(gs[k]) - g[k]).max() for gs in shifted)
         e = np.abs(got - g[k]).max()
         cond = np.abs(np.asarray(g32[k], dtype=np.float64) - g[k]).max()
         if kind == 'midtone':
             lim = (3e-5 if bn == 'none' else 2e-4) * (np.abs(g[k]).max() + 1e-6) + 2 * flip + 2e-7 * np.sqrt(cot.size) + \
-                (1e-7 * cot.size if bn != 'none' else 0.0)
+                (1e-7 * cot.size if bn != 'none' else 0.0) + 2 * cond
             if bn == 'train' and H * W < 256:
                 continue
         else:
             lim = 5e-2 * (np.abs(g[k]).max() + 1e-6) + 2 * flip + 5 * cond   # ill-conditioned kinds: coarse net only
-        if lim < e <= 3 * lim:
-            marginal.append((k, float(e / lim), (B, H, W, bn, kind, u16)))
-        if e > 3 * lim:
+        if e > lim:
             for sh in (3e-6, 1e-5, 3e-5):
                 a1, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=sh)
                 a2, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=-sh)
@@ -110,16 +134,21 @@ while time.time() - t0 < budget:
             pre = cache['rgb']
             print('  pixels within 1e-5 of a clip threshold:', int(((np.abs(pre - 1.0) < 1e-5) | (np.abs(pre - 1e-5) < 1e-5)).sum()), 'of', pre.size,
                   ' camera', 'drone' if cam is orc.DRONE_CAMERA_PARAMS else ('micro' if cam is orc.MICROSCOPY_CAMERA_PARAMS else 'identity'))
-            print('FAIL', (B, H, W, bn, kind, u16, k, e, lim, float(np.abs(g[k]).max()), float(flip)))
+            print('FAIL grad', (B, H, W, bn, kind, u16, k, e, lim, float(np.abs(g[k]).max()), float(flip), float(cond)))
             np.set_printoptions(precision=4, suppress=True)
             print('got', got.ravel()); print('ref', np.asarray(g[k]).ravel())
-            raise SystemExit(1)
+            if not os.environ.get('FUZZ_KEEP_GOING'):
+                raise SystemExit(1)
+            failures.append((k, float(e / lim), (B, H, W, bn, kind, u16)))
         worst['grad'] = max(worst['grad'], float(e / lim))
     n += 1
-for mrg in marginal:
-    print('marginal (ratio to its limit %.2f):' % mrg[1], mrg[0], mrg[2])
-if any(mrg[1] > 3 for mrg in marginal):
-    print('FAIL: output error more than 3x over its limit')
+for f in failures:
+    print('over its limit (ratio %.2f):' % f[1], f[0], f[2])
+if failures:
     raise SystemExit(1)
-print(f'{n} random cases ok in {time.time() - t0:.0f} s; worst out error / tolerance {worst["out"]:.2f}, '
+print(f'{n} random cases ok in {time.time() - t0:.0f} s; worst out error / max(tolerance, 6 sigma of the float32 oracle) '
+      f'{worst["out"]:.2f} (control = a second float32 evaluation of the oracle: {worst["ctrl"]:.2f}); '
       f'worst grad error / limit {worst["grad"]:.2f}')
+print(f'   for information: worst out error / tolerance alone {worst["out_tol"]:.2f}; literal per-pixel form max(tolerance, 2 x '
+      f'|oracle32 - oracle64| over 3x3): kernels worst {worst["lit"]:.2f}, {worst["n_lit"]} of {n} cases over 1; control worst '
+      f'{worst["lit_ctrl"]:.2f}, {worst["n_lit_ctrl"]} of {n} cases over 1')

@@ -143,6 +143,91 @@ def out_tolerance(cache, has_bn, base=1e-5):
     return tol
 
 
+F32_UNIT_ROUNDOFF = 2.0 ** -24
+LINEAR_CHAIN_ROUNDINGS = 71      # debayer conv 27 + white balance 1 + CCM 3 + RGB->YUV 3 + sharpen 9 + blur 25 + YUV->RGB 3
+
+
+def rounding_bound(raw, P, cache, has_bn):
+    """A-PRIORI float32 rounding-error bound of the output, pixel by pixel (no fitted constant).
+
+    Everything in front of the clip (pipeline_torch.py:183-203) is a chain of dot products; evaluated in float32 in ANY
+    order each of them obeys the standard forward bound |fl(sum a_i b_i) - sum a_i b_i| <= n u sum |a_i b_i| (u = 2^-24,
+    n = the roundings on the path: 71 for the reference's unfolded chain, fewer for the folded kernels).  Pushing |v|
+    through the chain with the absolute values of every weight gives mag(p) = sum |terms| behind pre-gamma value p, hence
+    |delta pre-gamma| <= 71 u mag(p); the power law x^(1/gamma) is concave, so its slope at the lower end of
+    [x - delta, x + delta] (never below the clip floor 1e-5, where it is 241) bounds what that is worth after the gamma;
+    BatchNorm multiplies by 1/std.  A pixel further than delta outside the clip range comes out exact.  BASELINE's 1e-5 is
+    the floor.  Returns (limit on |out - float64 oracle|, delta)."""
+    f64 = np.float64
+    A = P.astype(f64)
+    mosaic = np.abs(orc.raw2rgb(np.asarray(raw, dtype=f64), A.black_level, reduce_size=False))
+    m = orc.conv2d(mosaic, np.abs(A.debayer), 'mirror') * np.abs(A.white_balance).reshape(1, 3, 1, 1)
+    m = orc._mix(orc._mix(m, np.abs(A.colour_correction)), np.abs(A.M_RGB_2_YUV))
+    y = orc.conv2d(orc.conv2d(m[:, :1], np.abs(A.sharpening), 'zero'), np.abs(A.blur), 'mirror')
+    mag = orc._mix(np.concatenate([y, m[:, 1:]], axis=1), np.abs(A.M_YUV_2_RGB))
+    delta = LINEAR_CHAIN_ROUNDINGS * F32_UNIT_ROUNDOFF * mag
+    x = np.asarray(cache['rgb'], dtype=f64)
+    inv_g = 1.0 / float(np.asarray(A.gamma_correct).reshape(-1)[0])
+    xlo = np.clip(x - delta, 1e-5, 1.0)
+    slope = inv_g * xlo ** (inv_g - 1.0)
+    slope = np.where((x < 1e-5 - delta) | (x > 1.0 + delta), 0.0, slope)
+    scale = np.maximum(1.0, np.asarray(cache['istd'], dtype=f64).reshape(1, 3, 1, 1)) if has_bn else 1.0
+    return np.maximum(1e-5, slope * delta) * scale, delta
+
+
+def pixel_limit(tol, o32, o64):
+    """per-pixel output limit of the randomised sweeps: the heuristic tolerance, or twice the distance
+    of the float32 ORACLE (the reference's own arithmetic) from the float64 one, whichever is larger -- the float32 distance
+    taken as its maximum over the pixel's 3x3 neighbourhood (one pixel's round-off is one sample of a distribution whose
+    width, not whose sample, is the conditioning)."""
+    from scipy.ndimage import maximum_filter
+    d32 = np.abs(np.asarray(o32, dtype=np.float64) - o64)
+    return np.maximum(tol, 2.0 * maximum_filter(d32, size=(1, 1, 3, 3), mode='nearest'))
+
+
+def sigma_limit(tol, P, cache64, cache32, has_bn, k=6.0, window=7):
+    """per-pixel output limit of the randomised sweeps, statistically sound form: the heuristic tolerance, or k = 6 standard
+    deviations of the float32 ORACLE's own error at that pixel, whichever is larger.  The float32 oracle's error in front
+    of the clip, d(p) = rgb32(p) - rgb64(p), is round-off of a chain of dot products: zero-mean, with a spread that follows
+    the local magnitudes and is therefore smooth in p; sigma(p) = its RMS over a window x window neighbourhood.  After the
+    power law (concave: the slope at the lower end of [x - k sigma, x + k sigma], never below the clip floor) and BatchNorm
+    that is worth slope(p) sigma(p) / std; a pixel more than k sigma outside the clip range comes out exact.  A float32
+    kernel that rounds like the reference stays inside 6 sigma at every one of the ~1e8 pixels a sweep visits (two-sided
+    Gaussian tail 2e-9); the largest |d| of one 3x3 neighbourhood (the literal form, pixel_limit) is a 9-sample statistic
+    and is exceeded by a SECOND float32 evaluation of the oracle itself about as often as by the kernels
+    (tests/fuzz_gpu.py prints both)."""
+    from scipy.ndimage import uniform_filter
+    f64 = np.float64
+    d = np.asarray(cache32['rgb'], dtype=f64) - np.asarray(cache64['rgb'], dtype=f64)
+    sigma = np.sqrt(np.maximum(uniform_filter(d * d, size=(1, 1, window, window), mode='nearest'), 0.0))
+    x = np.asarray(cache64['rgb'], dtype=f64)
+    inv_g = 1.0 / float(np.asarray(P.gamma_correct, dtype=f64).reshape(-1)[0])
+    xlo = np.clip(x - k * sigma, 1e-5, 1.0)
+    slope = inv_g * xlo ** (inv_g - 1.0)
+    slope = np.where((x < 1e-5 - k * sigma) | (x > 1.0 + k * sigma), 0.0, slope)
+    scale = np.maximum(1.0, np.asarray(cache64['istd'], dtype=f64).reshape(1, 3, 1, 1)) if has_bn else 1.0
+    return np.maximum(tol, k * slope * sigma * scale)
+
+
+def check_float32_distance(label, mine, o64, o32, well):
+    """band by band (pre-gamma above / below WELL_CONDITIONED): this library -- a float32 evaluation of the reference's
+    formulas in another order -- must be as close to the float64 result as the float32 oracle is: RMS distance at most twice
+    the oracle's (+ 2e-7), largest at most 6 x the oracle's largest (+ 1e-6); the criterion check_param_case applies to the
+    reference's own float32 / float64 runs."""
+    mine = np.asarray(mine, dtype=np.float64)
+    o32 = np.asarray(o32, dtype=np.float64)
+    for band, sel in (('pre-gamma > 3e-3', well), ('pre-gamma <= 3e-3', ~well)):
+        if sel.any():
+            d_ref, d_mine = (o32 - o64)[sel], (mine - o64)[sel]
+            r_ref, r_mine = np.sqrt(np.mean(d_ref ** 2)), np.sqrt(np.mean(d_mine ** 2))
+            report(f'{label} vs float64 oracle, rms ({band}); float32 oracle rms {r_ref:.2e}', r_mine, 2 * r_ref + 2e-7)
+            report(f'{label} vs float64 oracle, max ({band}); float32 oracle max {np.abs(d_ref).max():.2e}',
+                   np.abs(d_mine).max(), 6 * np.abs(d_ref).max() + 1e-6)
+            assert r_mine <= 2 * r_ref + 2e-7, (label, band, 'rms vs the float32 oracle', r_mine, r_ref)
+            assert np.abs(d_mine).max() <= 6 * np.abs(d_ref).max() + 1e-6, \
+                (label, band, 'max vs the float32 oracle', np.abs(d_mine).max(), np.abs(d_ref).max())
+
+
 def check_param_case(case, golden, device):
     """fused forward + backward of one PARAM_CASES entry vs the float64 oracle and the golden vectors."""
     g = golden['param_cases']

@@ -847,6 +847,10 @@ def test_fused_forward_streaming_kernel(shape, dev):
         w = np.unravel_index((err / tol).argmax(), err.shape)
         pc.report(f'fwd-stream/{shape}/bn={bn}/out vs float64 oracle', err[w], tol[w])
         assert np.all(err <= tol), (shape, bn, err.max(), np.unravel_index(err.argmax(), err.shape))
+        # ... and band by band at the distance the float32 oracle itself keeps from the float64 one (not only inside the
+        # hand-set LOW_BAND_TOL)
+        o32, _, _ = orc.parametrized_forward(raw_np, P.astype(np.float32), bn=pc.oracle_bn(dict(case, bn=bn)))
+        pc.check_float32_distance(f'fwd-stream/{shape}/bn={bn}/out', y.cpu().numpy(), o, o32, c['rgb'] > pc.WELL_CONDITIONED)
         os.environ['R2L_FWD_TILED'] = '1'
         try:
             with pc.launch_shape_overrides(dev), torch.no_grad():
