@@ -483,6 +483,36 @@ R2L_HD const R2LFolded* r2l_opaque_after(const R2LFolded* p, float dep) {
   return p;
 }
 
+// Issue priority by PROGRESS.  The wavefronts of a SIMD start together (the band passes are sized for one round of resident
+// wavefronts) and the hardware favours the oldest one whenever several are ready: left alone they finish one after the
+// other, and the last one walks its rows alone with every scalar-load and memory wait exposed (the plane kernels'
+// wavefronts end between 25 and 68 us after a common start, profiles/r03_z_timeline_fwd.txt).  A wavefront that is
+// further BEHIND in its band gets the higher priority -- quarter of the band done -> s_setprio 3, 2, 1, 0 -- so the
+// wavefronts of a SIMD advance together and overlap until the end: 64x512x512 step 0.3940 -> 0.3873 ms, the sums pass of
+// the backward 54.9 -> 52.5 us (profiles/r04_progress_prio.txt).  s_setprio takes an immediate: a scalar if-chain.
+// R2L_PROGRESS_PRIO = 0: off; 1: per group of 6 rows; 2: per row step.
+#ifndef R2L_PROGRESS_PRIO_MODE
+#define R2L_PROGRESS_PRIO_MODE 1
+#endif
+#if R2L_PROGRESS_PRIO_MODE && !defined(R2L_EMUL)
+R2L_HD void r2l_progress_prio(int done, int total) {
+  const int q4 = done * 4;
+  if (q4 < total) __builtin_amdgcn_s_setprio(3);
+  else if (q4 < 2 * total) __builtin_amdgcn_s_setprio(2);
+  else if (q4 < 3 * total) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+#define R2L_PROGRESS_PRIO(done, total) r2l_progress_prio((done), (total))
+#if R2L_PROGRESS_PRIO_MODE == 2
+#define R2L_PROGRESS_PRIO_STEP(done, total) r2l_progress_prio((done), (total))
+#else
+#define R2L_PROGRESS_PRIO_STEP(done, total)
+#endif
+#else
+#define R2L_PROGRESS_PRIO(done, total)
+#define R2L_PROGRESS_PRIO_STEP(done, total)
+#endif
+
 // A kernel's argument block, re-read from the kernarg segment at the point of use: arguments that only the end of a kernel
 // needs (reduction tree, BatchNorm bookkeeping: 32 scalar registers' worth) otherwise stay live through the whole main
 // loop, where scalar registers are what the streaming kernels run out of (SGPR spills into VGPR lanes: 44 -> 39 with this;

@@ -176,18 +176,20 @@ R2L_HD void r2l_bp_step(const R2LBwd1Args& a, R2LBpState& st, R2LBpAcc& A, const
   // ---- folded chroma stencils of this row's parity ----------------------------------------------------------------------
   const float* rows[3] = {vu, vm, vl};
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 3; ++i) {
+    r2l_p2 x[3][2];  // the window row's pairs at column offsets 0, 1, 2 (r2l_row_pairs: straddles as one v_pk_mov_b32)
+    r2l_row_pairs(rows[i], x);
     R2L_PRAGMA_UNROLL
-  for (int j = 0; j < 3; ++j) {
-    r2l_p2 su = A.gau[i * 3 + j], sv = A.gav[i * 3 + j];
-    R2L_PRAGMA_UNROLL
-    for (int p = 0; p < 2; ++p) {
-      const r2l_p2 x = r2l_mk2(rows[i][2 * p + j], rows[i][2 * p + j + 1]);
-      su = r2l_pfma(gu[p], x, su);
-      sv = r2l_pfma(gv[p], x, sv);
+    for (int j = 0; j < 3; ++j) {
+      r2l_p2 su = A.gau[i * 3 + j], sv = A.gav[i * 3 + j];
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) {
+        su = r2l_pfma(gu[p], x[j][p], su);
+        sv = r2l_pfma(gv[p], x[j][p], sv);
+      }
+      A.gau[i * 3 + j] = su;
+      A.gav[i * 3 + j] = sv;
     }
-    A.gau[i * 3 + j] = su;
-    A.gav[i * 3 + j] = sv;
   }
   A.su = r2l_padd(A.su, r2l_padd(gu[0], gu[1]));
   A.sv = r2l_padd(A.sv, r2l_padd(gv[0], gv[1]));
@@ -318,9 +320,11 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
     // every group of 6 steps runs in full (rows past the band's end: clamped fetches, zero cotangent, nothing stored);
     // 6 is even, so the banks are back in place at the end of a group
     for (int qb = y0; qb < y1; qb += 6) {
+      R2L_PROGRESS_PRIO(qb - y0, y1 - y0);
 #define R2L_BP_STEP(K)                                                                                  \
   {                                                                                                     \
     const int q = qb + K;                                                                               \
+    R2L_PROGRESS_PRIO_STEP(q - y0, y1 - y0);                                                            \
     R2L_BP_LOAD_STEP(K, q)                                                                              \
     const R2LBpStage g_ = pfg[(K) % PFG];                                                               \
     r2l_bp_fetch_g<EPI>(gimg, plane, q + PFG, a.H, a.W, x0, a.ep, pfg[(K) % PFG]);                      \
@@ -458,9 +462,11 @@ R2L_BLOCKFN void r2l_bwd1_blur_block(const R2LBwd1Args& a, int bid, int nblk, fl
     R2L_BB_LOAD_STEP(4, y0 - 2)
     R2L_BB_LOAD_STEP(5, y0 - 1)
     for (int qb = y0; qb < y1; qb += 6) {
+      R2L_PROGRESS_PRIO(qb - y0, y1 - y0);
 #define R2L_BB_STEP(K)                                                                                  \
   {                                                                                                     \
     const int q = qb + K;                                                                               \
+    R2L_PROGRESS_PRIO_STEP(q - y0, y1 - y0);                                                            \
     R2L_BB_LOAD_STEP(K, q)                                                                              \
     const R2LBbStage g_ = pfg[(K) % PF];                                                                \
     {                                                                                                   \
@@ -611,9 +617,11 @@ R2L_BLOCKFN void r2l_bwd2_hp_block(const R2LBwd2Args& a, int bid, int nblk, floa
   R2L_HP_LOAD_STEP(4, y0 - 2)
   R2L_HP_LOAD_STEP(5, y0 - 1)
   for (int qb = y0; qb < y1; qb += 6) {
+    R2L_PROGRESS_PRIO(qb - y0, y1 - y0);
 #define R2L_HP_STEP(K)                                                                                  \
   {                                                                                                     \
     const int q = qb + K;                                                                               \
+    R2L_PROGRESS_PRIO_STEP(q - y0, y1 - y0);                                                            \
     R2L_HP_LOAD_STEP(K, q)                                                                              \
     r2l_hp_step<K>(a, gw, q, le, re, in_w && q < y1, hpb, x0);                                          \
   }
@@ -775,9 +783,11 @@ R2L_BLOCKFN void r2l_bwd1_blur_hp_block(const R2LBwd1Args& a, int bid, int nblk,
     R2L_BH_LOAD_STEP(4, y0 - 2)
     R2L_BH_LOAD_STEP(5, y0 - 1)
     for (int qb = y0; qb < y1; qb += 6) {
+      R2L_PROGRESS_PRIO(qb - y0, y1 - y0);
 #define R2L_BH_STEP(K)                                                                                  \
   {                                                                                                     \
     const int q = qb + K;                                                                               \
+    R2L_PROGRESS_PRIO_STEP(q - y0, y1 - y0);                                                            \
     R2L_BH_LOAD_STEP(K, q)                                                                              \
     const r2l_f4 y_ = pfy[(K) % PF];                                                                    \
     {                                                                                                   \
@@ -891,24 +901,28 @@ R2L_HD void r2l_b2s_sums(const R2LBwd2Args& a, R2LSumState& st, R2LSumAcc& A, bo
     r2l_p2 gy[2];
     gy[0] = gy[1] = r2l_splat2(0.f);
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
+      r2l_p2 x[3][2];
+      r2l_row_pairs(st.hp[(K + 2 + (2 - i)) % 3], x);  // window row 2 - i
       R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 3; ++j) {
-      const r2l_p2 w = r2l_splat2(F.sharp[i * 3 + j]);
-      const float* hr = st.hp[(K + 2 + (2 - i)) % 3];  // window row 2 - i
-      R2L_PRAGMA_UNROLL
-      for (int p = 0; p < 2; ++p) gy[p] = r2l_pfma(w, r2l_mk2(hr[2 * p + 2 - j], hr[2 * p + 3 - j]), gy[p]);
+      for (int j = 0; j < 3; ++j) {
+        const r2l_p2 w = r2l_splat2(F.sharp[i * 3 + j]);
+        R2L_PRAGMA_UNROLL
+        for (int p = 0; p < 2; ++p) gy[p] = r2l_pfma(w, x[2 - j][p], gy[p]);
+      }
     }
     if (!ok_t) gy[0] = gy[1] = r2l_splat2(0.f);
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
+      r2l_p2 x[3][2];
+      r2l_row_pairs(st.v[(K + 2 + i) % 3], x);  // V(t - 1 + i)
       R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 3; ++j) {
-      const float* vr = st.v[(K + 2 + i) % 3];  // V(t - 1 + i)
-      r2l_p2 sacc = A.gay[i * 3 + j];
-      R2L_PRAGMA_UNROLL
-      for (int p = 0; p < 2; ++p) sacc = r2l_pfma(gy[p], r2l_mk2(vr[2 * p + j], vr[2 * p + j + 1]), sacc);
-      A.gay[i * 3 + j] = sacc;
+      for (int j = 0; j < 3; ++j) {
+        r2l_p2 sacc = A.gay[i * 3 + j];
+        R2L_PRAGMA_UNROLL
+        for (int p = 0; p < 2; ++p) sacc = r2l_pfma(gy[p], x[j][p], sacc);
+        A.gay[i * 3 + j] = sacc;
+      }
     }
     A.sy = r2l_padd(A.sy, r2l_padd(gy[0], gy[1]));
   }
@@ -920,14 +934,16 @@ R2L_HD void r2l_b2s_sums(const R2LBwd2Args& a, R2LSumState& st, R2LSumAcc& A, bo
     gp[0] = r2l_mk2(ok_tm1 ? hc[1] : 0.f, ok_tm1 ? hc[2] : 0.f);
     gp[1] = r2l_mk2(ok_tm1 ? hc[3] : 0.f, ok_tm1 ? hc[4] : 0.f);
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
+      r2l_p2 x[3][2];
+      r2l_row_pairs(st.y[(K + 1 + i) % 3], x);
       R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 3; ++j) {
-      const float* yr = st.y[(K + 1 + i) % 3];
-      r2l_p2 sacc = A.gsh[i * 3 + j];
-      R2L_PRAGMA_UNROLL
-      for (int p = 0; p < 2; ++p) sacc = r2l_pfma(gp[p], r2l_mk2(yr[2 * p + j], yr[2 * p + j + 1]), sacc);
-      A.gsh[i * 3 + j] = sacc;
+      for (int j = 0; j < 3; ++j) {
+        r2l_p2 sacc = A.gsh[i * 3 + j];
+        R2L_PRAGMA_UNROLL
+        for (int p = 0; p < 2; ++p) sacc = r2l_pfma(gp[p], x[j][p], sacc);
+        A.gsh[i * 3 + j] = sacc;
+      }
     }
   }
 }
@@ -1008,9 +1024,11 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk, fl
     R2L_B2S_LOAD_STEP(5, y0 - 1)
     if (r2l_opaque_true()) r2l_b2s_luma<5>(a, st, y0 - 1, le, re);
     for (int qb = y0; qb < y1; qb += 6) {  // (a last group that runs past y1 also takes the step t = y1, see below)
+      R2L_PROGRESS_PRIO(qb - y0, y1 - y0);
 #define R2L_B2S_STEP(K)                                                                                       \
   {                                                                                                           \
     const int t = qb + K;                                                                                     \
+    R2L_PROGRESS_PRIO_STEP(t - y0, y1 - y0);                                                                  \
     R2L_B2S_LOAD_STEP(K, t)                                                                                   \
     if (K) r2l_b2s_swap(A, bank); /* the bank of this row's parity into the registers */                      \
     if (r2l_opaque_true()) {                                                                                  \

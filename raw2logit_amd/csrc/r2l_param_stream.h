@@ -148,11 +148,47 @@ struct R2LFsState {
   float piv[3];
 };
 
-// 3x3 stencil with per-column-parity weights on a 6-wide 3-row window -> 4 outputs as 2 pairs
+// 3x3 stencil with per-column-parity weights on a 6-wide 3-row window -> 4 outputs as 2 pairs.  A window row is three
+// aligned pairs P0 = (w0,w1), P1 = (w2,w3), P2 = (w4,w5); the middle tap's operands straddle them: ONE v_pk_mov_b32 each
+// (r2l_straddle) -- written as r2l_mk2(row[1], row[2]) hipcc copies both halves with a v_mov_b32 each, at every use.
+#ifndef R2L_STENCIL_STRADDLE
+#define R2L_STENCIL_STRADDLE 1
+#endif
+// the pairs of a 6-wide window row at column offsets 0, 1, 2: x[j][p] = (row[2p + j], row[2p + j + 1])
+R2L_HD void r2l_row_pairs(const float* row, r2l_p2 x[3][2]) {
+#if R2L_STENCIL_STRADDLE
+  const r2l_p2 P0 = r2l_mk2(row[0], row[1]), P1 = r2l_mk2(row[2], row[3]), P2 = r2l_mk2(row[4], row[5]);
+  x[0][0] = P0;
+  x[0][1] = P1;
+  x[1][0] = r2l_straddle(P0, P1);
+  x[1][1] = r2l_straddle(P1, P2);
+  x[2][0] = P1;
+  x[2][1] = P2;
+#else
+  R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j)
+    R2L_PRAGMA_UNROLL
+  for (int p = 0; p < 2; ++p) x[j][p] = r2l_mk2(row[2 * p + j], row[2 * p + j + 1]);
+#endif
+}
 template <class WT>
 R2L_HD void r2l_fs_stencil_parity(const float* r0, const float* r1, const float* r2, WT w /* [9][2] */, r2l_p2 o[2]) {
   o[0] = o[1] = r2l_splat2(0.f);
   const float* rows[3] = {r0, r1, r2};
+#if R2L_STENCIL_STRADDLE
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    const r2l_p2 P0 = r2l_mk2(rows[i][0], rows[i][1]), P1 = r2l_mk2(rows[i][2], rows[i][3]), P2 = r2l_mk2(rows[i][4], rows[i][5]);
+    const r2l_p2 O0 = r2l_straddle(P0, P1), O1 = r2l_straddle(P1, P2);
+    const r2l_p2 x[3][2] = {{P0, P1}, {O0, O1}, {P1, P2}};
+    R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      const r2l_p2 wy = r2l_mk2(w[i * 3 + j][0], w[i * 3 + j][1]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(wy, x[j][p], o[p]);
+    }
+  }
+#else
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 3; ++i)
     R2L_PRAGMA_UNROLL
@@ -161,6 +197,36 @@ R2L_HD void r2l_fs_stencil_parity(const float* r0, const float* r1, const float*
     R2L_PRAGMA_UNROLL
     for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(wy, r2l_mk2(rows[i][2 * p + j], rows[i][2 * p + j + 1]), o[p]);
   }
+#endif
+}
+// the same with ONE weight per tap for both halves (the sharpen): 3x3 cross-correlation on a 6-wide 3-row window
+template <class WT>
+R2L_HD void r2l_fs_stencil_plain(const float* r0, const float* r1, const float* r2, WT w /* [9] */, r2l_p2 o[2]) {
+  o[0] = o[1] = r2l_splat2(0.f);
+  const float* rows[3] = {r0, r1, r2};
+#if R2L_STENCIL_STRADDLE
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    const r2l_p2 P0 = r2l_mk2(rows[i][0], rows[i][1]), P1 = r2l_mk2(rows[i][2], rows[i][3]), P2 = r2l_mk2(rows[i][4], rows[i][5]);
+    const r2l_p2 O0 = r2l_straddle(P0, P1), O1 = r2l_straddle(P1, P2);
+    const r2l_p2 x[3][2] = {{P0, P1}, {O0, O1}, {P1, P2}};
+    R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      const r2l_p2 ws = r2l_splat2(w[i * 3 + j]);
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(ws, x[j][p], o[p]);
+    }
+  }
+#else
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 3; ++i)
+    R2L_PRAGMA_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    const r2l_p2 ws = r2l_splat2(w[i * 3 + j]);
+    R2L_PRAGMA_UNROLL
+    for (int p = 0; p < 2; ++p) o[p] = r2l_pfma(ws, r2l_mk2(rows[i][2 * p + j], rows[i][2 * p + j + 1]), o[p]);
+  }
+#endif
 }
 
 // the colour code of one output row (:203-217): Y'', U, V of the lane's 4 pixels -> RGB, clip, gamma, [statistics about the
@@ -185,9 +251,7 @@ R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc
                                 r2l_log2(fminf(fmaxf(rgb[1], 1e-5f), 1.0f)));
       const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));                    // :209
       x[p] = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
-      // (every lane accumulates: a lane past the frame's last column walks valid pixels of the clamped strip and its sums
-      // are dropped as a whole in r2l_fs_lane_sums -- a per-step `store_ok` here costs 24 v_cndmask per row step)
-      if (STATS == 1 && a.stat_partial) {
+      if (STATS == 1 && a.stat_partial && store_ok) {
         if (p == 0) piv[k] = (y == y0) ? x[0][0] : piv[k];
         const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-piv[k]));
         acc[k] = r2l_padd(acc[k], d);
@@ -237,7 +301,7 @@ R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc
 template <int NW, bool U16, int K, bool EPI>
 R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0, int y1, bool le, bool re,
                         int wave, int lane, float* ex, r2l_f4* fifo, float* ob, float* ypb, unsigned plane, int x0,
-                        bool store_ok, const float mean[3], const float istd[3]) {
+                        bool store_ok, const float mean[3], const float istd[3], float smask) {
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
   R2LFoldedRef Fh = R2L_FOLDED_REF(a.F);  // not laundered: the 25 blur weights stay in scalar registers (-1 %)
   constexpr int PY = K & 1;
@@ -364,7 +428,9 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
     const r2l_f4* f = fifo + ((K + 2) % R2L_FS_FIFO_ROWS) * 2 * 64 + lane;  // row q-4
     const r2l_f4 fu = f[0], fv = f[64];
     const r2l_p2 u[2] = {r2l_mk2(fu.x, fu.y), r2l_mk2(fu.z, fu.w)}, v[2] = {r2l_mk2(fv.x, fv.y), r2l_mk2(fv.z, fv.w)};
-    r2l_fs_colour<EPI, 1>(a, F, st.acc, st.piv, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd);
+    // (statistics: the branch-free form, weighted with the lane's 0 / 1 mask -- 6 v_pk_mul_f32 per row step where the
+    // conditional form `if (a.stat_partial && store_ok)` is if-converted into 24 v_cndmask_b32)
+    r2l_fs_colour<EPI, 2>(a, F, st.acc, st.piv, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd, smask, y == y0);
     const unsigned off0 = (unsigned)y * (unsigned)a.W + (unsigned)x0;
     // Y'(y), kept for kernel B1 of the backward: the middle row of the blur's window, stored last (the step's
     // registers are free here; next to the sharpen, or in front of the colour code, the kernel spills)
@@ -395,8 +461,8 @@ R2L_HD void r2l_fs_lane_sums(const r2l_p2* acc, const float* piv, double npx, bo
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
     // from the lane's pivot p to the common pivot 0.5:  x - .5 = (x - p) + dp
-    const double s1 = ok ? (double)acc[k][0] + (double)acc[k][1] : 0.0;
-    const double s2 = ok ? (double)acc[3 + k][0] + (double)acc[3 + k][1] : 0.0;
+    const double s1 = (double)acc[k][0] + (double)acc[k][1];
+    const double s2 = (double)acc[3 + k][0] + (double)acc[3 + k][1];
     const double dp = ok ? (double)piv[k] - 0.5 : 0.0;
     double v1 = fma(npx, dp, s1), v2 = fma(dp, fma(npx, dp, 2.0 * s1), s2);
     R2L_PRAGMA_UNROLL
@@ -500,6 +566,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
       istd[k] = a.bn[3 + k];
     }
   }
+  const float smask = (a.stat_partial && store_ok) ? 1.f : 0.f;  // does this lane's pixel count in the statistics?
   R2LFsState st;
   // statistics: float32 pair accumulators per work item (<= band_h x 4 pixels per lane); after every item the
   // wavefront adds its 64 lane sums (float64, fixed butterfly order) into its float64 totals in LDS -- the rounding
@@ -563,12 +630,14 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
         if ((k0 + i) % PF == j) pf[j] = t;
     }
     for (int qb = q0; qb < q1; qb += 6) {
+      R2L_PROGRESS_PRIO(qb - q0, q1 - q0);
 #define R2L_FS_STEP(K)                                                                                          \
   if (qb + K >= qf && qb + K < q1) {                                                                            \
     const int q = qb + K;                                                                                       \
+    R2L_PROGRESS_PRIO_STEP(q - q0, q1 - q0);                                                                    \
     r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
     if (q + 1 + PF <= q1) r2l_fs_fetch<U16>(a, img, r2l_mirror(q + 1 + PF, a.H), x0, le, re, lane, pf[K % PF]); \
-    r2l_fs_step<NW, U16, K, EPI>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, store_ok, mean, istd); \
+    r2l_fs_step<NW, U16, K, EPI>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, store_ok, mean, istd, smask); \
   }
       R2L_FS_STEP(0)
       R2L_FS_STEP(1)
@@ -746,9 +815,11 @@ R2L_HD void r2l_fa_item(const R2LFwdStreamArgs& a, int item, int lane, const flo
   // every group of 6 steps runs in full: rows past the band's end (last band of an image whose height is not a multiple
   // of 6) are computed from clamped fetches and neither stored nor counted
   for (int qb = y0; qb < y1; qb += 6) {
+    R2L_PROGRESS_PRIO(qb - y0, y1 - y0);
 #define R2L_FA_STEP(K)                                                                                  \
   {                                                                                                     \
     const int q = qb + K;                                                                               \
+    R2L_PROGRESS_PRIO_STEP(q - y0, y1 - y0);                                                            \
     R2L_FA_LOAD_STEP(K, q)                                                                              \
     if (!STATS || r2l_opaque_true())                                                                    \
       r2l_fa_step<K, EPI, STATS>(a, st, acc, piv, q, y0, in_w && q < y1, ob, plane, x0, mean, istd);    \
@@ -902,16 +973,7 @@ R2L_HD void r2l_fl_step(const R2LFwdStreamArgs& a, R2LFlState& st, int y, bool l
   }
   if (OUT) {
     r2l_p2 o[2];  // rows Y(y-1), Y(y), Y(y+1) = slots K+2, K, K+1
-    o[0] = o[1] = r2l_splat2(0.f);
-    R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 3; ++i)
-      R2L_PRAGMA_UNROLL
-    for (int j = 0; j < 3; ++j) {
-      const r2l_p2 ws = r2l_splat2(F.sharp[i * 3 + j]);
-      R2L_PRAGMA_UNROLL
-      for (int p = 0; p < 2; ++p)
-        o[p] = r2l_pfma(ws, r2l_mk2(st.y[(K + 2 + i) % 3][2 * p + j], st.y[(K + 2 + i) % 3][2 * p + j + 1]), o[p]);
-    }
+    r2l_fs_stencil_plain(st.y[(K + 2) % 3], st.y[K % 3], st.y[(K + 1) % 3], F.sharp, o);
     if (store_ok) {
       r2l_f4 s4;
       s4.x = o[0][0];
@@ -964,6 +1026,7 @@ R2L_BLOCKFN void r2l_fwd_luma_block(const R2LFwdStreamArgs& a, int bid, int nblk
   R2L_FL_STEP(4, y0 - 2, true, false)
   R2L_FL_STEP(5, y0 - 1, true, false)
   for (int qb = y0; qb < y1; qb += 6) {
+    R2L_PROGRESS_PRIO(qb - y0, y1 - y0);
     R2L_FL_STEP(0, qb + 0, true, true)
     R2L_FL_STEP(1, qb + 1, true, true)
     R2L_FL_STEP(2, qb + 2, true, true)
