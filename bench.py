@@ -63,8 +63,8 @@ def algo_bytes_per_px(kernel):
     return None
 
 
-PMC_PARAM = 'r03_pmc_traffic.json'
-PMC_STATIC = 'r02_pmc_traffic_static.json'
+PMC_PARAM = 'r04_pmc_traffic.json'
+PMC_STATIC = 'r04_pmc_traffic_static.json'      # all three static kernels of static_c3, this round's build
 
 
 def pmc_traffic(kernel, B, S, name=PMC_PARAM, shape=(64, 512)):
@@ -82,7 +82,7 @@ def pmc_traffic(kernel, B, S, name=PMC_PARAM, shape=(64, 512)):
     v = t.get(kernel, {}).get('total_bytes')
     if v is None:
         return None, f'profiles/{name} has no entry for {kernel}'
-    return v, f'committed rocprofv3 --pmc profile profiles/{name} (same build, same shape; not measured in this run)'
+    return v, f'committed rocprofv3 --pmc profile profiles/{name} (this round\'s build, same shape; not measured in this run)'
 
 
 def parse():
@@ -379,7 +379,9 @@ def static_records(torch, lib, clock, dev):
         name = max(k, key=lambda n: k[n]['launches'] * k[n]['avg_us'])
         avg_us = sum(v['launches'] * v['avg_us'] for v in k.values()) / 20      # all launches of one call
         ach = B * S * S * 16.0 / (avg_us * 1e-6) / 1e9
-        recs.append({'chain': what, 'shape': [B, S, S], 'kernel': name, 'avg_us': round(avg_us, 1),
+        traffic, source = pmc_traffic(name, B, S, PMC_STATIC, (256, 1024))
+        recs.append({'chain': what, 'shape': [B, S, S], 'kernel': name, 'avg_us': round(avg_us, 1), 'traffic': traffic,
+                     'traffic_source': source,
                      'ms_per_call_wall': round(wall_ms, 4), 'algo_bytes_per_px': 16.0,
                      'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(ach / HBM_PEAK_GBS, 4),
@@ -606,11 +608,13 @@ def main():
         model.process_group = dist.group.WORLD
     params = list(model.parameters())
     fwd = model
+    nccl = os.environ.get('R2L_BENCH_BACKEND', 'nccl') == 'nccl'
     if args.graph:
-        if world > 1:
-            raise SystemExit('bench.py: --graph is a single-GPU option (the statistics exchange splits the step calls)')
+        if world > 1 and not nccl:
+            raise SystemExit('bench.py: --graph with several ranks needs RCCL (a gloo group moves host memory: not capturable)')
         from raw2logit_amd.graphs import StepGraph
-        graph_step = StepGraph(model, raw, cot)
+        # several ranks: the two statistics all-gathers and the gradient all-reduce are captured with the kernels
+        graph_step = StepGraph(model, raw, cot, process_group=dist.group.WORLD if world > 1 else None)
 
     pending = []
 
@@ -672,6 +676,21 @@ def main():
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                         'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
 
+    graph_ms = graph_err = None
+    if world > 1 and nccl and dev.type == 'cuda' and not args.graph:
+        # the same data-parallel step as ONE HIP graph with its RCCL collectives captured (raw2logit_amd/graphs.py): at
+        # BASELINE config 5's 64 x 256 x 256 per GPU the eager step is host-bound, and every rank pays the host twice more
+        # around the two all-gathers
+        try:
+            from raw2logit_amd.graphs import StepGraph
+            finish()
+            m2 = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True).to(dev).train()
+            m2.raw_bits = 12
+            g2 = StepGraph(m2, raw, cot, process_group=dist.group.WORLD)
+            clock.preroll(g2.replay, None, 0.05)
+            graph_ms = 1e3 * clock.time_steps(g2.replay, args.steps, args.warmup) / args.steps
+        except Exception as e:                       # noqa: BLE001
+            graph_err = '%s: %s' % (type(e).__name__, e)
     static_c3 = small = None
     # (sub-records: a failure in one of them must not cost the headline line -- it is reported in its place)
     if world == 1 and dev.type == 'cuda' and not args.no_small_shapes:
@@ -713,10 +732,16 @@ def main():
             # the kernels' HIP events sit between the launches of the instrumented pass: each event pair costs the queue
             # ~2 us, so that pass runs slower than the timed one -- its own wall clock is the one the kernel sum must fit in
             'instrumented_ms_per_step': round(getattr(kernel_times, 'wall_ms_per_step', 0.0), 4) if kernels else None,
+            'warmup_effective': args.warmup + preroll_steps,     # untimed steps in front of the K timed ones
             'preroll': {'steps': preroll_steps, 'seconds': PREROLL_S,
                         'why': 'untimed; brings the GPU clocks up after the host-side cpu_baseline leg, before the W warm-up '
                                'steps and the K timed steps'},
         }
+        if graph_ms is not None:
+            out['ms_per_step_graph'] = round(graph_ms, 4)
+            out['value_graph'] = round(px_per_step / (graph_ms * 1e-3) / 1e6, 1)
+        if graph_err is not None:
+            out['graph_error'] = graph_err
         if comm_us is not None:
             # wall time of each ISP collective per call (device events on the launch stream around the exchange, from the
             # instrumented pass): the two small all-gathers sit inside the step, the gradient all-reduce overlaps

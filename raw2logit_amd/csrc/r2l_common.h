@@ -483,6 +483,27 @@ R2L_HD const R2LFolded* r2l_opaque_after(const R2LFolded* p, float dep) {
   return p;
 }
 
+// Workgroup ids are dealt round-robin over the 8 XCDs (id % 8), each with its own 4 MiB L2.  Kernels whose consecutive
+// work items share rows (the band passes: a band re-reads the halo rows of its neighbours) can walk the items through this
+// map: inside every window of 8 M consecutive ids, XCD x takes the M CONTIGUOUS virtual ids [x M, (x + 1) M) -- M
+// neighbouring bands then run on one XCD at about the same time and their shared halo rows are L2 hits instead of second
+// fetches from HBM, while the chip as a whole still works on one compact region (handing each XCD a contiguous EIGHTH of
+// the whole launch is slower than no map at all: eight regions in flight, profiles/r04_ab_static_xcd.txt).
+// R2L_XCD_REMAP = M (0: off).
+#ifndef R2L_XCD_REMAP
+#define R2L_XCD_REMAP 0
+#endif
+R2L_HD int r2l_xcd_contiguous(int bid, int nblk) {
+#if R2L_XCD_REMAP
+  constexpr int M = R2L_XCD_REMAP, G = 8 * M;
+  const int w0 = bid - bid % G;
+  return (w0 + G <= nblk) ? w0 + (bid & 7) * M + ((bid - w0) >> 3) : bid;
+#else
+  (void)nblk;
+  return bid;
+#endif
+}
+
 // Issue priority by PROGRESS.  The wavefronts of a SIMD start together (the band passes are sized for one round of resident
 // wavefronts) and the hardware favours the oldest one whenever several are ready: left alone they finish one after the
 // other, and the last one walks its rows alone with every scalar-load and memory wait exposed (the plane kernels'

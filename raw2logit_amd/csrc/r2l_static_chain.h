@@ -28,6 +28,17 @@
 // r2l_static_kernels.h), log2 / exp2 in float32.
 #pragma once
 #include "r2l_static_stream.h"
+#ifndef R2L_CHAIN_BF
+#define R2L_CHAIN_BF 1
+#endif
+#ifndef R2L_CHAIN_PROGRESS_PRIO
+#define R2L_CHAIN_PROGRESS_PRIO 1  // (default chain 963 -> 944 us, profiles/r04_static_chain_ab.txt)
+#endif
+#if R2L_CHAIN_PROGRESS_PRIO
+#define R2L_CHAIN_PRIO(d, t) R2L_PROGRESS_PRIO(d, t)
+#else
+#define R2L_CHAIN_PRIO(d, t)
+#endif
 
 #ifndef R2L_EMUL
 
@@ -423,23 +434,41 @@ R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, i
   constexpr bool LANES = R2L_HAVE_LANE_SHIFTS;
   constexpr int PF = DEB ? 2 : R2L_CHAIN_PF;
   R2LRowStageT<RAWK> stage;
+  // BRANCH-FREE row loop on float32 / 16-bit frames (R2L_CHAIN_BF; r2l_stream_fetch_row_bf): every fetch unconditional
+  // (rows past the band's last needed one re-fetch that row), every group of 6 steps in full (a step past q1 only finishes
+  // rows >= y1, which are not stored) -- hipcc then counts its vmcnt waits instead of waiting for the row just requested
+  constexpr bool BF = R2L_CHAIN_BF && RAWK != R2L_RAW_F64;
+  constexpr unsigned ESZ = (RAWK == R2L_RAW_U16) ? 2u : 4u;
+  const unsigned xo = ESZ * (unsigned)x0, xleft = ESZ * (unsigned)(x0 + (le ? 0 : -2)), xright = ESZ * (unsigned)(x0 + (re ? 2 : 4));
+  const unsigned xl = LANES ? (lane < 32 ? xleft : xright) : xleft, xr = xright;
+  const int rlast = q1 - 1 + LA;  // last raw row (before the symmetric extension) the band's steps consume
+  (void)xo; (void)xl; (void)xr; (void)rlast;
+#define R2L_CHAIN_FETCH(row_, st_)                                                                                \
+  {                                                                                                               \
+    if constexpr (BF) {                                                                                           \
+      const int rr_ = ((row_) < rlast) ? (row_) : rlast;                                                          \
+      r2l_stream_fetch_row_bf<RAWK, LANES>(a, img, r2l_symmetric(rr_, a.H), xo, xl, xr, le, re, (st_));           \
+    } else {                                                                                                      \
+      r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric((row_), a.H), x0, le, re, (st_));                   \
+    }                                                                                                             \
+  }
   // warm-up: raw rows q0-LA .. q0+LA-1 into their slots (q0 is a multiple of 6, hence of NR)
   R2L_PRAGMA_UNROLL
   for (int i = -LA; i < LA; ++i) {
-    r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 + i, a.H), x0, le, re, stage);
+    R2L_CHAIN_FETCH(q0 + i, stage)
     r2l_stream_convert_row<RAWK, LANES>(a, stage, le, re, st.rw[(i + NR) % NR]);
   }
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
   R2LRowStageT<RAWK> pf[PF];  // ring: step K consumes pf[K % PF] (raw row q + LA) and refills it with row q + LA + PF
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < PF; ++i) r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q0 + LA + i, a.H), x0, le, re, pf[i]);
+  for (int i = 0; i < PF; ++i) R2L_CHAIN_FETCH(q0 + LA + i, pf[i])
   for (int qb = q0; qb < q1; qb += 6) {
+    R2L_CHAIN_PRIO(qb - q0, q1 - q0);
 #define R2L_CHAIN_STEP(K)                                                                                         \
-  if (qb + K < q1) {                                                                                              \
+  if (BF || qb + K < q1) {                                                                                        \
     const int q = qb + K;                                                                                         \
     r2l_stream_convert_row<RAWK, LANES>(a, pf[K % PF], le, re, st.rw[(K + LA) % NR]);                             \
-    if (q + PF < q1)                                                                                              \
-      r2l_stream_fetch_row<RAWK, LANES>(a, img, r2l_symmetric(q + LA + PF, a.H), x0, le, re, pf[K % PF]);         \
+    if (BF || q + PF < q1) R2L_CHAIN_FETCH(q + LA + PF, pf[K % PF])                                               \
     r2l_chain_step<DEB, SH, DN, K>(a, st, q, y0, y1, le, re, NW, wave, lane, ex, fifo, outb, plane, x0, store_ok); \
   }
     R2L_CHAIN_STEP(0)
@@ -450,6 +479,7 @@ R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, i
     R2L_CHAIN_STEP(5)
 #undef R2L_CHAIN_STEP
   }
+#undef R2L_CHAIN_FETCH
 }
 
 #endif  // !R2L_EMUL

@@ -44,6 +44,52 @@ struct R2LRowStageT<R2L_RAW_F64> {
 // enters the window; only lane 0 / lane 63 fetch theirs from the neighbouring strip (one load instruction for
 // both, staged in v[0..1] resp. v[0]).  Otherwise every lane loads its own neighbour pairs (hits in L1).  On the
 // bilinear chain (1 neighbour each side) the lane form is 3 % faster, on Malvar (2 each side) 9 % slower.
+// BRANCH-FREE form (float32 / 16-bit frames): every lane issues the same loads -- the 16 (8) bytes of its own columns and
+// ONE pair beyond them from an in-row address (lanes 0-31: the pair on their left, lanes 32-63: on their right; at the
+// image's edges the lane's own columns, whose mirror images convert_row takes from the centre values) [LANES], or both
+// pairs [!LANES].  With a load under a lane-dependent or uniform condition anywhere in the row loop hipcc's s_waitcnt
+// insertion gives up counting: the row step waited with vmcnt(0) .. vmcnt(3), i.e. for the row it had JUST requested and
+// for the previous row's stores, instead of for the row requested PF steps ago (the lesson of r2l_fa_fetch_raw, round 3;
+// profiles/r04_static_branch_free.txt).
+// Addresses: a wave-uniform row pointer (scalar registers) + the lane's unsigned element offsets xo / xl / xr, constants of
+// the work item -- the `global_load v, voffset, s[base]` form, one 32-bit register per stream instead of a 64-bit pointer
+// per load.
+template <int RAWK, bool LANES>
+R2L_HD void r2l_stream_fetch_row_bf(const R2LStaticArgs& a, size_t img0, int ys, unsigned xo, unsigned xl, unsigned xr,
+                                    bool le, bool re, R2LRowStageT<RAWK>& st) {
+  static_assert(RAWK != R2L_RAW_F64, "float64 frames keep the conditional form");
+  const size_t e = img0 + (size_t)ys * a.W;  // wave-uniform
+  st.ys = ys;
+  float* v = st.v;
+  // (xo, xl, xr: BYTE offsets, 32-bit: uniform 64-bit base + zero-extended 32-bit lane offset is the saddr form)
+  if (RAWK == R2L_RAW_U16) {
+    const char* r = (const char*)(a.raw.u16 + e);
+    const r2l_f2 c = *(const r2l_f2*)(r + xo);
+    v[1] = c.x;
+    v[2] = c.y;
+    v[0] = *(const float*)(r + xl);  // LANES: xl = the pair on the lane's side (left for lanes 0-31, right for 32-63)
+    v[3] = LANES ? 0.f : *(const float*)(r + xr);
+    return;
+  }
+  const char* r = (const char*)(a.raw.f32 + e);
+  const r2l_f4 c = r2l_stream_load_f4((const float*)(r + xo));
+  v[2] = c.x;
+  v[3] = c.y;
+  v[4] = c.z;
+  v[5] = c.w;
+  if (LANES) {
+    const r2l_f2 q = *(const r2l_f2*)(r + xl);
+    v[0] = q.x;
+    v[1] = q.y;
+    v[6] = v[7] = 0.f;
+  } else {
+    const r2l_f2 l = *(const r2l_f2*)(r + xl), q = *(const r2l_f2*)(r + xr);
+    v[0] = le ? c.y : l.x;  // x = -2 -> 1, x = -1 -> 0 (symmetric extension)
+    v[1] = le ? c.x : l.y;
+    v[6] = re ? c.w : q.x;  // x = W -> W-1, x = W+1 -> W-2
+    v[7] = re ? c.z : q.y;
+  }
+}
 template <int RAWK, bool LANES>
 R2L_HD void r2l_stream_fetch_row(const R2LStaticArgs& a, size_t img0, int ys, int x0, bool le, bool re,
                                  R2LRowStageT<RAWK>& st) {
@@ -213,7 +259,7 @@ R2L_HD double r2l_widen(float x) {
 
 // WB * CCM, clip, gamma and the three 16-byte stores of one output row (4 pixels of this lane)
 R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], float* outb, size_t plane,
-                                  size_t off) {
+                                  size_t off, bool ok = true) {
   float x[3][4];
   R2L_PRAGMA_UNROLL
   for (int c = 0; c < 4; ++c)
@@ -230,7 +276,7 @@ R2L_HD void r2l_stream_finish_row(const R2LStaticArgs& a, const double d[4][3], 
     st.y = x[k][1];
     st.z = x[k][2];
     st.w = x[k][3];
-    r2l_stream_store_f4(outb + (size_t)k * plane + off, st);
+    if (ok) r2l_stream_store_f4(outb + (size_t)k * plane + off, st);
   }
 }
 
@@ -540,13 +586,244 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   }
 }
 
+// ---- row stage with SCALAR strip edges (branch-free kernels) ----------------------------------------------------------
+// The columns beyond a lane's four come from the neighbouring lanes (DPP wave shifts); only the strip's first / last lane
+// need values of the neighbouring strips -- two wave-uniform addresses per row: ONE s_load_dwordx2 each (scalar cache, no
+// vector-memory instruction, no per-lane address, no condition), carried in scalar registers until the row enters the
+// window.  At the image's left / right edge the scalar loads read in-row dummies and the lanes there mirror their own
+// columns (symmetric extension).
+#ifndef R2L_EMUL
+R2L_HD float r2l_swshr(float x, float edge) {  // previous lane's x; lane 0 of the wavefront gets `edge`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
+                                                               0x138, 0xf, 0xf, false));
+}
+R2L_HD float r2l_swshl(float x, float edge) {  // next lane's x; lane 63 gets `edge`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
+                                                               0x130, 0xf, 0xf, false));
+}
+template <int RAWK>
+struct R2LRowStageS {
+  r2l_f4 c;       // the lane's 4 columns (16-bit containers: c.x, c.y = the 4 undecoded values)
+  r2l_f2 sl, sr;  // wave-uniform: columns (strip - 2, strip - 1) and (strip + 256, strip + 257) (16-bit: .x = both, undecoded)
+  int ys;
+};
+// sbl / sbr: wave-uniform BYTE offsets of the two edge pairs inside a row; xo: the lane's byte offset
+template <int RAWK>
+R2L_HD void r2l_stream_fetch_row_s(const R2LStaticArgs& a, size_t img0, int ys, unsigned xo, unsigned sbl, unsigned sbr,
+                                   R2LRowStageS<RAWK>& st) {
+  static_assert(RAWK != R2L_RAW_F64, "float32 / 16-bit frames");
+  const size_t e = img0 + (size_t)ys * a.W;  // wave-uniform
+  st.ys = ys;
+  if (RAWK == R2L_RAW_U16) {
+    const char* r = (const char*)(a.raw.u16 + e);
+    const r2l_f2 c = *(const r2l_f2*)(r + xo);
+    st.c.x = c.x;
+    st.c.y = c.y;
+    st.c.z = st.c.w = 0.f;
+    st.sl.x = *(const __attribute__((address_space(4))) float*)(r + sbl);
+    st.sr.x = *(const __attribute__((address_space(4))) float*)(r + sbr);
+    st.sl.y = st.sr.y = 0.f;
+    return;
+  }
+  const char* r = (const char*)(a.raw.f32 + e);
+  st.c = r2l_stream_load_f4((const float*)(r + xo));
+  typedef float v2_t __attribute__((ext_vector_type(2)));
+  const v2_t tl = *(const __attribute__((address_space(4))) v2_t*)(r + sbl);
+  const v2_t tr = *(const __attribute__((address_space(4))) v2_t*)(r + sbr);
+  st.sl.x = tl.x;
+  st.sl.y = tl.y;
+  st.sr.x = tr.x;
+  st.sr.y = tr.y;
+}
+// staged row -> 8 black-level-corrected values (columns x0-2 .. x0+5); le0 / re63: the strip starts / ends at the image's
+// edge (wave-uniform); le / re: this lane holds the image's first / last 4 columns
+template <int RAWK, class DT>
+R2L_HD void r2l_stream_convert_row_s(const R2LStaticArgs& a, const R2LRowStageS<RAWK>& st, bool le0, bool le, bool re,
+                                     DT dst[8]) {
+  float c0, c1, c2, c3, l0, l1, r0, r1;
+  if (RAWK == R2L_RAW_U16) {
+    const unsigned lo = r2l_f2u(st.c.x), hi = r2l_f2u(st.c.y), sl = r2l_f2u(st.sl.x), sr = r2l_f2u(st.sr.x);
+    c0 = r2l_raw_decode(lo & 0xffffu, a.raw);
+    c1 = r2l_raw_decode(lo >> 16, a.raw);
+    c2 = r2l_raw_decode(hi & 0xffffu, a.raw);
+    c3 = r2l_raw_decode(hi >> 16, a.raw);
+    l0 = r2l_raw_decode(sl & 0xffffu, a.raw);
+    l1 = r2l_raw_decode(sl >> 16, a.raw);
+    r0 = r2l_raw_decode(sr & 0xffffu, a.raw);
+    r1 = r2l_raw_decode(sr >> 16, a.raw);
+  } else {
+    c0 = st.c.x;
+    c1 = st.c.y;
+    c2 = st.c.z;
+    c3 = st.c.w;
+    l0 = st.sl.x;
+    l1 = st.sl.y;
+    r0 = st.sr.x;
+    r1 = st.sr.y;
+  }
+  float v[8];
+  // columns x0-2, x0-1 = the left lane's x0+2, x0+3; the strip's first lane: the neighbouring strip's last two columns,
+  // or (image edge, symmetric extension) its own columns 1, 0
+  v[0] = r2l_swshr(c2, le0 ? c1 : l0);
+  v[1] = r2l_swshr(c3, le0 ? c0 : l1);
+  v[2] = c0;
+  v[3] = c1;
+  v[4] = c2;
+  v[5] = c3;
+  const float q0 = r2l_swshl(c0, r0), q1 = r2l_swshl(c1, r1);  // columns x0+4, x0+5 = the right lane's x0, x0+1
+  v[6] = re ? c3 : q0;  // x = W -> W-1, x = W+1 -> W-2
+  v[7] = re ? c2 : q1;
+  const int ys = st.ys;
+  const float be = (ys & 1) ? a.blf[2] : a.blf[0], bo = (ys & 1) ? a.blf[3] : a.blf[1];
+  dst[0] = (DT)(v[0] - (le ? bo : be));
+  dst[1] = (DT)(v[1] - (le ? be : bo));
+  dst[2] = (DT)(v[2] - be);
+  dst[3] = (DT)(v[3] - bo);
+  dst[4] = (DT)(v[4] - be);
+  dst[5] = (DT)(v[5] - bo);
+  dst[6] = (DT)(v[6] - (re ? bo : be));
+  dst[7] = (DT)(v[7] - (re ? be : bo));
+}
+#endif
+
+// The same work item with a BRANCH-FREE row loop (float32 / 16-bit frames, whole short chain): every fetch is
+// unconditional (r2l_stream_fetch_row_bf; rows past the band's last needed row re-fetch that row: L1 hits), the prefetch
+// ring is indexed by the unroll position (U = lcm(window depth, PF) steps per group: no register copies), every group runs
+// in full and only the stores are predicated (rows past the band's end, lanes past the frame's last column: a clamped
+// strip).  hipcc then counts its vmcnt waits: a row step waits for the row it requested PF steps ago and for nothing else.
+#ifndef R2L_STREAM_BF
+#define R2L_STREAM_BF 2  // 0: off; 1: bilinear and Malvar2004; 2: Malvar2004 only (bilinear is faster in its round-1 form)
+#endif
+#ifndef R2L_STREAM_BF_PF_BILINEAR
+#define R2L_STREAM_BF_PF_BILINEAR 6
+#endif
+#ifndef R2L_STREAM_BF_PF_MALVAR
+#define R2L_STREAM_BF_PF_MALVAR 5
+#endif
+#ifndef R2L_STREAM_BF_BILINEAR_F32WIN
+#define R2L_STREAM_BF_BILINEAR_F32WIN 1
+#endif
+#ifndef R2L_STREAM_BF_SCALAR_EDGES
+#define R2L_STREAM_BF_SCALAR_EDGES 0  // 1: strip edges through scalar loads + lane shifts (measured slower, r04_ab_static_se.txt)
+#endif
+template <int DEB, int RAWK>
+R2L_HD void r2l_static_stream_item_bf(const R2LStaticStreamArgs& sa, int item, int lane) {
+  const R2LStaticArgs& a = sa.s;
+  constexpr int HALO = DEB ? 2 : 1, NR = 2 * HALO + 1;
+  constexpr bool LANES = (DEB == 0) && R2L_HAVE_LANE_SHIFTS;
+  constexpr int PF = DEB ? R2L_STREAM_BF_PF_MALVAR : R2L_STREAM_BF_PF_BILINEAR;
+  constexpr int U = (PF % NR == 0) ? PF : PF * NR;  // steps per unrolled group: a multiple of both ring sizes
+  static_assert(U % NR == 0 && U % PF == 0, "ring slots are compile-time indices");
+  const int seg = item % sa.nseg, r = item / sa.nseg;
+  const int band = r % sa.nband, b = r / sa.nband;
+  const int xs = seg * 256 + 4 * lane;
+  const bool in_w = xs < a.W;
+  const int x0 = in_w ? xs : a.W - 4;  // lanes past the last column walk the last 4 columns and store nothing
+  const int y0 = band * sa.band_h;
+  const int y1 = (y0 + sa.band_h < a.H) ? y0 + sa.band_h : a.H;
+  const bool le = x0 == 0, re = x0 + 4 >= a.W;
+  const size_t plane = (size_t)a.H * a.W;
+  const size_t img = (size_t)b * plane;
+  float* outb = a.out + (size_t)b * 3 * plane;
+  // (float32 window for bilinear too: 24 registers instead of 48, widened exactly where used -- what makes room for the
+  // deeper prefetch ring at three wavefronts per SIMD)
+  constexpr bool WF32 = DEB ? (R2L_STREAM_MALVAR_F32WIN != 0) : (R2L_STREAM_BF_BILINEAR_F32WIN != 0);
+  typedef typename R2LWinType<WF32>::type WT;
+  WT win[NR][8];
+  int par[NR];
+  // the lane's element offsets inside a row: its 4 columns, the pair on its left (x0 - 2; at the image's left edge its
+  // own columns) and on its right (x0 + 4; its own); LANES: xl = the pair on the lane's side of the wavefront
+  constexpr unsigned ESZ = (RAWK == R2L_RAW_U16) ? 2u : 4u;  // (as byte offsets: r2l_stream_fetch_row_bf / _s)
+  const unsigned xo = ESZ * (unsigned)x0, xleft = ESZ * (unsigned)(x0 + (le ? 0 : -2)), xright = ESZ * (unsigned)(x0 + (re ? 2 : 4));
+  const unsigned xl = LANES ? (lane < 32 ? xleft : xright) : xleft, xr = xright;
+  // scalar strip edges (R2L_STREAM_BF_SCALAR_EDGES): the pairs left of the strip's first and right of its last lane
+  const int sx0 = seg * 256;
+  const bool le0 = sx0 == 0;
+  const unsigned sbl = ESZ * (unsigned)(le0 ? 0 : sx0 - 2), sbr = ESZ * (unsigned)(sx0 + 256 + 2 <= a.W ? sx0 + 256 : a.W - 2);
+  (void)xl; (void)xr; (void)sbl; (void)sbr; (void)le0;
+  const int ylast = y1 - 1 + HALO;  // last source row (before the symmetric extension) this band needs
+#if R2L_STREAM_BF_SCALAR_EDGES
+  typedef R2LRowStageS<RAWK> StageT;
+#define R2L_BF_FETCH(ys_, st_) r2l_stream_fetch_row_s<RAWK>(a, img, (ys_), xo, sbl, sbr, (st_))
+#define R2L_BF_CONVERT(st_, dst_) r2l_stream_convert_row_s<RAWK, WT>(a, (st_), le0, le, re, (dst_))
+#else
+  typedef R2LRowStageT<RAWK> StageT;
+#define R2L_BF_FETCH(ys_, st_) r2l_stream_fetch_row_bf<RAWK, LANES>(a, img, (ys_), xo, xl, xr, le, re, (st_))
+#define R2L_BF_CONVERT(st_, dst_) r2l_stream_convert_row<RAWK, LANES, WT>(a, (st_), le, re, (dst_))
+#endif
+  {
+    StageT st;
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < NR - 1; ++i) {
+      const int ys = r2l_symmetric(y0 - HALO + i, a.H);
+      R2L_BF_FETCH(ys, st);
+      R2L_BF_CONVERT(st, win[i]);
+      par[i] = ys & 1;
+    }
+  }
+  StageT pf[PF];  // ring: step k consumes pf[k % PF] (row y + HALO) and refills it with row y + HALO + PF
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i) {
+    const int yr = (y0 + HALO + i < ylast) ? y0 + HALO + i : ylast;
+    R2L_BF_FETCH(r2l_symmetric(yr, a.H), pf[i]);
+  }
+  for (int yb = y0; yb < y1; yb += U) {
+#ifdef R2L_STREAM_PROGRESS_PRIO
+    R2L_PROGRESS_PRIO(yb - y0, y1 - y0);
+#endif
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < U; ++k) {
+      const int y = yb + k;
+      R2L_BF_CONVERT(pf[k % PF], win[(k + NR - 1) % NR]);
+      par[(k + NR - 1) % NR] = pf[k % PF].ys & 1;
+      {
+        const int yr = (y + HALO + PF < ylast) ? y + HALO + PF : ylast;
+        R2L_BF_FETCH(r2l_symmetric(yr, a.H), pf[k % PF]);
+      }
+      double d[4][3];
+      if constexpr (DEB == 0) {
+        if (y > 0 && y < a.H - 1) {
+          if (y & 1)
+            r2l_stream_bilinear_row_interior<1>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], le, re, d);
+          else
+            r2l_stream_bilinear_row_interior<0>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], le, re, d);
+        } else {
+          const int tpy[3] = {par[k % NR], par[(k + 1) % NR], par[(k + 2) % NR]};
+          r2l_stream_bilinear_row(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], tpy, le, re, d);
+        }
+      } else {
+        if (y & 1)
+          r2l_stream_malvar_rowT<1, WF32>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], win[(k + 3) % NR],
+                                          win[(k + 4) % NR], d);
+        else
+          r2l_stream_malvar_rowT<0, WF32>(win[k % NR], win[(k + 1) % NR], win[(k + 2) % NR], win[(k + 3) % NR],
+                                          win[(k + 4) % NR], d);
+      }
+      const int yc = y < y1 ? y : y1 - 1;  // (rows past the band's end: computed, not stored)
+      r2l_stream_finish_row(a, d, outb, plane, (size_t)yc * a.W + x0, in_w && y < y1);
+    }
+  }
+}
+
+#undef R2L_BF_FETCH
+#undef R2L_BF_CONVERT
+
 #define R2L_STREAM_NT 256  // 4 independent wavefronts per workgroup
 template <int DEB, int RAWK, bool LUMA>
 R2L_BLOCKFN void r2l_static_stream_block(const R2LStaticStreamArgs& sa, int bid, int nblk, float* lds) {
   (void)lds;
   (void)nblk;
+  bid = r2l_xcd_contiguous(bid, nblk);
   R2L_PHASE_BEGIN_N(R2L_STREAM_NT)
   const int item = bid * (R2L_STREAM_NT / 64) + (tid >> 6);  // one work item per wavefront
+#if R2L_STREAM_BF && !defined(R2L_EMUL)
+  if constexpr (!LUMA && RAWK != R2L_RAW_F64 && (R2L_STREAM_BF == 1 || DEB == 1)) {
+    // (the wavefront index as a SCALAR: the work item and its rows must not look lane-dependent)
+    const int witem = bid * (R2L_STREAM_NT / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (witem < sa.nitems) r2l_static_stream_item_bf<DEB, RAWK>(sa, witem, tid & 63);
+    return;
+  }
+#endif
   if (item < sa.nitems) r2l_static_stream_item<DEB, RAWK, LUMA>(sa, item, tid & 63);
   R2L_PHASE_END
 }

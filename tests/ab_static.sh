@@ -1,18 +1,14 @@
 #!/bin/bash
-# A/B of the static short chain (BASELINE config 3) on the GPU box: default build, then each tests/_build/lib_<v>.so,
-# optionally under R2L_STREAM_BANDS settings (BANDS="8 32 64")
+# A/B of device-library builds on the static chains (256x1024x1024 and 1024x512x512): tests/ab_static.sh lib.so ...
 cd "$(dirname "$0")/.."
-for v in default "$@"; do
-  if [ "$v" = default ]; then unset R2L_LIB_PATH; else export R2L_LIB_PATH=$PWD/tests/_build/lib_$v.so; fi
-  for nb in ${BANDS:-0}; do
-    if [ "$nb" = 0 ]; then unset R2L_STREAM_BANDS; else export R2L_STREAM_BANDS=$nb; fi
-    for deb in bilinear malvar2004; do
-      python bench.py --workload static --steps 30 --warmup 5 --no-cpu-baseline --debayer $deb 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-r=d['roofline']
-print('%-10s bands=%-3s %-10s %9.0f Mpix/s  %7.1f us  %6.1f GB/s  frac %.3f' % ('$v', '$nb', '$deb', d['value'], r['avg_us'], r['achieved'], r['frac']))
+for r in 1 2; do
+for lib in "$@"; do
+  for cfg in "--debayer bilinear" "--debayer bilinear --batch 1024 --size 512" "--debayer malvar2004" "--debayer bilinear --sharpening sharpening_filter --denoising gaussian_denoising"; do
+    R2L_LIB_PATH=$PWD/$lib python bench.py --workload static $cfg --steps 20 --warmup 12 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+o = json.loads(sys.stdin.readline())
+print('%-10s %-88s %.1f us  frac %.4f  wall ms %.4f' % ('$(basename $lib .so)', '$cfg', o['roofline']['avg_us'], o['roofline']['frac'], o['ms_per_step']))
 "
-    done
   done
+done
 done
