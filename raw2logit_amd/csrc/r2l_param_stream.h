@@ -24,6 +24,12 @@
 #ifndef R2L_FS_PF
 #define R2L_FS_PF 2
 #endif
+#ifndef R2L_FS_BF_FETCH
+#define R2L_FS_BF_FETCH 1
+#endif
+#ifndef R2L_FS_FULL_GROUPS
+#define R2L_FS_FULL_GROUPS 1
+#endif
 
 struct R2LFwdStreamArgs {
   R2LRaw raw;
@@ -99,6 +105,26 @@ R2L_HD void r2l_fs_fetch(const R2LFwdStreamArgs& a, size_t img0, int ym, int x0,
     const float* r = a.raw.f32 + e;
     s.c = r2l_stream_load_f4(r);
     if ((lane == 0 && !le) || (lane == 63 && !re)) s.e = (lane == 0) ? r[-1] : r[4];
+  }
+}
+// ... branch-free: every lane loads an edge value from an in-row address, only the strip's first / last lane use theirs
+// (a load under a lane-dependent or uniform condition in the row loop makes hipcc wait with vmcnt(0) in every step)
+template <bool U16>
+R2L_HD void r2l_fs_fetch_bf(const R2LFwdStreamArgs& a, size_t img0, int ym, int x0, bool le, bool re, int lane,
+                            R2LFsStage& s) {
+  const size_t e = img0 + (size_t)ym * a.W + x0;
+  const int eo = (lane < 32) ? (le ? 0 : -1) : (re ? 3 : 4);
+  s.ym = ym;
+  if (U16) {
+    const unsigned short* r = a.raw.u16 + e;
+    const r2l_f2 b = *(const r2l_f2*)r;
+    s.c.x = b.x;
+    s.c.y = b.y;
+    s.e = r2l_u2f((unsigned)r[eo]);
+  } else {
+    const float* r = a.raw.f32 + e;
+    s.c = r2l_stream_load_f4(r);
+    s.e = r[eo];
   }
 }
 // staged row -> 6 black-level-corrected values, columns x0-1 .. x0+4 (mirror padding at the image edges: column
@@ -298,13 +324,15 @@ R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc
   }
 }
 
-template <int NW, bool U16, int K, bool EPI>
+// K: ring position of the step (window / chroma-ring slots); PYQ: parity of row q; FULL: the driver runs every group of 6
+// steps in full (r2l_fwd_stream_block) -- rows past the band's end are computed and neither stored nor counted
+template <int NW, bool U16, int K, bool EPI, int PYQ = (K & 1), bool FULL = false>
 R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0, int y1, bool le, bool re,
                         int wave, int lane, float* ex, r2l_f4* fifo, float* ob, float* ypb, unsigned plane, int x0,
                         bool store_ok, const float mean[3], const float istd[3], float smask) {
   R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque(a.F));
   R2LFoldedRef Fh = R2L_FOLDED_REF(a.F);  // not laundered: the 25 blur weights stay in scalar registers (-1 %)
-  constexpr int PY = K & 1;
+  constexpr int PY = PYQ;
   const int H = a.H;
   const float* vu = st.v[(K + 2) % 3];  // V(q-1)
   const float* vm = st.v[K % 3];        // V(q)
@@ -410,7 +438,12 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
   }
   // ---- output row y = q-4 ------------------------------------------------------------------------------------
   const int y = q - 4;
-  if (y >= y0 && y < y1) {
+  const bool row_ok = y < y1;  // FULL: rows past the band's end (the padding steps of its last group)
+  if (FULL) {
+    store_ok = store_ok && row_ok;
+    smask = row_ok ? smask : 0.f;
+  }
+  if (y >= y0 && (FULL || row_ok)) {
     r2l_p2 ypp[2];
     {
       // window rows y-2 .. y+2 = q-6 .. q-2 sit in ring slots K .. K+4
@@ -419,10 +452,11 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
       for (int i = 0; i < 5; ++i)
         R2L_PRAGMA_UNROLL
       for (int j = 0; j < 8; ++j) yw[i][j] = st.yp[(K + i) % 6][j];
-      // the first / last two image rows take the weight sets with the mirror padding folded in
+      // the first / last two image rows take the weight sets with the mirror padding folded in (a padding row past the
+      // image's last row: any finite weights)
       const int set = (y < 2) ? y : (y - (H - 2)) + 2;
       const __attribute__((address_space(4))) float* w25 =
-          (y >= 2 && y < H - 2) ? &Fh.blur[0] : &F.blur_edge[0][0] + 25 * set;
+          ((y >= 2 && y < H - 2) || y >= H) ? &Fh.blur[0] : &F.blur_edge[0][0] + 25 * set;
       r2l_blur_row2w(yw, w25, ypp);
     }
     const r2l_f4* f = fifo + ((K + 2) % R2L_FS_FIFO_ROWS) * 2 * 64 + lane;  // row q-4
@@ -594,6 +628,53 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     for (int i = 0; i < 6; ++i)
       R2L_PRAGMA_UNROLL
     for (int j = 0; j < 8; ++j) st.yp[i][j] = 0.f;
+#if R2L_FS_FULL_GROUPS
+    // first luma row computed: qf = y0 - 3 (Y'(y0-2) needs Y(y0-3)); steps s = 0, 1, ... with q = qf + s, unrolled 6-fold:
+    // the ring position of a step is s mod 6 (every window slot a compile-time index), the parity of its row (s + 1) mod 2
+    // (bands start on even rows).  EVERY group of 6 runs in full and every fetch is unconditional (r2l_fs_fetch_bf, rows
+    // past the band's last raw row re-fetch that row): with a conditionally executed step or fetch in the loop hipcc
+    // waited with vmcnt(0) right behind each fetch -- for the row just requested and the previous rows' stores.  The
+    // padding steps of the last group (band_h + 7 steps: 22-row bands pad 1) finish rows >= y1, which are neither stored
+    // nor counted.
+    {
+      const int qf = y0 - 3, q1 = y1 + 4;  // q1: exclusive, = the last raw row the band consumes
+      {
+        R2LFsStage s0, s1;
+        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(qf - 1, a.H), x0, le, re, lane, s0);
+        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(qf, a.H), x0, le, re, lane, s1);
+        r2l_fs_convert<U16>(a, F, s0, le, re, st.v[2]);
+        r2l_fs_convert<U16>(a, F, s1, le, re, st.v[0]);
+      }
+      R2LFsStage pf[PF];  // ring: step s consumes pf[s % PF] (raw row q + 1) and refills it with row q + 1 + PF
+      R2L_PRAGMA_UNROLL
+      for (int i = 0; i < PF; ++i) {
+        const int rr = (qf + 1 + i < q1) ? qf + 1 + i : q1;
+        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(rr, a.H), x0, le, re, lane, pf[i]);
+      }
+      const int nsteps = q1 - qf;
+      for (int sb = 0; sb < nsteps; sb += 6) {
+        R2L_PROGRESS_PRIO(sb, nsteps);
+#define R2L_FS_STEP(K)                                                                                          \
+  {                                                                                                             \
+    const int q = qf + sb + K;                                                                                  \
+    r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
+    {                                                                                                           \
+      const int rr_ = (q + 1 + PF < q1) ? q + 1 + PF : q1;                                                      \
+      r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(rr_, a.H), x0, le, re, lane, pf[K % PF]);                         \
+    }                                                                                                           \
+    r2l_fs_step<NW, U16, K, EPI, (K + 1) & 1, true>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, \
+                                                   store_ok, mean, istd, smask);                                \
+  }
+        R2L_FS_STEP(0)
+        R2L_FS_STEP(1)
+        R2L_FS_STEP(2)
+        R2L_FS_STEP(3)
+        R2L_FS_STEP(4)
+        R2L_FS_STEP(5)
+#undef R2L_FS_STEP
+      }
+    }
+#else
     // first luma row computed: qf = y0 - 3 (Y'(y0-2) needs Y(y0-3)).  The loop is unrolled 6-fold with q = qb + K,
     // qb a multiple of 6, so that every window slot is a compile-time index; the first pass enters it at K0 = qf - q0
     // (the steps before qf are skipped, not computed), and the warm-up rows go to the slots that position implies.
@@ -636,7 +717,11 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     const int q = qb + K;                                                                                       \
     R2L_PROGRESS_PRIO_STEP(q - q0, q1 - q0);                                                                    \
     r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
-    if (q + 1 + PF <= q1) r2l_fs_fetch<U16>(a, img, r2l_mirror(q + 1 + PF, a.H), x0, le, re, lane, pf[K % PF]); \
+    if (R2L_FS_BF_FETCH) {                                                                                      \
+      const int rr_ = (q + 1 + PF < q1) ? q + 1 + PF : q1;                                                      \
+      r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(rr_, a.H), x0, le, re, lane, pf[K % PF]);                         \
+    } else if (q + 1 + PF <= q1)                                                                                \
+      r2l_fs_fetch<U16>(a, img, r2l_mirror(q + 1 + PF, a.H), x0, le, re, lane, pf[K % PF]);                     \
     r2l_fs_step<NW, U16, K, EPI>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, store_ok, mean, istd, smask); \
   }
       R2L_FS_STEP(0)
@@ -647,6 +732,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
       R2L_FS_STEP(5)
 #undef R2L_FS_STEP
     }
+#endif
     if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // exchange buffers free for the next item
     if (a.stat_partial) r2l_fs_lane_sums(st.acc, st.piv, store_ok ? 4.0 * (double)(y1 - y0) : 0.0, store_ok, lane, tots);
   }
