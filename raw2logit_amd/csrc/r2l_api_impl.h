@@ -172,6 +172,9 @@ R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GF
 #ifndef R2L_FS_OCC
 #define R2L_FS_OCC 3
 #endif
+#ifndef R2L_FS_STATS_KERNEL
+#define R2L_FS_STATS_KERNEL 1
+#endif
 #ifndef R2L_FS_MINBAND
 #define R2L_FS_MINBAND 16  // rows: shortest band of the row-streaming forward (7 halo rows of luma per band)
 #endif
@@ -187,6 +190,17 @@ R2L_FS_KERNEL(r2l_launch_fwd_stream_w1_u16, 1, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w2_u16, 2, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w4_u16, 4, true)
 R2L_FS_KERNEL(r2l_launch_fwd_stream_w8_u16, 8, true)
+// ... the statistics pass of train-mode BatchNorm (no output; keeps Y' when asked): its own instantiation
+#define R2L_FS_KERNEL_STATS(name, NW, U16)                                                              \
+  R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC_NW(NW), r2l_fwd_stream_block<NW, U16, false, true>)
+R2L_FS_KERNEL_STATS(r2l_launch_fwd_stream_stats_w1, 1, false)
+R2L_FS_KERNEL_STATS(r2l_launch_fwd_stream_stats_w2, 2, false)
+R2L_FS_KERNEL_STATS(r2l_launch_fwd_stream_stats_w4, 4, false)
+R2L_FS_KERNEL_STATS(r2l_launch_fwd_stream_stats_w8, 8, false)
+R2L_FS_KERNEL_STATS(r2l_launch_fwd_stream_stats_w1_u16, 1, true)
+R2L_FS_KERNEL_STATS(r2l_launch_fwd_stream_stats_w2_u16, 2, true)
+R2L_FS_KERNEL_STATS(r2l_launch_fwd_stream_stats_w4_u16, 4, true)
+R2L_FS_KERNEL_STATS(r2l_launch_fwd_stream_stats_w8_u16, 8, true)
 // ... with the output epilogue (flip / flip / rot90 of the output planes as part of the stores, R2LEpi)
 #define R2L_FS_KERNEL_EPI(name, NW, U16)                                                                \
   R2L_KERNEL_NT_LDS(name, R2LFwdStreamArgs, (NW) * 64, R2L_FS_LDS_FLOATS(NW), R2L_FS_OCC_NW(NW), r2l_fwd_stream_block<NW, U16, true>)
@@ -395,6 +409,27 @@ static int r2l_tile_grid(int ntiles, int cap) {
   int g = ntiles < cap ? ntiles : cap;
   if (g >= 8) g -= g % 8;
   return g < 1 ? 1 : g;
+}
+
+// Band height of the plane passes (r2l_param_stream.h, r2l_param_plane_bwd.h): a multiple of 6 rows (bands start on
+// multiples of 6: the ring slot of a row is the unroll position of its step), the one that needs the fewest rounds of
+// `slots` resident wavefronts x the rows a wavefront walks (+ 4 load-only warm-up steps + its start) -- 64x512x512 apply
+// pass: 24 rows = 2,816 wavefronts, one round at 3 per SIMD (65 us; 18 rows: 68.5; 12: 67.5; 36: 71.5,
+// profiles/r03_apply_kept.txt; re-swept under the progress-priority build, profiles/r04_bands.txt); 64x256x256: 6 rows.
+// `env`: override of diagnostic builds.
+static int r2l_band_rows(int B, int H, int W, long slots, const char* env) {
+  const long nstrip = (W + 255) / 256;
+  int bh = 6;
+  long best = -1;
+  for (int c = 6; c <= 48; c += 6) {
+    const long items = (long)B * nstrip * ((H + c - 1) / c);
+    const long cost = ((items + slots - 1) / slots) * (10L * c + 32);
+    if (best < 0 || cost < best) {
+      best = cost;
+      bh = c;
+    }
+  }
+  return (r2l_env_int(env, bh) + 5) / 6 * 6;
 }
 
 // ---- workspace ----------------------------------------------------------------------------------
@@ -626,24 +661,9 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     const bool epi = ep && ep->on && out;
     fa.ep = epi ? *ep : R2LEpi{0, 0, 0, 0};
     // The passes on the kept luma plane (r2l_param_stream.h: r2l_fwd_luma_block, r2l_fwd_apply_block): independent
-    // wavefronts, one per (image, band, 256-column strip).  Band height, a multiple of 6 (bands start on multiples of 6
-    // rows): the one that needs the fewest rounds of resident wavefronts x the rows a wavefront walks (+ 4 warm-up steps
-    // that only load, + its start) -- 64x512x512 apply pass: 24 rows = 2,816 wavefronts, one round at 3 per SIMD (65 us;
-    // 18 rows = 3,712 wavefronts: 68.5 us; 12: 67.5; 36: 71.5; profiles/r03_apply_kept.txt); 64x256x256: 6 rows
+    // wavefronts, one per (image, band, 256-column strip); band heights: r2l_band_rows
     const long nstrip = (W + 255) / 256;
-    auto band_rows = [&](long slots, const char* env) {
-      int bh = 6;
-      long best = -1;
-      for (int c = 6; c <= 48; c += 6) {
-        const long items = (long)B * nstrip * ((H + c - 1) / c);
-        const long cost = ((items + slots - 1) / slots) * (10L * c + 32);
-        if (best < 0 || cost < best) {
-          best = cost;
-          bh = c;
-        }
-      }
-      return (r2l_env_int(env, bh) + 5) / 6 * 6;
-    };
+    auto band_rows = [&](long slots, const char* env) { return r2l_band_rows(B, H, W, slots, env); };
     const bool kept_ok = !r2l_env_int("R2L_FWD_APPLY_RECOMPUTE", 0);
     // statistics pass = luma pass + statistics from the plane, where that is faster than the streaming forward without
     // output: frames one strip wide (64x256x256: 12 + 26 us against 46; 128x256x256: 17 + 36 against 61).  On 512-wide
@@ -694,6 +714,16 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
                                             {r2l_launch_fwd_apply_epi, r2l_launch_fwd_apply_epi_u16}};
       return atable[epi ? 1 : 0][raw.u16 ? 1 : 0](fa, (int)((grid + R2L_FA_NWV - 1) / R2L_FA_NWV), stream);
     }
+#if R2L_FS_STATS_KERNEL
+    if (!out && stats) {  // the statistics pass: its own instantiation (no output code, fewer live scalars)
+      static const launch_t stable[2][4] = {
+          {r2l_launch_fwd_stream_stats_w1, r2l_launch_fwd_stream_stats_w2, r2l_launch_fwd_stream_stats_w4,
+           r2l_launch_fwd_stream_stats_w8},
+          {r2l_launch_fwd_stream_stats_w1_u16, r2l_launch_fwd_stream_stats_w2_u16, r2l_launch_fwd_stream_stats_w4_u16,
+           r2l_launch_fwd_stream_stats_w8_u16}};
+      return stable[raw.u16 ? 1 : 0][nw](fa, sgrid, stream);
+    }
+#endif
     return table[epi ? 1 : 0][raw.u16 ? 1 : 0][nw](fa, sgrid, stream);
   }
 #endif
@@ -825,18 +855,8 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   if (saved && planes && !r2l_env_int("R2L_BWD1_TILED", 0)) {
     // persistent workgroups of 4 independent wavefronts, two per CU (<= 256 VGPRs), not more workgroups than kernel B2
     // runs (its last workgroups reduce both kernels' partials); band height as for the forward's plane passes
-    const long nstrip = (W + 255) / 256, slots = 256L * 4 * 2;
-    int bh = 6;
-    long best = -1;
-    for (int c = 6; c <= 48; c += 6) {
-      const long items = (long)B * nstrip * ((H + c - 1) / c);
-      const long cost = ((items + slots - 1) / slots) * (10L * c + 32);
-      if (best < 0 || cost < best) {
-        best = cost;
-        bh = c;
-      }
-    }
-    a1.band_h = (r2l_env_int("R2L_BP_BAND", bh) + 5) / 6 * 6;
+    const long nstrip = (W + 255) / 256;
+    a1.band_h = r2l_band_rows(B, H, W, 256L * 4 * 2, "R2L_BP_BAND");
     const long items = (long)B * nstrip * ((H + a1.band_h - 1) / a1.band_h);
     long g = (items + R2L_BP_NWV - 1) / R2L_BP_NWV;
     const long cap = r2l_env_int("R2L_GRID_BWD1", 512);
@@ -854,20 +874,8 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
     // when B2 runs as plane passes too
     blur_hp = !r2l_env_int("R2L_BWD2_TILED", 0) && !r2l_env_int("R2L_BWD_SPLIT_BLUR", 0);
     a1.hp = ws.hp;
-    {  // (its own band height: R2L_HB_OCC wavefronts per SIMD; not more workgroups than wrote the first pass's partials)
-      const long slots_hb = 256L * 4 * R2L_HB_OCC;
-      int bh = 6;
-      long best = -1;
-      for (int c = 6; c <= 48; c += 6) {
-        const long items = (long)B * ((W + 255) / 256) * ((H + c - 1) / c);
-        const long cost = ((items + slots_hb - 1) / slots_hb) * (10L * c + 32);
-        if (best < 0 || cost < best) {
-          best = cost;
-          bh = c;
-        }
-      }
-      a1.band_hb = (r2l_env_int("R2L_HB_BAND", bh) + 5) / 6 * 6;
-    }
+    // (its own band height: R2L_HB_OCC wavefronts per SIMD; not more workgroups than wrote the first pass's partials)
+    a1.band_hb = r2l_band_rows(B, H, W, 256L * 4 * R2L_HB_OCC, "R2L_HB_BAND");
     if (!e1) e1 = blur_hp ? r2l_launch_bwd1_blur_hp(a1, g1p, stream) : r2l_launch_bwd1_blur(a1, g1p, stream);
 #else
     e1 = 0;
@@ -903,19 +911,7 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   if (g1p && !r2l_env_int("R2L_BWD2_TILED", 0)) {
     // kernel B2 as two passes over planes (r2l_param_plane_bwd.h)
     const long nstrip = (W + 255) / 256;
-    auto band_rows = [&](long slots, const char* env) {
-      int bh = 6;
-      long best = -1;
-      for (int c = 6; c <= 48; c += 6) {
-        const long items = (long)B * nstrip * ((H + c - 1) / c);
-        const long cost = ((items + slots - 1) / slots) * (10L * c + 32);
-        if (best < 0 || cost < best) {
-          best = cost;
-          bh = c;
-        }
-      }
-      return (r2l_env_int(env, bh) + 5) / 6 * 6;
-    };
+    auto band_rows = [&](long slots, const char* env) { return r2l_band_rows(B, H, W, slots, env); };
     a2.hp = ws.hp;
     a2.band_h = band_rows(256L * 4 * 4, "R2L_HP_BAND");
     const long hitems = (long)B * nstrip * ((H + a2.band_h - 1) / a2.band_h);

@@ -579,7 +579,9 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
   }
 }
 
-template <int NW, bool U16, bool EPI = false>
+// SONLY: the statistics pass of train-mode BatchNorm as its own instantiation -- no output, no BatchNorm constants, no
+// epilogue: fewer live scalars (the general kernel parks ~25 of them per row step in vector lanes, v_readlane_b32)
+template <int NW, bool U16, bool EPI = false, bool SONLY = false>
 R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -593,14 +595,14 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
   const bool le = x0 == 0, re = x0 + 4 >= a.W;
   const unsigned plane = (unsigned)a.H * (unsigned)a.W;
   float mean[3] = {0.f, 0.f, 0.f}, istd[3] = {1.f, 1.f, 1.f};
-  if (a.bn) {
+  if (!SONLY && a.bn) {
     R2L_PRAGMA_UNROLL
     for (int k = 0; k < 3; ++k) {
       mean[k] = a.bn[k];
       istd[k] = a.bn[3 + k];
     }
   }
-  const float smask = (a.stat_partial && store_ok) ? 1.f : 0.f;  // does this lane's pixel count in the statistics?
+  const float smask = ((SONLY || a.stat_partial) && store_ok) ? 1.f : 0.f;  // does this lane's pixel count in the statistics?
   R2LFsState st;
   // statistics: float32 pair accumulators per work item (<= band_h x 4 pixels per lane); after every item the
   // wavefront adds its 64 lane sums (float64, fixed butterfly order) into its float64 totals in LDS -- the rounding
@@ -615,7 +617,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     const int y0 = band * a.band_h;
     const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
     const size_t img = (size_t)b * plane;
-    float* ob = a.out ? a.out + (size_t)b * 3 * plane : nullptr;
+    float* ob = (!SONLY && a.out) ? a.out + (size_t)b * 3 * plane : nullptr;
     float* ypb = a.yp_out ? a.yp_out + (size_t)b * plane : nullptr;
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < 6; ++i) st.acc[i] = r2l_splat2(0.f);
@@ -662,8 +664,8 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
       const int rr_ = (q + 1 + PF < q1) ? q + 1 + PF : q1;                                                      \
       r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(rr_, a.H), x0, le, re, lane, pf[K % PF]);                         \
     }                                                                                                           \
-    r2l_fs_step<NW, U16, K, EPI, (K + 1) & 1, true>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, \
-                                                   store_ok, mean, istd, smask);                                \
+    r2l_fs_step<NW, U16, K, EPI, (K + 1) & 1, true>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo,             \
+                                                   SONLY ? nullptr : ob, ypb, plane, x0, store_ok, mean, istd, smask); \
   }
         R2L_FS_STEP(0)
         R2L_FS_STEP(1)
@@ -734,9 +736,9 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     }
 #endif
     if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // exchange buffers free for the next item
-    if (a.stat_partial) r2l_fs_lane_sums(st.acc, st.piv, store_ok ? 4.0 * (double)(y1 - y0) : 0.0, store_ok, lane, tots);
+    if (SONLY || a.stat_partial) r2l_fs_lane_sums(st.acc, st.piv, store_ok ? 4.0 * (double)(y1 - y0) : 0.0, store_ok, lane, tots);
   }
-  if (a.stat_partial) r2l_fs_stats_finish<NW, NT>(a, bid, nblk, tid, wave, tots, red);
+  if (SONLY || a.stat_partial) r2l_fs_stats_finish<NW, NT>(a, bid, nblk, tid, wave, tots, red);
 }
 
 // ================================================================================================

@@ -94,6 +94,10 @@ while time.time() - t0 < budget:
                                                                   if obn else None))[0], dtype=np.float64)
     finally:
         orc.REVERSE_TAP_ORDER = False
+    # (sanity of the whole set-up: the A-PRIORI float32 rounding bound of the chain -- rigorous, 15-30 x above what
+    # float32 arithmetic actually does -- must hold for the kernels and for the float32 oracle at every pixel)
+    bound, _ = pc.rounding_bound(raw_np, P, cache, bn != 'none')
+    worst['bound'] = max(worst.get('bound', 0.0), float((eo / bound).max()), float((np.abs(o32 - o) / bound).max()))
     lim_px = pc.sigma_limit(tol, P, cache, c32, bn != 'none')
     lim_lit = pc.pixel_limit(tol, o32, o)
     eb = np.abs(o32b - o)
@@ -149,6 +153,10 @@ if failures:
 print(f'{n} random cases ok in {time.time() - t0:.0f} s; worst out error / max(tolerance, 6 sigma of the float32 oracle) '
       f'{worst["out"]:.2f} (control = a second float32 evaluation of the oracle: {worst["ctrl"]:.2f}); '
       f'worst grad error / limit {worst["grad"]:.2f}')
-print(f'   for information: worst out error / tolerance alone {worst["out_tol"]:.2f}; literal per-pixel form max(tolerance, 2 x '
+if worst.get('bound', 0.0) > 1.0:
+    print(f'FAIL: an output left the a-priori float32 rounding bound (ratio {worst["bound"]:.2f})')
+    raise SystemExit(1)
+print(f'   for information: worst error / a-priori rounding bound (kernels and float32 oracle) {worst.get("bound", 0.0):.3f}; '
+      f'worst out error / tolerance alone {worst["out_tol"]:.2f}; literal per-pixel form max(tolerance, 2 x '
       f'|oracle32 - oracle64| over 3x3): kernels worst {worst["lit"]:.2f}, {worst["n_lit"]} of {n} cases over 1; control worst '
       f'{worst["lit_ctrl"]:.2f}, {worst["n_lit_ctrl"]} of {n} cases over 1')

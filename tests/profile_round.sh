@@ -4,7 +4,7 @@
 # Results land in gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
