@@ -114,6 +114,11 @@ def parse():
                     help='replay the whole step as ONE HIP graph (raw2logit_amd/graphs.py: StepGraph): the step costs the '
                          'host one graph launch instead of two C-ABI calls + autograd; matters below ~8 Mpix per step, '
                          'where the host is the bound (single GPU)')
+    ap.add_argument('--graph-also', action='store_true',
+                    help='several ranks over RCCL: after the eager measurement, time the same data-parallel step as ONE HIP '
+                         'graph with its collectives captured (ms_per_step_graph / value_graph in the line).  Opt-in: a '
+                         'capture that fails on one rank only would leave the others inside a collective, and the headline '
+                         'line is printed last')
     ap.add_argument('--no-small-shapes', action='store_true',
                     help="skip the small_shapes sub-records (the datasets' 256x256 tiles: BASELINE configs 4 / 5 per GPU)")
     ap.add_argument('--raw-u16', action='store_true',
@@ -677,7 +682,7 @@ def main():
                         'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
 
     graph_ms = graph_err = None
-    if world > 1 and nccl and dev.type == 'cuda' and not args.graph:
+    if world > 1 and nccl and dev.type == 'cuda' and not args.graph and args.graph_also:
         # the same data-parallel step as ONE HIP graph with its RCCL collectives captured (raw2logit_amd/graphs.py): at
         # BASELINE config 5's 64 x 256 x 256 per GPU the eager step is host-bound, and every rank pays the host twice more
         # around the two all-gathers
