@@ -439,7 +439,7 @@ struct R2LWorkspace {
   float* part_b2;
   float* part_small;
   double* sums;
-  double* gpartial;    // [R2L_NSUMS][R2L_MAX_GROUPS] group partials of the in-kernel final reductions
+  double* gpartial;    // [R2L_MAX_GROUPS][R2L_NSUMS] group partials of the in-kernel final reductions
   unsigned* counters;  // [1 + R2L_MAX_GROUPS] arrival counters: zeroed by the fold kernel, zero after every launch
   float* gypp;
   float* yp;     // (B,H,W): the sharpened luma Y' of the forward, for kernel B1 (R2L_F_KEEP_LUMA)
@@ -642,7 +642,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     long cap = r2l_env_int("R2L_GRID_FWD", (int)(resident < R2L_MAX_BLOCKS ? resident : R2L_MAX_BLOCKS));
     if (cap > R2L_MAX_BLOCKS) cap = R2L_MAX_BLOCKS;
     const int sgrid = (int)(nitems < cap ? nitems : cap);
-    fa.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, stats ? ws.counters : nullptr, 12, 0};
+    fa.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, (stats && !(r2l_env_int("R2L_EXP_NO_TREE", 0) & 1)) ? ws.counters : nullptr, 12, 0};
     fa.stats_out = stats;
     if (fin)
       fa.fin = *fin;
@@ -794,7 +794,7 @@ int r2l_bn_bwd_reduce(const float* grad_out, const float* out, const double* tot
   int grid = nitems < (size_t)cap ? (int)nitems : cap;
   // a workspace that went through r2l_isp_fwd / r2l_isp_bwd has valid arrival counters: the last workgroups
   // of the launch finish the reduction; otherwise a second, tiny launch does
-  const bool in_kernel = (flags & R2L_F_FOLDED_VALID) != 0;
+  const bool in_kernel = (flags & R2L_F_FOLDED_VALID) != 0 && !(r2l_env_int("R2L_EXP_NO_TREE", 0) & 2);
   R2LBnReduceArgs a{grad_out, out, ws.part_small, B, H, W,
                     R2LTree{ws.part_small, nullptr, ws.gpartial, in_kernel ? ws.counters : nullptr, 6, 0},
                     sums, totals, bn_bwd};
@@ -894,6 +894,10 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   // bwd2 fits two workgroups per CU (<= 128 VGPRs, 68 KB of LDS): 512 workgroups
   const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", R2L_OCC_BWD2 >= 4 ? 512 : 256));
   R2LBwd2Args a2;
+  a2.nmain = 0;
+  a2.b1_partial = nullptr;
+  a2.b1_n = 0;
+  a2.b1_tot = nullptr;
   a2.raw = raw;
   a2.F = ws.folded;
   a2.gypp = ws.gypp;
@@ -926,12 +930,19 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
     long gs = (sitems + R2L_B2S_NWV - 1) / R2L_B2S_NWV;
     const long cap = r2l_env_int("R2L_GRID_BWD2", 768);  // 3 workgroups of 4 wavefronts per CU
     if (gs > cap) gs = cap;
-    if (gs < g1w) gs = g1w;  // its last workgroups add B1's partials too: not fewer workgroups than wrote those
     if (gs > R2L_MAX_BLOCKS) gs = R2L_MAX_BLOCKS;
-    a2.tree = R2LTree{ws.part_b1, ws.part_b2, ws.gpartial, ws.counters, R2L_B1_NACC, g1w};
+    // its last workgroups reduce B2's partials; R2L_B2S_HELPERS more workgroups (the grid leaves room for them beside one
+    // round of the others) add B1's meanwhile; the last arrival of all unfolds the 155 totals into the 132 gradients
+    const bool tree = !(r2l_env_int("R2L_EXP_NO_TREE", 0) & 4);
+    a2.tree = R2LTree{nullptr, ws.part_b2, ws.gpartial, tree ? ws.counters : nullptr, 0, 0};
+    a2.nmain = (int)gs;
+    a2.b1_partial = ws.part_b1;
+    a2.b1_n = g1w;
+    a2.b1_tot = ws.sums;
     a2.params = params;
     a2.grad_params = grad_params;
-    return raw.u16 ? r2l_launch_bwd2_sums_u16(a2, (int)gs, stream) : r2l_launch_bwd2_sums(a2, (int)gs, stream);
+    const int grid = (int)gs + (tree ? R2L_B2S_HELPERS : 0);
+    return raw.u16 ? r2l_launch_bwd2_sums_u16(a2, grid, stream) : r2l_launch_bwd2_sums(a2, grid, stream);
   }
 #endif
   const bool in_kernel = g1w <= g2;
@@ -1766,6 +1777,11 @@ int r2l_l2_bwd(const float* x, const float* y, const float* grad_sum, float* gra
 
 #ifdef R2L_TEST_HOOKS
 // diagnostic builds: where the per-phase cycle stamps of -DR2L_EXP_STAMPS builds land in the workspace (tests/stamps.py)
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+int r2l_test_tail_stamps(unsigned long long* out32) {  // (tests/tail_timeline.py)
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(r2l_tail_ts), sizeof(unsigned long long) * 32);
+}
+#endif
 size_t r2l_test_debug_offset(int B, int H, int W) {
   const R2LWorkspace ws = r2l_carve((void*)0, B, H, W);
   return (size_t)((char*)ws.debug - (char*)0);

@@ -245,6 +245,20 @@ R2L_HD void r2l_glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 #define R2L_LN2 0.69314718055994530942
 
+// diagnostic builds (-DR2L_EXP_STAMPS): s_memrealtime (100 MHz) at the stations of a launch's tail -- end of the item loop,
+// partials stored, tickets, tree levels, unfold -- as seen by thread 0 of whichever workgroup passes a station last
+// (= the launch's last workgroup); slots 0-9 statistics pass, 10-19 bn_reduce, 20-29 B2's sums pass.  tests/tail_timeline.py
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+__device__ unsigned long long r2l_tail_ts[32];
+#define R2L_TAILST(k)                                                                 \
+  do {                                                                                \
+    if (threadIdx.x == 0) r2l_tail_ts[k] = __builtin_amdgcn_s_memrealtime();          \
+  } while (0)
+#else
+#define R2L_TAILST(k)
+#endif
+#define R2L_TAIL_BASE(NSLOTS) ((NSLOTS) == 12 ? 0 : ((NSLOTS) == 6 ? 10 : 20))
+
 // Primitives of the in-kernel final reductions.  Partials travel between workgroups (possibly on different
 // XCDs, whose L2s are not coherent with each other) through device-coherent accesses: relaxed agent-scope
 // atomic stores / loads, which write through / read past the local L2.  A full agent-scope fence would work
@@ -552,6 +566,7 @@ R2L_HD const __attribute__((address_space(4))) T* r2l_kernargs() {
 // element (k, c) of T = M_RGB_2_YUV * colour_correction * diag(white_balance), float64
 R2L_HD double r2l_fold_T_one(const float* P, int k, int c) {
   double s = 0;
+  R2L_PRAGMA_UNROLL
   for (int j = 0; j < 3; ++j) s += (double)P[R2L_P_M_RGB2YUV + k * 3 + j] * (double)P[R2L_P_CCM + j * 3 + c];
   return s * (double)P[R2L_P_WHITE_BALANCE + c];
 }
@@ -560,6 +575,7 @@ R2L_HD double r2l_fold_A_one(const float* P, int k, int par, int t) {
   const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
   const int c = r2l_site_channel(py + dy + 2, px + dx + 2);
   double s = 0;
+  R2L_PRAGMA_UNROLL
   for (int j = 0; j < 3; ++j) s += r2l_fold_T_one(P, k, j) * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
   return s;
 }
@@ -647,11 +663,13 @@ R2L_HD double r2l_unfold_gT(const float* P, const double* S, int k, int j) {
   const double* b2 = S + R2L_B1_NACC;
   const double* GA = (k == 0) ? (b2 + R2L_B2_GAY) : (k == 1 ? b1 + R2L_B1_GAU : b1 + R2L_B1_GAV);
   double s = 0;
+  R2L_PRAGMA_UNROLL
   for (int par = 0; par < 4; ++par)
-    for (int t = 0; t < 9; ++t) {
-      const int c = r2l_site_channel((par >> 1) + t / 3 + 1, (par & 1) + t % 3 + 1);
-      s += GA[par * 9 + t] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
-    }
+    R2L_PRAGMA_UNROLL
+  for (int t = 0; t < 9; ++t) {  // (unrolled: the channel of a tap is a constant then, the 72 LDS reads go out as a batch)
+    const int c = r2l_site_channel((par >> 1) + t / 3 + 1, (par & 1) + t % 3 + 1);
+    s += GA[par * 9 + t] * (double)P[R2L_P_DEBAYER + (j * 3 + c) * 9 + t];
+  }
   return s;
 }
 // black_level[site] gets  - sum_{k, par, t : site(par, t) == site} A[k][par][t] * S_k[par]  (S_k[par] = sum of gK over
@@ -660,13 +678,20 @@ R2L_HD double r2l_unfold_bl_part(const double* S, const double* TG, int site, in
   const double* b1 = S;
   const double* b2 = S + R2L_B1_NACC;
   const double* SS = (k == 0) ? (b2 + R2L_B2_SY) : (k == 1 ? b1 + R2L_B1_SU : b1 + R2L_B1_SV);
+  // (unrolled, every product formed and the ones of other sites dropped by a select: the LDS reads go out as one batch;
+  // as a loop with a `continue` this was a chain of 36 dependent read + fma steps, 2 us of the launch's tail)
+  const double* A = TG + 18 + k * 36;
   double g = 0;
-  for (int par = 0; par < 4; ++par)
+  R2L_PRAGMA_UNROLL
+  for (int par = 0; par < 4; ++par) {
+    const double ss = SS[par];
+    R2L_PRAGMA_UNROLL
     for (int t = 0; t < 9; ++t) {
       const int py = par >> 1, px = par & 1, dy = t / 3 - 1, dx = t % 3 - 1;
-      if ((((py + dy + 2) & 1) * 2 + ((px + dx + 2) & 1)) != site) continue;
-      g -= TG[18 + (k * 4 + par) * 9 + t] * SS[par];  // folded A[k][par][t], float64
+      const double prod = A[par * 9 + t] * ss;  // folded A[k][par][t], float64
+      g -= ((((py + dy + 2) & 1) * 2 + ((px + dx + 2) & 1)) == site) ? prod : 0.0;
     }
+  }
   return g;
 }
 // Unfold the reduced sums into the gradient of trainable parameter `o` (index into the packed block);
@@ -688,10 +713,15 @@ R2L_HD float r2l_unfold_one(const float* P, const double* S, int o, const double
     const int e = o - R2L_P_DEBAYER, j = e / 27, c = (e % 27) / 9, t = e % 9;
     const int dy = t / 3 - 1, dx = t % 3 - 1;
     double g = 0;
+    R2L_PRAGMA_UNROLL
     for (int k = 0; k < 3; ++k) {
       const double* GA = (k == 0) ? (b2 + R2L_B2_GAY) : (k == 1 ? b1 + R2L_B1_GAU : b1 + R2L_B1_GAV);
-      for (int par = 0; par < 4; ++par)
-        if (r2l_site_channel((par >> 1) + dy + 2, (par & 1) + dx + 2) == c) g += T[k * 3 + j] * GA[par * 9 + t];
+      const double tk = T[k * 3 + j];
+      R2L_PRAGMA_UNROLL
+      for (int par = 0; par < 4; ++par) {
+        const double prod = tk * GA[par * 9 + t];
+        g += (r2l_site_channel((par >> 1) + dy + 2, (par & 1) + dx + 2) == c) ? prod : 0.0;
+      }
     }
     return (float)g;
   }

@@ -562,7 +562,7 @@ R2L_HD void r2l_rows_3x6(const float* Pl, int tx, int frow, float w[3][6]) {
 struct R2LTree {
   const float* partial;   // [split][nblk]
   const float* partial2;  // [nslots - split][nblk] (slots >= split), may be null when split == nslots
-  double* gpartial;       // [nslots][R2L_MAX_GROUPS]
+  double* gpartial;       // [group][nslots] (room for R2L_MAX_GROUPS x R2L_NSUMS)
   unsigned* counters;     // [1 + R2L_MAX_GROUPS]; null: no in-kernel reduction
   int split;
   int nblk1;  // workgroups that wrote `partial` (slots < split), when that was another launch with another grid
@@ -570,125 +570,221 @@ struct R2LTree {
 };
 // Returns true (uniformly over the workgroup) in the ONE workgroup that arrives last; out[0..NSLOTS) then
 // holds the totals.  `out` may be LDS or global memory; lds4: 4 floats of LDS scratch for the tickets;
-// scratch: LDS staging area of scratch_n doubles (>= NSLOTS * R2L_TREE_GROUP floats and >= R2L_MAX_GROUPS
-// doubles).  The coherent loads are spread over all lanes and staged through LDS, so that their latency is
-// paid once per level rather than once per addend; the additions then run in a fixed order from LDS.
-template <int NSLOTS, int NT = R2L_NT>
-R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* lds4, double* out, double* scratch,
-                                 int scratch_n) {
+// scratch: LDS staging area of scratch_n doubles (>= 16 NSLOTS).
+// This is the tail of its launch -- the last workgroup runs it with the rest of the chip idle -- so it is written for
+// latency: a lane issues all the coherent loads of its slot as one batch into registers and adds them in a fixed order
+// from there (parked in LDS and added by a loop of dependent LDS reads, level 2 alone took 5.5 / 2.6 / 7.6 us of the
+// statistics / bn_reduce / sums launches: profiles/r04_tails.txt); group partials are laid out [group][slot], so the
+// level-2 loads of neighbouring lanes are neighbours; with few slots, P lanes share a slot's groups (group q goes to
+// lane q mod P) and their P sums are added in lane order.
+#ifndef R2L_EMUL
+template <int CTRL>
+R2L_HD double r2l_dpp_add_f64(double d) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, d);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return d + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+R2L_HD double r2l_row16_sum(double d) {  // every lane: the sum over its row of 16 lanes (the order depends on the lane only)
+  d = r2l_dpp_add_f64<0xb1>(d);          // quad_perm:[1,0,3,2]
+  d = r2l_dpp_add_f64<0x4e>(d);          // quad_perm:[2,3,0,1]
+  d = r2l_dpp_add_f64<0x124>(d);         // row_ror:4
+  return r2l_dpp_add_f64<0x128>(d);      // row_ror:8
+}
+#endif
+template <int NSLOTS, int NT>
+struct R2LTreeShape {
+  static constexpr int P0 = NT / NSLOTS;
+  static constexpr int P = P0 >= 16 ? 16 : (P0 >= 8 ? 8 : (P0 >= 4 ? 4 : (P0 >= 2 ? 2 : 1)));  // lanes per slot, level 2
+  // loads in flight per lane, level 2: one batch up to 768 workgroups (many slots) / all of a lane's groups (few)
+  static constexpr int CH = NSLOTS >= 64 ? 48 : (R2L_MAX_GROUPS / P < 16 ? R2L_MAX_GROUPS / P : 16);
+};
+struct R2LNoWork {
+#ifdef R2L_EMUL
+  void operator()(int) const {}
+#else
+  __device__ void operator()(int) const {}
+#endif
+};
+// Level 1: true (uniformly over the workgroup) in the workgroup that arrives last in its group of 16, after it has stored the
+// group's partial of every slot.  `meanwhile(tid)`: work of every thread that does not depend on the totals, run while
+// the ticket travels.
+template <int NSLOTS, int NT = R2L_NT, class MEANWHILE = R2LNoWork>
+R2L_BLOCKFN bool r2l_tree_level1(const R2LTree& tr, int bid, int nblk, float* lds4, MEANWHILE&& meanwhile = R2LNoWork()) {
   unsigned* lu = (unsigned*)lds4;
-  float* sf = (float*)scratch;
-  const int g = bid / R2L_TREE_GROUP, ngroups = (nblk + R2L_TREE_GROUP - 1) / R2L_TREE_GROUP;
+  const int g = bid / R2L_TREE_GROUP;
   const int g0 = g * R2L_TREE_GROUP;
   const int gsize = (nblk - g0 < R2L_TREE_GROUP) ? nblk - g0 : R2L_TREE_GROUP;
   R2L_PHASE_BEGIN
-  if (tid == 0) lu[0] = r2l_ticket(tr.counters + 1 + g);
+  unsigned t1 = 0;
+  if (tid == 0) t1 = r2l_ticket(tr.counters + 1 + g);
+  meanwhile(tid);
+  if (tid == 0) lu[0] = t1;
   R2L_PHASE_END
   if (lu[0] + 1 != (unsigned)gsize) return false;
+  R2L_TAILST(R2L_TAIL_BASE(NSLOTS) + 2);
   R2L_PHASE_BEGIN
   if (tid == 0) tr.counters[1 + g] = 0;
-  // the coherent loads of a lane are issued as one batch (all in flight together) and parked in LDS afterwards: as
-  // `sf[idx] = load(...)` in a plain loop each of them was a round trip of its own, five in a row for kernel B2's 155
-  // slots -- on the critical path of the launch's last workgroup
   {
-    constexpr int NB1 = (NSLOTS * R2L_TREE_GROUP + NT - 1) / NT;
-    float v1[NB1];
     const int n1 = tr.nblk1 > 0 ? tr.nblk1 : nblk;
+#ifdef R2L_EMUL
+    for (int sl = tid; sl < NSLOTS; sl += NT) {
+      const bool first = sl < tr.split;
+      const float* src = first ? tr.partial + (size_t)sl * n1 + g0 : tr.partial2 + (size_t)(sl - tr.split) * nblk + g0;
+      int lim = first ? n1 - g0 : gsize;  // (the other launch may have written fewer workgroups' partials)
+      if (lim > gsize) lim = gsize;
+      double acc = 0.0;
+      for (int m = 0; m < lim; ++m) acc += (double)r2l_load_coherent(src + m);
+      r2l_store_coherent(tr.gpartial + (size_t)g * NSLOTS + sl, acc);
+    }
+#else
+    // sixteen neighbouring lanes take the sixteen workgroups of a slot (one 64-byte run of the slot's row), all loads of a
+    // lane in one batch -- unconditional, from clamped addresses, zeros selected afterwards: a load under a condition is a
+    // branch with its own wait -- and the sixteen are added in registers (DPP: pairs, quads, the row's quads)
+    static_assert(NT % 16 == 0 && R2L_TREE_GROUP == 16, "a row of 16 lanes per slot");
+    constexpr int NB1 = (NSLOTS * 16 + NT - 1) / NT;
+    float v1[NB1];
     R2L_PRAGMA_UNROLL
     for (int it = 0; it < NB1; ++it) {
-      const int idx = tid + it * NT;
-      v1[it] = 0.f;
-      if (idx < NSLOTS * gsize) {
-        const int sl = idx / gsize, m = idx - sl * gsize;
-        if (sl < tr.split)
-          v1[it] = (g0 + m < n1) ? r2l_load_coherent(tr.partial + (size_t)sl * n1 + g0 + m) : 0.f;
-        else
-          v1[it] = r2l_load_coherent(tr.partial2 + (size_t)(sl - tr.split) * nblk + g0 + m);
-      }
+      const int idx = tid + it * NT, m = idx & 15;
+      const int sl = (idx >> 4) < NSLOTS ? (idx >> 4) : NSLOTS - 1;
+      const bool first = sl < tr.split;
+      const float* src = first ? tr.partial + (size_t)sl * n1 + g0 : tr.partial2 + (size_t)(sl - tr.split) * nblk + g0;
+      int lim = first ? n1 - g0 : gsize;  // (the other launch may have written fewer workgroups' partials)
+      if (lim > gsize) lim = gsize;
+      const int last = lim > 0 ? lim - 1 : 0;
+      v1[it] = r2l_load_coherent(src + (m < last ? m : last));
+      if (m >= lim) v1[it] = 0.f;
     }
     R2L_PRAGMA_UNROLL
     for (int it = 0; it < NB1; ++it) {
       const int idx = tid + it * NT;
-      if (idx < NSLOTS * gsize) sf[idx] = v1[it];
+      const double d = r2l_row16_sum((double)v1[it]);
+      if ((idx & 15) == 0 && (idx >> 4) < NSLOTS) r2l_store_coherent(tr.gpartial + (size_t)g * NSLOTS + (idx >> 4), d);
     }
-  }
-  R2L_PHASE_END
-  R2L_PHASE_BEGIN
-  for (int sl = tid; sl < NSLOTS; sl += NT) {
-    double acc = 0.0;
-    for (int m = 0; m < gsize; ++m) acc += (double)sf[sl * gsize + m];
-    r2l_store_coherent(tr.gpartial + (size_t)sl * R2L_MAX_GROUPS + g, acc);
+#endif
   }
   R2L_STORES_DONE();
   R2L_PHASE_END
+  R2L_TAILST(R2L_TAIL_BASE(NSLOTS) + 4);
+  return true;
+}
+// Level 2, for the workgroups level 1 let through (and `extra` more arrivals: workgroups that contribute something else the
+// last one needs): true (uniformly) in the ONE workgroup that arrives last; out[0..NSLOTS) then holds the totals.
+struct R2LNoExtra {
+#ifdef R2L_EMUL
+  double fetch(int) const { return 0.0; }
+  void put(int, double) const {}
+#else
+  __device__ double fetch(int) const { return 0.0; }
+  __device__ void put(int, double) const {}
+#endif
+};
+// `also`: something else the last workgroup reads from global memory -- also.fetch(tid) goes out with the batch of loads,
+// also.put(tid, value) files it once the batch is in
+template <int NSLOTS, int NT = R2L_NT, class ALSO = R2LNoExtra>
+R2L_BLOCKFN bool r2l_tree_level2(const R2LTree& tr, int nblk, int extra, float* lds4, double* out, double* scratch,
+                                 ALSO&& also = R2LNoExtra()) {
+  unsigned* lu = (unsigned*)lds4;
+  const int ngroups = (nblk + R2L_TREE_GROUP - 1) / R2L_TREE_GROUP;
   R2L_PHASE_BEGIN
   if (tid == 0) lu[1] = r2l_ticket(tr.counters);
   R2L_PHASE_END
-  if (lu[1] + 1 != (unsigned)ngroups) return false;
-  const int chunk = scratch_n / ngroups;  // slots per pass
-  for (int s0 = 0; s0 < NSLOTS; s0 += chunk) {
-    const int cnt = (NSLOTS - s0 < chunk) ? NSLOTS - s0 : chunk;
-    R2L_PHASE_BEGIN
-    if (tid == 0) tr.counters[0] = 0;
-    for (int base = 0; base < cnt * ngroups; base += 8 * NT) {  // batches of 8 loads in flight per lane (see above)
-      double v2[8];
+  if (lu[1] + 1 != (unsigned)(ngroups + extra)) return false;
+  R2L_TAILST(R2L_TAIL_BASE(NSLOTS) + 5);
+  // the group partials of every slot, in group order (lane `part` of a slot: groups part, part + P, ...)
+  constexpr int P = R2LTreeShape<NSLOTS, NT>::P, CH = R2LTreeShape<NSLOTS, NT>::CH;
+  R2L_PHASE_BEGIN
+  if (tid == 0) tr.counters[0] = 0;
+  const double also_v = also.fetch(tid);
+  for (int w = tid; w < NSLOTS * P; w += NT) {
+    const int part = w / NSLOTS, sl = w - part * NSLOTS;
+    double acc = 0.0;
+    for (int q0 = part; q0 < ngroups; q0 += CH * P) {
+      double v[CH];
       R2L_PRAGMA_UNROLL
-      for (int it = 0; it < 8; ++it) {
-        const int idx = base + tid + it * NT;
-        v2[it] = 0.0;
-        if (idx < cnt * ngroups) {
-          const int sl = idx / ngroups, q = idx - sl * ngroups;
-          v2[it] = r2l_load_coherent(tr.gpartial + (size_t)(s0 + sl) * R2L_MAX_GROUPS + q);
-        }
+      for (int k = 0; k < CH; ++k) {
+        const int q = q0 + k * P;
+        v[k] = r2l_load_coherent(tr.gpartial + (size_t)(q < ngroups ? q : ngroups - 1) * NSLOTS + sl);
       }
       R2L_PRAGMA_UNROLL
-      for (int it = 0; it < 8; ++it) {
-        const int idx = base + tid + it * NT;
-        if (idx < cnt * ngroups) scratch[idx] = v2[it];
-      }
+      for (int k = 0; k < CH; ++k) acc += (q0 + k * P < ngroups) ? v[k] : 0.0;
     }
-    R2L_PHASE_END
+    if (P == 1)
+      out[sl] = acc;
+    else
+      scratch[w] = acc;  // [part][slot]
+  }
+  also.put(tid, also_v);
+  R2L_PHASE_END
+  if (P > 1) {
     R2L_PHASE_BEGIN
-    for (int sl = tid; sl < cnt; sl += NT) {
+    for (int sl = tid; sl < NSLOTS; sl += NT) {
       double acc = 0.0;
-      for (int q = 0; q < ngroups; ++q) acc += scratch[sl * ngroups + q];
-      out[s0 + sl] = acc;
+      R2L_PRAGMA_UNROLL
+      for (int p = 0; p < P; ++p) acc += scratch[p * NSLOTS + sl];
+      out[sl] = acc;
     }
     R2L_PHASE_END
   }
+  R2L_TAILST(R2L_TAIL_BASE(NSLOTS) + 6);
   return true;
+}
+template <int NSLOTS, int NT = R2L_NT, class MEANWHILE = R2LNoWork>
+R2L_BLOCKFN bool r2l_tree_finish(const R2LTree& tr, int bid, int nblk, float* lds4, double* out, double* scratch,
+                                 int scratch_n, MEANWHILE&& meanwhile = R2LNoWork()) {
+  (void)scratch_n;
+  if (!r2l_tree_level1<NSLOTS, NT>(tr, bid, nblk, lds4, meanwhile)) return false;
+  return r2l_tree_level2<NSLOTS, NT>(tr, nblk, 0, lds4, out, scratch);
 }
 
 // sums (float64 in LDS) -> the 132 parameter gradients; tg (R2L_UNFOLD_TG doubles) and pl (R2L_P_COUNT floats)
 // are LDS
 #define R2L_UNFOLD_TG (126 + 12)  // T[9], gT[9], folded A[3][4][9], black-level partial sums [site][k]
 // (every phase walks its work items with a stride of NT threads, so workgroups smaller than R2L_NT can run it too)
+// r2l_unfold_from_lds: the packed parameters already sit in pl.  TABLES_DONE: and the tables that depend on the parameters
+// only (r2l_unfold_tables_lane: T, the folded stencils A) in tg -- computed while the tree's first ticket travelled
+template <int NT = R2L_NT>
+R2L_HD void r2l_unfold_tables_lane(int tid, double* tg, const float* pl) {
+  for (int t = tid; t < 128 + 108; t += NT) {
+    if (t < 9) {
+      tg[t] = r2l_fold_T_one(pl, t / 3, t % 3);
+    } else if (t >= 128) {
+      const int e = t - 128;
+      tg[18 + e] = r2l_fold_A_one(pl, e / 36, (e % 36) / 9, e % 9);
+    }
+  }
+}
+template <int NT = R2L_NT, bool TABLES_DONE = false>
+R2L_BLOCKFN void r2l_unfold_from_lds(const double* sums, double* tg, const float* pl, float* grad_params) {
+  R2L_TAILST(23);
+  R2L_PHASE_BEGIN
+  if (!TABLES_DONE) r2l_unfold_tables_lane<NT>(tid, tg, pl);
+  for (int t = tid; t < 128; t += NT) {
+    if (t >= 64 && t < 73) tg[9 + t - 64] = r2l_unfold_gT(pl, sums, (t - 64) / 3, (t - 64) % 3);
+    // the black-level gradient sums 108 products per site: 12 lanes take one (site, k) each (36 candidates, fixed order)
+    // instead of 4 lanes walking all 108 -- this runs in the launch's last workgroup with the rest of the chip idle
+    if (TABLES_DONE && t < 12) tg[126 + t] = r2l_unfold_bl_part(sums, tg, t / 3, t % 3);
+  }
+  R2L_PHASE_END
+  R2L_TAILST(28);
+  if (!TABLES_DONE) {
+    R2L_PHASE_BEGIN
+    for (int t = tid; t < 12; t += NT) tg[126 + t] = r2l_unfold_bl_part(sums, tg, t / 3, t % 3);
+    R2L_PHASE_END
+  }
+  R2L_TAILST(29);
+  R2L_PHASE_BEGIN
+  for (int t = tid; t < R2L_P_NTRAIN; t += NT) grad_params[t] = r2l_unfold_one(pl, sums, t, tg);
+  R2L_PHASE_END
+}
 template <int NT = R2L_NT>
 R2L_BLOCKFN void r2l_unfold_phases(const float* params, const double* sums, double* tg, float* pl,
                                    float* grad_params) {
   R2L_PHASE_BEGIN
   for (int t = tid; t < R2L_P_COUNT; t += NT) pl[t] = params[t];
   R2L_PHASE_END
-  R2L_PHASE_BEGIN
-  for (int t = tid; t < 128 + 108; t += NT) {
-    if (t < 9) {
-      tg[t] = r2l_fold_T_one(pl, t / 3, t % 3);
-    } else if (t >= 64 && t < 73) {
-      tg[9 + t - 64] = r2l_unfold_gT(pl, sums, (t - 64) / 3, (t - 64) % 3);
-    } else if (t >= 128) {
-      const int e = t - 128;
-      tg[18 + e] = r2l_fold_A_one(pl, e / 36, (e % 36) / 9, e % 9);
-    }
-  }
-  R2L_PHASE_END
-  // the black-level gradient sums 108 products per site: 12 lanes take one (site, k) each (36 candidates, fixed order)
-  // instead of 4 lanes walking all 108 -- this runs in the launch's last workgroup with the rest of the chip idle
-  R2L_PHASE_BEGIN
-  for (int t = tid; t < 12; t += NT) tg[126 + t] = r2l_unfold_bl_part(sums, tg, t / 3, t % 3);
-  R2L_PHASE_END
-  R2L_PHASE_BEGIN
-  for (int t = tid; t < R2L_P_NTRAIN; t += NT) grad_params[t] = r2l_unfold_one(pl, sums, t, tg);
-  R2L_PHASE_END
+  r2l_unfold_from_lds<NT>(sums, tg, pl, grad_params);
 }
 
 // packed forms: pair p = columns (2p, 2p+1) of the micro-tile row
@@ -763,10 +859,28 @@ struct R2LBnFinalizeArgs {
   double eps, momentum;  // momentum < 0: cumulative moving average, 1 / num_batches_tracked (after its increment)
   long long* num_batches_tracked;  // optional, incremented by one
 };
-R2L_BLOCKFN void r2l_bn_finalize_phases(const R2LBnFinalizeArgs& a) {
-  R2L_PHASE_BEGIN
+// what the bookkeeping reads from global memory (lanes 0-2): asked for early by callers whose last workgroup runs it at the
+// end of a launch, so that it arrives behind waits that happen anyway
+struct R2LBnPre {
+  long long nbt;  // num_batches_tracked before this step
+  float rm, rv;   // running_mean / running_var of the lane's channel
+};
+R2L_HD R2LBnPre r2l_bn_finalize_fetch(const R2LBnFinalizeArgs& a, int tid) {
+  R2LBnPre p;
+  p.nbt = 0;
+  p.rm = p.rv = 0.f;
   if (tid < 3) {
-    const long long nbt = a.num_batches_tracked ? *a.num_batches_tracked + 1 : 1;
+    if (a.num_batches_tracked) p.nbt = *a.num_batches_tracked;
+    if (a.running_mean) {
+      p.rm = a.running_mean[tid];
+      p.rv = a.running_var[tid];
+    }
+  }
+  return p;
+}
+R2L_HD void r2l_bn_finalize_lane(const R2LBnFinalizeArgs& a, int tid, const R2LBnPre& pre) {
+  if (tid < 3) {
+    const long long nbt = pre.nbt + 1;
     const double mom = a.momentum < 0.0 ? 1.0 / (double)nbt : a.momentum;
     double n = 0.0, s1 = 0.0, s2 = 0.0;  // rank order: every rank computes bit-identical statistics
     for (int r = 0; r < a.nranks; ++r) {
@@ -787,10 +901,14 @@ R2L_BLOCKFN void r2l_bn_finalize_phases(const R2LBnFinalizeArgs& a) {
     }
     if (a.running_mean) {
       const double unb = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
-      a.running_mean[tid] = (float)((1.0 - mom) * (double)a.running_mean[tid] + mom * mean);
-      a.running_var[tid] = (float)((1.0 - mom) * (double)a.running_var[tid] + mom * unb);
+      a.running_mean[tid] = (float)((1.0 - mom) * (double)pre.rm + mom * mean);
+      a.running_var[tid] = (float)((1.0 - mom) * (double)pre.rv + mom * unb);
     }
   }
+}
+R2L_BLOCKFN void r2l_bn_finalize_phases(const R2LBnFinalizeArgs& a) {
+  R2L_PHASE_BEGIN
+  r2l_bn_finalize_lane(a, tid, r2l_bn_finalize_fetch(a, tid));
   R2L_PHASE_END
   R2L_PHASE_BEGIN  // after every lane has read the counter
   if (tid == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
@@ -1675,6 +1793,13 @@ struct R2LBwd2Args {
   int asym;             // r2l_walk_init: uneven tile shares for the two workgroups of a CU (0 = even)
   float* hp;            // plane passes (r2l_param_plane_bwd.h): (B,H,W) the blur's adjoint of dL/dY''
   int band_h;           // plane passes: rows per work item (a multiple of 6)
+  // the sums pass (r2l_bwd2_sums_block) with helper workgroups: workgroups [0, nmain) walk the work items and reduce B2's
+  // partials (tree.partial2, tree.split = 0); workgroups nmain + h add B1's partials b1_partial[slot][b1_n] of slots
+  // 8 h ... 8 h + 7 into b1_tot[slot] while the others compute
+  int nmain;
+  const float* b1_partial;
+  int b1_n;
+  double* b1_tot;  // [R2L_B1_NACC]
 };
 
 enum { R2L_L2_GSHARP = 0, R2L_L2_GAY = 9, R2L_L2_SY = 27, R2L_L2_NACC = 29 };

@@ -212,7 +212,10 @@ R2L_HD float r2l_bp_slot(const R2LBpAcc& A, const float* E, const float* O, int 
 }
 
 // lanes -> one partial per slot and workgroup, in a fixed order (R2L_BLOCK_REDUCE_F for R2L_BP_NT threads): slots
-// [0, NSLOTS) of val(i) go to partial[(slot0 + i) * nblk + bid]
+// [0, NSLOTS) of val(i) go to partial[(slot0 + i) * nblk + bid].  The last workgroup's copy of this is part of the launch's
+// tail: one wait for the coherent stores, behind the last batch of slots (not one per batch).  (Adding the 64 lanes of a
+// wavefront in registers first -- six DPP steps per slot -- was measured and is slower: ~100 cycles per slot and
+// wavefront on the vector unit, against LDS traffic that runs beside it; B1 +4 us, profiles/r04_tails.txt.)
 template <int NSLOTS, int NT = R2L_BP_NT, class VAL>
 R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int slot0, int bid, int nblk, VAL&& val) {
   R2L_PRAGMA_UNROLL
@@ -243,7 +246,7 @@ R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int sl
       for (int j = 0; j < 16; ++j) s += lds[32 * (NT + 1) + tid * 16 + j];
       r2l_store_coherent(&partial[(size_t)(slot0 + base + tid) * nblk + bid], s);
     }
-    R2L_STORES_DONE();  // B2's last workgroups finish the reduction
+    if (base + 32 >= NSLOTS) R2L_STORES_DONE();  // B2's last workgroups finish the reduction
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
@@ -364,7 +367,9 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
     O[4 * c + 3] = o4.w;
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
-  r2l_bp_block_reduce<R2L_B1_NACC, R2L_BP_NT>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return r2l_bp_slot(A, E, O, i); });
+  // (not the blur-weight sums, slots < R2L_B1_GAU: the blur pass that runs behind this launch on the same grid writes them)
+  r2l_bp_block_reduce<R2L_B1_NACC - R2L_B1_GAU, R2L_BP_NT>(lds, tid, a.partial, R2L_B1_GAU, bid, nblk,
+                                                           [&](int i) { return r2l_bp_slot(A, E, O, R2L_B1_GAU + i); });
 }
 
 // ---- second pass: the 25 blur-weight sums  d/d gaussian_blur.weight[i][j] = sum_p gY''(p) * Y'_ext(p + (i-2, j-2)) from
@@ -960,10 +965,63 @@ R2L_HD float r2l_b2s_slot(const R2LSumAcc& A, const float* E, const float* O, in
 #ifndef R2L_B2S_PF
 #define R2L_B2S_PF 2
 #endif
+// Helper workgroups of the sums pass (bid >= a.nmain): B1's partials -- complete before this launch starts -- are added
+// while the main workgroups walk their items, so that the launch's tail reduces B2's 49 slots, not 155.  Helper h:
+// slots 8 h ... 8 h + 7, 32 lanes per slot (lane j: workgroups j, j + 32, ... in order; the 32 lane sums in lane order).
+#define R2L_B2S_HELPERS ((R2L_B1_NACC + 7) / 8)
+struct R2LB1Totals {  // (r2l_tree_level2's `also`: the last workgroup picks up the helpers' totals with its own loads)
+  const double* tot;
+  double* sums;
+  __device__ double fetch(int tid) const { return tid < R2L_B1_NACC ? r2l_load_coherent(tot + tid) : 0.0; }
+  __device__ void put(int tid, double v) const {
+    if (tid < R2L_B1_NACC) sums[tid] = v;
+  }
+};
+R2L_BLOCKFN void r2l_b2s_helper(const R2LBwd2Args& a, int h, float* lds, int tid) {
+  static_assert(R2L_B2S_NT == 256, "8 slots x 32 lanes");
+  double* hd = (double*)(lds + 2048);
+  const int sl = h * 8 + (tid >> 5), j = tid & 31;
+  const int n1 = a.b1_n;
+  const float* row = a.b1_partial + (size_t)(sl < R2L_B1_NACC ? sl : R2L_B1_NACC - 1) * n1;
+  double acc = 0.0;
+  for (int m0 = j; m0 < n1; m0 += 32 * 16) {
+    float v[16];
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 16; ++k) v[k] = row[(m0 + 32 * k < n1) ? m0 + 32 * k : n1 - 1];
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k < 16; ++k) acc += (m0 + 32 * k < n1) ? (double)v[k] : 0.0;
+  }
+  hd[tid] = acc;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (tid < 8 && h * 8 + tid < R2L_B1_NACC) {
+    double t = 0.0;
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 32; ++i) t += hd[tid * 32 + i];
+    r2l_store_coherent(a.b1_tot + h * 8 + tid, t);
+  }
+  R2L_STORES_DONE();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <bool U16>
-R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk, float* lds) {
+R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_launch, float* lds) {
   constexpr int NWV = R2L_B2S_NWV, NT = R2L_B2S_NT;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int nblk = a.nmain > 0 ? a.nmain : nblk_launch;  // the workgroups that walk the work items
+  if (bid >= nblk) {
+    if (!a.tree.counters) return;
+    double* sums = (double*)(lds + 4);
+    double* tg = sums + R2L_NSUMS;
+    float* pl = (float*)(tg + R2L_UNFOLD_TG);
+    if (tid < R2L_P_COUNT) pl[tid] = a.params[tid];
+    r2l_b2s_helper(a, bid - nblk, lds, tid);  // (its barriers also publish pl)
+    r2l_unfold_tables_lane<NT>(tid, tg, pl);  // in case this workgroup turns out to be the launch's last
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!r2l_tree_level2<R2L_B2_NACC, NT>(a.tree, nblk, R2L_B2S_HELPERS, lds, sums + R2L_B1_NACC, (double*)(lds + 1024),
+                                          R2LB1Totals{a.b1_tot, sums}))
+      return;
+    r2l_unfold_from_lds<NT, true>(sums, tg, pl, a.grad_params);
+    return;
+  }
 #ifdef R2L_EXP_STAMPS
   const unsigned long long tl0_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1078,18 +1136,36 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk, fl
     ((unsigned long long*)a.debug)[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
+  R2L_TAILST(20);
+  // the packed parameters of the unfold, asked for now: they arrive behind the partials' store wait, not as a round trip of
+  // their own in the launch's last workgroup
+  static_assert(R2L_P_COUNT <= NT, "one parameter per lane");
+  const float pv = (a.tree.counters && tid < R2L_P_COUNT) ? a.params[tid] : 0.f;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
   r2l_bp_block_reduce<R2L_B2_NACC, NT>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return r2l_b2s_slot(A, E, O, i); });
+  R2L_TAILST(21);
   if (a.tree.counters) {
     double* sums = (double*)(lds + 4);
     double* tg = sums + R2L_NSUMS;
     float* pl = (float*)(tg + R2L_UNFOLD_TG);
-    if (!r2l_tree_finish<R2L_NSUMS, NT>(a.tree, bid, nblk, lds, sums, (double*)(lds + 1024), (R2L_B2S_LDS_FLOATS - 1024) / 2))
+    // the packed parameters go to LDS, and what the unfold derives from them alone is computed while the first ticket
+    // travels (by every workgroup: the vector unit has nothing else to do then; only the last one uses it)
+    if (tid < R2L_P_COUNT) pl[tid] = pv;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (a.nmain > 0) {  // B2's slots here, B1's by the helper workgroups
+      if (!r2l_tree_level1<R2L_B2_NACC, NT>(a.tree, bid, nblk, lds, [&](int t) { r2l_unfold_tables_lane<NT>(t, tg, pl); })) return;
+      if (!r2l_tree_level2<R2L_B2_NACC, NT>(a.tree, nblk, R2L_B2S_HELPERS, lds, sums + R2L_B1_NACC, (double*)(lds + 1024),
+                                            R2LB1Totals{a.b1_tot, sums}))
+        return;
+    } else if (!r2l_tree_finish<R2L_NSUMS, NT>(a.tree, bid, nblk, lds, sums, (double*)(lds + 1024),
+                                               (R2L_B2S_LDS_FLOATS - 1024) / 2,
+                                               [&](int t) { r2l_unfold_tables_lane<NT>(t, tg, pl); }))
       return;
 #ifdef R2L_TEST_HOOKS
     if (a.debug && tid < R2L_NSUMS) ((double*)a.debug)[tid] = sums[tid];  // (tests: the 155 totals, slot by slot)
 #endif
-    r2l_unfold_phases<NT>(a.params, sums, tg, pl, a.grad_params);
+    r2l_unfold_from_lds<NT, true>(sums, tg, pl, a.grad_params);
+    R2L_TAILST(27);
   }
 }
 

@@ -550,6 +550,12 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
   a.W = ka->W;
   // ---- statistics: lanes -> one partial per slot and workgroup (fixed order), then the shared tree ------------
   {
+    R2L_TAILST(0);
+    // (the bookkeeping's reads of global memory, asked for now: they arrive behind the partials' store wait)
+    R2LBnPre pre;
+    pre.nbt = 0;
+    pre.rm = pre.rv = 0.f;
+    if (a.tree.counters && a.fin.bn) pre = r2l_bn_finalize_fetch(a.fin, tid);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wavefront is done with its chroma ring
     if (tid < 6) {  // the wavefronts' totals in wavefront order; (high, low) float32 halves in slots tid and 6 + tid
       double acc = 0.0;
@@ -560,6 +566,7 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
     }
     R2L_STORES_DONE();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_TAILST(1);
     double* sl = (double*)(red + 4);  // totals in LDS: the bookkeeping below reads them back
     if (a.tree.counters &&
         r2l_tree_finish<12, NT>(a.tree, bid, nblk, red, sl, (double*)(red + 512), (R2L_FS_RED_FLOATS(NW) - 512) / 2)) {
@@ -573,8 +580,10 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
         R2LBnFinalizeArgs f = a.fin;
         f.tot = sl;
         f.nranks = 1;
-        r2l_bn_finalize_phases(f);
+        r2l_bn_finalize_lane(f, tid, pre);
+        if (tid == 0 && f.num_batches_tracked) *f.num_batches_tracked = pre.nbt + 1;  // (lanes 0-2 read it long ago)
       }
+      R2L_TAILST(7);
     }
   }
 }

@@ -208,7 +208,9 @@ R2L_BLOCKFN void r2l_bn_reduce_block(const R2LBnReduceArgs& a, int bid, int nblk
   R2L_PHASE_BEGIN  // one phase: the wavefronts stream independently (a barrier per item would cap the loads in flight)
   for (int item = bid; item < nitems; item += nblk) r2l_bn_reduce_item(tid, a, item, nsegpp, R2L_TREG(regs));
   R2L_PHASE_END
+  R2L_TAILST(10);
   R2L_BLOCK_REDUCE(6, regs, lds, a.partial, bid, nblk)
+  R2L_TAILST(11);
   if (a.tree.counters) {
     double* sl = (double*)(lds + 4);
     if (!r2l_tree_finish<6>(a.tree, bid, nblk, lds, sl, (double*)(lds + 512), (R2L_RED_FLOATS_N(6) - 512) / 2))
@@ -219,6 +221,7 @@ R2L_BLOCKFN void r2l_bn_reduce_block(const R2LBnReduceArgs& a, int bid, int nblk
       if (a.bn_bwd && a.totals) a.bn_bwd[tid] = (float)(sl[tid] / a.totals[6]);
     }
     R2L_PHASE_END
+    R2L_TAILST(17);
   }
 }
 
