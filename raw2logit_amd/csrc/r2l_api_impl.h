@@ -849,9 +849,10 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   int g1p = 0;  // workgroups of the plane passes, when they run
   bool blur_hp = false;  // ... with r2l_bwd1_blur_hp_block doing kernel B2's first pass
 #ifndef R2L_EMUL
-  // ... where there is enough work for their eight launch tails: 128x256x256 (8.4 Mpx) 124 us against the tile kernels' 132,
-  // 64x256x256 (4.2 Mpx) 99 against 85 (profiles/r03_z_bench.json, small_shapes)
-  const bool planes = r2l_env_int("R2L_BWD_PLANES", 0) || (size_t)B * H * W >= ((size_t)6 << 20);
+  // ... where there is enough work for their launch tails: 128x256x256 (8.4 Mpx) 102 us against the tile kernels' 110+,
+  // 64x256x256 (4.2 Mpx) 77.7 against 80.5 since the tails were shortened (profiles/r04_small.txt; round 3: 99 against 85,
+  // and the threshold was 6 Mi px)
+  const bool planes = r2l_env_int("R2L_BWD_PLANES", 0) || (size_t)B * H * W >= ((size_t)4 << 20);
   if (saved && planes && !r2l_env_int("R2L_BWD1_TILED", 0)) {
     // persistent workgroups of 4 independent wavefronts, two per CU (<= 256 VGPRs), not more workgroups than kernel B2
     // runs (its last workgroups reduce both kernels' partials); band height as for the forward's plane passes

@@ -34,9 +34,14 @@
 #define R2L_BP_NWV 4                                  // wavefronts (work items in flight) per workgroup
 #define R2L_BP_BANK 40                                // floats of one parity bank: GAU[9], GAV[9], SU, SV as pairs
 #define R2L_BP_NT (64 * R2L_BP_NWV)
-#define R2L_BP_RED_FLOATS (32 * (R2L_BP_NT + 1) + 32 * 16)
+#define R2L_BP_RED_FLOATS_R(ROWS, NT) ((ROWS) * ((NT) + 1) + (ROWS) * 16)  // r2l_bp_block_reduce, ROWS slots at a time
+#define R2L_BP_RED_FLOATS R2L_BP_RED_FLOATS_R(32, R2L_BP_NT)
 #define R2L_BP_SWAP_FLOATS (R2L_BP_NWV * 64 * R2L_BP_BANK)
-#define R2L_BP_LDS_FLOATS (R2L_BP_SWAP_FLOATS > R2L_BP_RED_FLOATS ? R2L_BP_SWAP_FLOATS : R2L_BP_RED_FLOATS)
+// B1's plane pass: its 81 slots in two batches of 41 (two workgroups per CU: 45 KB each)
+#define R2L_BP_ROWS 41
+#define R2L_BP_LDS_FLOATS                                                                    \
+  (R2L_BP_SWAP_FLOATS > R2L_BP_RED_FLOATS_R(R2L_BP_ROWS, R2L_BP_NT) ? R2L_BP_SWAP_FLOATS \
+                                                                     : R2L_BP_RED_FLOATS_R(R2L_BP_ROWS, R2L_BP_NT))
 
 struct R2LBpStage {  // grad_out of one row in flight: 3 channels x the lane's 4 pixels
   r2l_f4 g[3];
@@ -216,37 +221,39 @@ R2L_HD float r2l_bp_slot(const R2LBpAcc& A, const float* E, const float* O, int 
 // tail: one wait for the coherent stores, behind the last batch of slots (not one per batch).  (Adding the 64 lanes of a
 // wavefront in registers first -- six DPP steps per slot -- was measured and is slower: ~100 cycles per slot and
 // wavefront on the vector unit, against LDS traffic that runs beside it; B1 +4 us, profiles/r04_tails.txt.)
-template <int NSLOTS, int NT = R2L_BP_NT, class VAL>
+// ROWS slots go through LDS at a time (LDS floats: R2L_BP_RED_FLOATS_R(ROWS, NT)): every batch costs three barriers
+template <int NSLOTS, int NT = R2L_BP_NT, int ROWS = 32, class VAL>
 R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int slot0, int bid, int nblk, VAL&& val) {
+  static_assert(ROWS <= NT, "one lane per slot in the last stage");
   R2L_PRAGMA_UNROLL
-  for (int base = 0; base < NSLOTS; base += 32) {
+  for (int base = 0; base < NSLOTS; base += ROWS) {
     R2L_PRAGMA_UNROLL
-    for (int i = 0; i < 32; ++i)
+    for (int i = 0; i < ROWS; ++i)
       if (base + i < NSLOTS) lds[i * (NT + 1) + tid] = val(base + i);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {
       const int slot = tid >> 4, part = tid & 15;  // 16 lanes per slot add NT / 16 values each; NT / 16 slots per pass
       R2L_PRAGMA_UNROLL
-      for (int h = 0; h < (32 * 16 + NT - 1) / NT; ++h) {
+      for (int h = 0; h < (ROWS * 16 + NT - 1) / NT; ++h) {
         const int sl = slot + h * (NT / 16);
-        if (sl < 32) {
+        if (sl < ROWS) {
           float s = 0.f;
           if (base + sl < NSLOTS) {
             R2L_PRAGMA_UNROLL
             for (int j = 0; j < NT / 16; ++j) s += lds[sl * (NT + 1) + part + 16 * j];
           }
-          lds[32 * (NT + 1) + sl * 16 + part] = s;
+          lds[ROWS * (NT + 1) + sl * 16 + part] = s;
         }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (tid < 32 && base + tid < NSLOTS) {
+    if (tid < ROWS && base + tid < NSLOTS) {
       float s = 0.f;
       R2L_PRAGMA_UNROLL
-      for (int j = 0; j < 16; ++j) s += lds[32 * (NT + 1) + tid * 16 + j];
+      for (int j = 0; j < 16; ++j) s += lds[ROWS * (NT + 1) + tid * 16 + j];
       r2l_store_coherent(&partial[(size_t)(slot0 + base + tid) * nblk + bid], s);
     }
-    if (base + 32 >= NSLOTS) R2L_STORES_DONE();  // B2's last workgroups finish the reduction
+    if (base + ROWS >= NSLOTS) R2L_STORES_DONE();  // B2's last workgroups finish the reduction
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
@@ -368,8 +375,8 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
   // (not the blur-weight sums, slots < R2L_B1_GAU: the blur pass that runs behind this launch on the same grid writes them)
-  r2l_bp_block_reduce<R2L_B1_NACC - R2L_B1_GAU, R2L_BP_NT>(lds, tid, a.partial, R2L_B1_GAU, bid, nblk,
-                                                           [&](int i) { return r2l_bp_slot(A, E, O, R2L_B1_GAU + i); });
+  r2l_bp_block_reduce<R2L_B1_NACC - R2L_B1_GAU, R2L_BP_NT, R2L_BP_ROWS>(
+      lds, tid, a.partial, R2L_B1_GAU, bid, nblk, [&](int i) { return r2l_bp_slot(A, E, O, R2L_B1_GAU + i); });
 }
 
 // ---- second pass: the 25 blur-weight sums  d/d gaussian_blur.weight[i][j] = sum_p gY''(p) * Y'_ext(p + (i-2, j-2)) from
@@ -820,7 +827,9 @@ R2L_BLOCKFN void r2l_bwd1_blur_hp_block(const R2LBwd1Args& a, int bid, int nblk,
                                            // spread 2-2-1-1 over the SIMDs: a second one only fits if it lands 1-1-2-2)
 #define R2L_B2S_NT (64 * R2L_B2S_NWV)
 #define R2L_B2S_BANK 20                    // floats of one row-parity bank: GAY[9] pairs, SY pair
-#define R2L_B2S_LDS_FLOATS (32 * (R2L_B2S_NT + 1) + 32 * 16)  // reduction scratch (>= the bank areas and the tree's scratch)
+// reduction scratch (>= the bank areas and the tree's scratch): all 49 slots in one batch -- 53.5 KB, three workgroups per CU
+// still fit the 160 KB
+#define R2L_B2S_LDS_FLOATS R2L_BP_RED_FLOATS_R(R2L_B2_NACC, R2L_B2S_NT)
 struct R2LSumStage {  // one HP row in flight: the lane's 4 values + the neighbour beyond the strip edge
   r2l_f4 c;
   float e;
@@ -1142,7 +1151,8 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_lau
   static_assert(R2L_P_COUNT <= NT, "one parameter per lane");
   const float pv = (a.tree.counters && tid < R2L_P_COUNT) ? a.params[tid] : 0.f;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
-  r2l_bp_block_reduce<R2L_B2_NACC, NT>(lds, tid, a.partial, 0, bid, nblk, [&](int i) { return r2l_b2s_slot(A, E, O, i); });
+  r2l_bp_block_reduce<R2L_B2_NACC, NT, R2L_B2_NACC>(lds, tid, a.partial, 0, bid, nblk,
+                                                    [&](int i) { return r2l_b2s_slot(A, E, O, i); });
   R2L_TAILST(21);
   if (a.tree.counters) {
     double* sums = (double*)(lds + 4);

@@ -98,13 +98,13 @@ def test_plane_backward_frame_shapes(mode, dev):
 
 
 def test_plane_backward_at_the_dispatch_threshold(dev):
-    """The SHIPPED library at its own dispatch threshold: 24 x 512 x 512 = 6 Mi px is the smallest batch whose backward
+    """The SHIPPED library at its own dispatch threshold: 16 x 512 x 512 = 4 Mi px is the smallest batch whose backward
     runs as plane passes (r2l_api_impl.h: `planes`).  BatchNorm in eval mode decouples the frames, the cotangent is zero
-    except on frames 0 and 23 (the first and the last band items of the launch), so all 132 gradients equal the float64
+    except on frames 0 and 15 (the first and the last band items of the launch), so all 132 gradients equal the float64
     oracle's on those two frames: DEFAULT_GRAD_RTOL of the gradient's scale + the clip-flip allowance.  Also without
     BatchNorm and from 16-bit containers (bit-identical).  Reference: pipeline_torch.py:187-217 under autograd."""
     from raw2logit_amd import _lib
-    B, H, W = 24, 512, 512
+    B, H, W = 16, 512, 512
     lib = _lib.device_library()
     assert lib.path == _lib.LIB_PATH
     u = np.rint(orc.synth_raw(B, H, W, seed=4, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
@@ -142,7 +142,7 @@ def test_plane_backward_at_the_dispatch_threshold(dev):
         tol = pc.out_tolerance(c, bn)
         err = np.abs(y_sel - o)
         w = np.unravel_index((err / tol).argmax(), err.shape)
-        pc.report(f'threshold-24x512x512/bn={bn}/out (frames 0, 23) vs float64 oracle', err[w], tol[w])
+        pc.report(f'threshold-16x512x512/bn={bn}/out (frames 0, 15) vs float64 oracle', err[w], tol[w])
         assert np.all(err <= tol), (bn, err.max())
         og, _, _ = orc.parametrized_backward(P64, c, cot_np[sel])
         lo, _, _ = orc.parametrized_backward(P64, c, cot_np[sel], clip_shift=1e-6)
@@ -153,7 +153,7 @@ def test_plane_backward_at_the_dispatch_threshold(dev):
             flip = max(np.abs(np.asarray(lo[k]) - ref).max(), np.abs(np.asarray(hi[k]) - ref).max())
             lim = pc.DEFAULT_GRAD_RTOL * (np.abs(ref).max() + 1e-6) + flip
             e = np.abs(got - ref).max()
-            pc.report(f'threshold-24x512x512/bn={bn}/grad {k} vs float64 oracle (plane passes, shipped library)', e, lim)
+            pc.report(f'threshold-16x512x512/bn={bn}/grad {k} vs float64 oracle (plane passes, shipped library)', e, lim)
             assert e <= lim, (bn, k, e, lim)
 
 
