@@ -37,6 +37,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GRAPH_TRIAL_TIMEOUT_S = 90      # several ranks: capture + agreement + timing of the graph trial, or the eager line goes out
 PREROLL_S = float(os.environ.get('R2L_BENCH_PREROLL_S', '0.3'))   # untimed pre-roll of the step before the W warm-up steps
                                # (GPU clocks, see main(); counter-collection runs of the profiling scripts set 0)
 # algorithmic HBM bytes per raw pixel of each kernel family, by kernel-name prefix; the
@@ -114,11 +115,13 @@ def parse():
                     help='replay the whole step as ONE HIP graph (raw2logit_amd/graphs.py: StepGraph): the step costs the '
                          'host one graph launch instead of two C-ABI calls + autograd; matters below ~8 Mpix per step, '
                          'where the host is the bound (single GPU)')
-    ap.add_argument('--graph-also', action='store_true',
-                    help='several ranks over RCCL: after the eager measurement, time the same data-parallel step as ONE HIP '
-                         'graph with its collectives captured (ms_per_step_graph / value_graph in the line).  Opt-in: a '
-                         'capture that fails on one rank only would leave the others inside a collective, and the headline '
-                         'line is printed last')
+    ap.add_argument('--graph-also', action='store_true', help='(accepted for compatibility: the graph trial is the default now)')
+    ap.add_argument('--no-graph-trial', action='store_true',
+                    help='several ranks over RCCL: skip the graph trial.  By default, after the eager measurement, the same '
+                         'data-parallel step is captured as ONE HIP graph with its collectives (raw2logit_amd/graphs.py) and '
+                         'timed the same way; the ranks agree on whether every capture succeeded, a watchdog prints the eager '
+                         'line and ends the process if the trial does not finish in time, and the faster of the two is the '
+                         "line's value (the other one is reported beside it)")
     ap.add_argument('--no-small-shapes', action='store_true',
                     help="skip the small_shapes sub-records (the datasets' 256x256 tiles: BASELINE configs 4 / 5 per GPU)")
     ap.add_argument('--raw-u16', action='store_true',
@@ -256,7 +259,8 @@ def _init_distributed(torch, dist, world, local_rank):
         if world > 1:
             dist.init_process_group('gloo')
         return dev
-    if world > 1:
+    one_rank = world == 1 and os.environ.get('R2L_BENCH_ONE_RANK_DIST') == '1'   # (tests: the N > 1 code on a 1-GPU box)
+    if world > 1 or one_rank:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before anything initialises HIP
     ndev = torch.cuda.device_count()
     backend = os.environ.get('R2L_BENCH_BACKEND', 'nccl')
@@ -271,6 +275,11 @@ def _init_distributed(torch, dist, world, local_rank):
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+    if one_rank:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ['R2L_SPLIT_SINGLE_RANK'] = '1'        # raw2logit_amd/functional.py: the exchange path with one rank
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     if world > 1 and dist.get_world_size() != world:
         raise SystemExit(f'bench.py: {dist.get_world_size()} ranks joined, expected {world}')
     return dev
@@ -280,6 +289,7 @@ class Clock:
     """the contract's timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks"""
 
     def __init__(self, torch, dist, world, dev):
+        # (world: > 1 whenever a process group exists -- also the one-rank group of R2L_BENCH_ONE_RANK_DIST)
         self.torch, self.dist, self.world, self.dev = torch, dist, world, dev
 
     def barrier(self):
@@ -600,7 +610,10 @@ def main():
 
     dev = _init_distributed(torch, dist, world, local_rank)
     lib = _lib.library_for(torch.empty(1, device=dev))[0]      # raises if the HIP extension is missing
-    clock = Clock(torch, dist, world, dev)
+    # a process group exists: several ranks, or the one-rank RCCL group of R2L_BENCH_ONE_RANK_DIST (tests: the N > 1 code path
+    # on a one-GPU box)
+    group_on = dist.is_available() and dist.is_initialized()
+    clock = Clock(torch, dist, 2 if group_on else 1, dev)
 
     # SURVEY.md section 8d "perf" distribution: uniform 12-bit codes, raw = u16 / 4095 (float32)
     u16 = np.random.default_rng(rank).integers(0, 4096, (B, S, S)).astype(np.uint16)
@@ -609,17 +622,17 @@ def main():
     model = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True)
     model = model.to(dev).train()
     model.raw_bits = 12
-    if world > 1:
+    if group_on:
         model.process_group = dist.group.WORLD
     params = list(model.parameters())
     fwd = model
     nccl = os.environ.get('R2L_BENCH_BACKEND', 'nccl') == 'nccl'
     if args.graph:
-        if world > 1 and not nccl:
+        if group_on and not nccl:
             raise SystemExit('bench.py: --graph with several ranks needs RCCL (a gloo group moves host memory: not capturable)')
         from raw2logit_amd.graphs import StepGraph
         # several ranks: the two statistics all-gathers and the gradient all-reduce are captured with the kernels
-        graph_step = StepGraph(model, raw, cot, process_group=dist.group.WORLD if world > 1 else None)
+        graph_step = StepGraph(model, raw, cot, process_group=dist.group.WORLD if group_on else None)
 
     pending = []
 
@@ -636,7 +649,7 @@ def main():
             p.grad = None
         y = fwd(raw)
         y.backward(cot)
-        if world > 1:                                # data-parallel sum of the 132-float ISP gradient, asynchronous
+        if group_on:                                 # data-parallel sum of the 132-float ISP gradient, asynchronous
             pending.append(F_.GradAllReduce(params, dist.group.WORLD))
 
     # GPU clocks: this process has just spent ~30 s on the host (the cpu_baseline leg) and finds the chip at idle clocks;
@@ -655,10 +668,10 @@ def main():
     comm_us = None
     if not args.no_roofline:
         # instrumented pass of the same K steps with the library's per-kernel HIP-event hooks switched on
-        F_.CommTimer.enable(world > 1)
+        F_.CommTimer.enable(group_on)
         # (a replayed graph makes no library calls: the per-kernel hooks see the same kernels through the eager step)
         kernels = kernel_times(lib, clock, (lambda: step(True)) if args.graph else step, args.steps, finish)
-        comm_us = F_.CommTimer.report() if world > 1 else None
+        comm_us = F_.CommTimer.report() if group_on else None
         F_.CommTimer.enable(False)
 
     if kernels:
@@ -682,20 +695,6 @@ def main():
                         'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
 
     graph_ms = graph_err = None
-    if world > 1 and nccl and dev.type == 'cuda' and not args.graph and args.graph_also:
-        # the same data-parallel step as ONE HIP graph with its RCCL collectives captured (raw2logit_amd/graphs.py): at
-        # BASELINE config 5's 64 x 256 x 256 per GPU the eager step is host-bound, and every rank pays the host twice more
-        # around the two all-gathers
-        try:
-            from raw2logit_amd.graphs import StepGraph
-            finish()
-            m2 = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True).to(dev).train()
-            m2.raw_bits = 12
-            g2 = StepGraph(m2, raw, cot, process_group=dist.group.WORLD)
-            clock.preroll(g2.replay, None, 0.05)
-            graph_ms = 1e3 * clock.time_steps(g2.replay, args.steps, args.warmup) / args.steps
-        except Exception as e:                       # noqa: BLE001
-            graph_err = '%s: %s' % (type(e).__name__, e)
     static_c3 = small = None
     # (sub-records: a failure in one of them must not cost the headline line -- it is reported in its place)
     if world == 1 and dev.type == 'cuda' and not args.no_small_shapes:
@@ -711,11 +710,15 @@ def main():
         except Exception as e:                       # noqa: BLE001
             static_c3 = {'error': '%s: %s' % (type(e).__name__, e)}
 
-    if rank == 0:
+    def line(graph_ms, graph_err):
+        """the JSON line: the faster of the eager step and -- several RCCL ranks -- the step as one HIP graph is its value"""
+        use_graph = graph_ms is not None and graph_ms < 1e3 * dt / args.steps
+        ms = graph_ms if use_graph else 1e3 * dt / args.steps
+        val = px_per_step / (ms * 1e-3) / 1e6
         out = {
-            'metric': 'ISP Mpix/s (fwd+bwd) on 512x512 raw batches', 'value': round(value, 1),
+            'metric': 'ISP Mpix/s (fwd+bwd) on 512x512 raw batches', 'value': round(val, 1),
             'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic' + (' (uint16 containers)' if args.raw_u16 else '') +
                     (' -- HOST EMULATION: functional check of the launcher, not a measurement'
@@ -726,13 +729,13 @@ def main():
             'config': {'workload': f'parametrized ISP fwd+bwd, BatchNorm train, {B}x{S}x{S} 12-bit RGGB '
                                    f'frames per GPU, Drone camera parameters',
                        'global_batch': world * B, 'frame': [S, S],
-                       'parallelism': f'batch shard x{world}' if world > 1 else 'single GPU',
-                       'step': 'forward + backward' + (' + 132-float grad all-reduce' if world > 1 else '')},
+                       'parallelism': f'batch shard x{world}' if group_on else 'single GPU',
+                       'step': 'forward + backward' + (' + 132-float grad all-reduce' if group_on else '')},
             'roofline': roofline,
             # the whole step against SURVEY.md section 8d's 52 B/px (single fused backward)
-            'step_roofline': {'algo_bytes_per_px': 52.0, 'achieved': round(px_per_step / world * 52.0 * args.steps / dt / 1e9, 1),
+            'step_roofline': {'algo_bytes_per_px': 52.0, 'achieved': round(px_per_step / world * 52.0 / (ms * 1e-3) / 1e9, 1),
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': round(px_per_step / world * 52.0 * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
+                              'frac': round(px_per_step / world * 52.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             'kernels': kernels,
             # the kernels' HIP events sit between the launches of the instrumented pass: each event pair costs the queue
             # ~2 us, so that pass runs slower than the timed one -- its own wall clock is the one the kernel sum must fit in
@@ -745,6 +748,10 @@ def main():
         if graph_ms is not None:
             out['ms_per_step_graph'] = round(graph_ms, 4)
             out['value_graph'] = round(px_per_step / (graph_ms * 1e-3) / 1e6, 1)
+            out['ms_per_step_eager'] = round(1e3 * dt / args.steps, 4)
+            out['value_eager'] = round(value, 1)
+            out['launch'] = ('one HIP graph per step, its RCCL collectives captured (raw2logit_amd/graphs.py: StepGraph)'
+                             if use_graph else 'eager (the graph was not faster)')
         if graph_err is not None:
             out['graph_error'] = graph_err
         if comm_us is not None:
@@ -759,8 +766,47 @@ def main():
             out['static_c3'] = static_c3
         if cpu is not None:
             out['cpu_baseline'] = cpu
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        return out
+
+    # ---- several ranks over RCCL: the same data-parallel step as ONE HIP graph with its collectives captured.  At N > 1 the eager
+    # step pays the host three more times (two statistics all-gathers, the gradient all-reduce) and is host-bound; the graph costs
+    # one launch.  The eager line is complete at this point: a watchdog prints it and ends the process should the trial not come
+    # back (a capture or a replay that hangs on one rank), and the ranks agree on success before anything collective is timed.
+    if group_on and nccl and dev.type == 'cuda' and not args.graph and not args.no_graph_trial:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps(line(None, 'watchdog: the graph trial did not finish in %d s' % GRAPH_TRIAL_TIMEOUT_S)), flush=True)
+            os._exit(0)
+        dog = threading.Timer(GRAPH_TRIAL_TIMEOUT_S, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            from raw2logit_amd.graphs import StepGraph
+            finish()
+            ok, g2 = 1.0, None
+            try:
+                m2 = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True).to(dev).train()
+                m2.raw_bits = 12
+                g2 = StepGraph(m2, raw, cot, process_group=dist.group.WORLD)
+            except Exception as e:                   # noqa: BLE001
+                ok, graph_err = 0.0, '%s: %s' % (type(e).__name__, e)
+            t = torch.tensor([ok], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)     # every rank captured, or nobody replays
+            if float(t.item()) > 0:
+                g2.replay()
+                torch.cuda.synchronize()
+                clock.preroll(g2.replay, None, 0.05)
+                graph_ms = 1e3 * clock.time_steps(g2.replay, args.steps, args.warmup) / args.steps
+            elif graph_err is None:
+                graph_err = 'the capture failed on another rank'
+        except Exception as e:                       # noqa: BLE001
+            graph_ms, graph_err = None, '%s: %s' % (type(e).__name__, e)
+        dog.cancel()
+    if rank == 0:
+        print(json.dumps(line(graph_ms, graph_err)), flush=True)
+    if group_on:
         dist.barrier()
         dist.destroy_process_group()
 

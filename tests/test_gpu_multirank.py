@@ -237,3 +237,27 @@ def test_bench_two_gloo_ranks_on_the_device(dev):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, 'bench_gloo2_functional.json'), 'w') as f:
             json.dump(out, f)
+
+
+def test_bench_graph_trial_with_one_rccl_rank(dev):
+    """The N > 1 branch of `bench.py` on the one-GPU box (R2L_BENCH_ONE_RANK_DIST=1: a one-rank RCCL group, the exchange path
+    forced): eager measurement, then the graph trial -- capture with the collectives, agreement between the ranks, the same
+    timing protocol under the watchdog -- and a line that carries both numbers and says which one is its value."""
+    import json
+    e = dict(os.environ, R2L_BENCH_ONE_RANK_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(_free_port()))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '10', '--warmup', '3', '--batch', '64',
+                        '--size', '256', '--quick'], env=e, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out, = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{')]
+    assert 'graph_error' not in out, out.get('graph_error')
+    assert out['ms_per_step_graph'] > 0 and out['ms_per_step_eager'] > 0
+    assert out['ms_per_step'] == min(out['ms_per_step_graph'], out['ms_per_step_eager'])
+    assert set(out['comm_us']) == {'bn statistics all-gather', 'bn-bwd sums all-gather', 'grad all-reduce'}
+    print(f"bench graph trial, one RCCL rank, 64x256x256: {out['ms_per_step_eager']} ms per step eager, "
+          f"{out['ms_per_step_graph']} as one graph")
+    out_dir = os.path.join(REPO, 'gpurun_out')
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, 'bench_rccl_x1_graph_trial.json'), 'w') as f:
+            json.dump(out, f)
