@@ -27,7 +27,7 @@ CASES = (
     ('staged_f32', (4, 24, 40), 'f32', 'staged', 'drone'),        # track_stages=True: the stage-by-stage kernels
     ('staged_u16', (2, 16, 24), 'u16', 'staged', 'drone'),
     ('config5_shard', (128, 256, 256), 'f32', 'fused', 'drone'),  # BASELINE config 5's per-GPU share (64 x 256 x 256) x 2
-    ('planes_shard', (48, 512, 512), 'f32', 'fused', 'drone'),    # 24 x 512 x 512 per rank = 6 Mpx: the backward as passes over planes
+    ('planes_shard', (48, 512, 512), 'f32', 'fused', 'drone'),    # 24 x 512 x 512 per rank (>= 4 Mi px): the backward as passes over planes
 )
 
 

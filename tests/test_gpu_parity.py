@@ -50,7 +50,7 @@ def test_frame_shapes_around_tile_boundaries(dev):
 
 # ---- the plane-pass backward (r2l_param_plane_bwd.h: bwd1_plane, bwd1_blur_hp | bwd1_blur + bwd2_hp, bwd2_sums) -- the
 # kernels behind the headline number -- DIRECTLY against the float64 oracle, the reference's golden float32 gradients and
-# its own float64 run (grad64).  The shipped library takes them at B*H*W >= 6 Mi px only, so the small cases run on the
+# its own float64 run (grad64).  The shipped library takes them at B*H*W >= 4 Mi px only, so the small cases run on the
 # diagnostic build with R2L_BWD_PLANES=1 (same source); test_plane_backward_at_the_dispatch_threshold runs the shipped one.
 PLANE_MODES = {'fused-middle-pass': {'R2L_BWD_PLANES': '1'},
                'split-blur': {'R2L_BWD_PLANES': '1', 'R2L_BWD_SPLIT_BLUR': '1'}}
@@ -651,7 +651,7 @@ def test_backward_kernels_as_passes_over_planes(shape, dev):
                 raw = torch.from_numpy(u).to(dev)
             else:
                 raw = torch.from_numpy(u.astype(np.float32) / np.float32(4095)).to(dev)
-            env = dict(env, R2L_BWD_PLANES='1')      # (the default only for batches of >= 6 Mpx)
+            env = dict(env, R2L_BWD_PLANES='1')      # (the default only for batches of >= 4 Mi px)
             os.environ.update(env)
             try:
                 with pc.launch_shape_overrides(dev):
