@@ -1261,8 +1261,18 @@ R2L_HD float r2l_b1_slot(const R2LBwd1Regs& r, int i) {
 #define R2L_ACC_B1(regs, i) r2l_b1_slot(R2L_TREG(regs), i)
 
 struct R2LBnConsts {
-  float mean[3], istd[3], mg[3], mgx[3];
+  float mean[3], istd[3], mg[3], mgx[3];  // mg, mgx: istd * mean(g), istd * mean(g * xhat) (r2l_bn_bwd_pair)
 };
+// BatchNorm2d backward of one pixel pair, train mode: istd * (g - mean(g) - xhat * mean(g * xhat)), evaluated as
+// fma(istd, g, -istd * mean(g)) - xhat * (istd * mean(g * xhat)).  Not (g - mean(g)) first: mean(g) is small against g, so
+// that difference rounds by the SAME amount for every g of a binade (-(mean(g) mod ulp)) -- a bias of ~ N ulp / 4 in every sum
+// over the N pixels of a plane, which the black-level gradient (a sum that cancels to 1/1000 of its terms when BatchNorm sits
+// on low-variance frames) showed as 3e-4 of its scale; the product istd * g has fresh low bits for every pixel.  In eval mode
+// mg = mgx = 0 and only the scaling remains; without BatchNorm istd = 1 too, which leaves g unchanged (exactly).
+R2L_HD r2l_p2 r2l_bn_bwd_pair(r2l_p2 g, r2l_p2 xhat, float istd, float c0, float c1) {
+  return r2l_pfma(xhat, r2l_splat2(-c1), r2l_pfma(r2l_splat2(istd), g, r2l_splat2(-c0)));
+}
+
 
 // 4 consecutive pixels of the ISP's layout read back from the augmented layout: p = the position of the first one
 R2L_HD r2l_f4 r2l_epi_load4(const float* p, int sc) {
@@ -1431,11 +1441,7 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
       r2l_p2 x = og;
       if (ADD) x = r2l_padd(x, r2l_mk2(valid0 ? a.additive[off + 2 * p] : 0.f, valid1 ? a.additive[off + 2 * p + 1] : 0.f));
       const r2l_p2 xhat = r2l_pmul(r2l_padd(x, r2l_splat2(-bc.mean[k])), r2l_splat2(bc.istd[k]));
-      // BatchNorm2d backward, train mode: istd * (g - mean(g) - xhat * mean(g*xhat)); in eval mode
-      // mg = mgx = 0 and only the scaling remains; without BatchNorm mean = 0, istd = 1 too, which
-      // leaves g unchanged (exactly)
-      r2l_p2 gx = r2l_padd(r2l_mk2(g[2 * p], g[2 * p + 1]), r2l_splat2(-bc.mg[k]));
-      gx = r2l_pmul(r2l_splat2(bc.istd[k]), r2l_pfma(xhat, r2l_splat2(-bc.mgx[k]), gx));
+      r2l_p2 gx = r2l_bn_bwd_pair(r2l_mk2(g[2 * p], g[2 * p + 1]), xhat, bc.istd[k], bc.mg[k], bc.mgx[k]);
       if (RAGGED) gx = r2l_mk2(valid0 ? gx[0] : 0.f, valid1 ? gx[1] : 0.f);
       const r2l_p2 gxo = r2l_pmul(gx, og);
       ggam = r2l_pfma(gxo, lg, ggam);
@@ -1555,8 +1561,7 @@ R2L_HD void r2l_bwd1_rows2(const float* V, const float* YP, const R2LBwd1Args& a
         r2l_p2 x = og;
         if (ADD) x = r2l_padd(x, r2l_mk2(a.additive[off + 2 * p], a.additive[off + 2 * p + 1]));
         const r2l_p2 xhat = r2l_pmul(r2l_padd(x, r2l_splat2(-bc.mean[k])), r2l_splat2(bc.istd[k]));
-        r2l_p2 gx = r2l_padd(r2l_mk2(g[2 * p], g[2 * p + 1]), r2l_splat2(-bc.mg[k]));  // BatchNorm2d backward
-        gx = r2l_pmul(r2l_splat2(bc.istd[k]), r2l_pfma(xhat, r2l_splat2(-bc.mgx[k]), gx));
+        r2l_p2 gx = r2l_bn_bwd_pair(r2l_mk2(g[2 * p], g[2 * p + 1]), xhat, bc.istd[k], bc.mg[k], bc.mgx[k]);
         const r2l_p2 gxo = r2l_pmul(gx, og);
         ggam = r2l_pfma(gxo, lg, ggam);
         const r2l_p2 gc = r2l_pmul(r2l_pmul(gxo, r2l_splat2(F.inv_gamma)), r2l_mk2(r2l_rcp(xc[0]), r2l_rcp(xc[1])));
@@ -1640,8 +1645,8 @@ R2L_HD void r2l_bwd1_pixels(int tid, const float* V, const float* YP, const R2LB
   for (int k = 0; k < 3; ++k) {
     bc.mean[k] = a.bn ? a.bn[k] : 0.f;
     bc.istd[k] = a.bn ? a.bn[3 + k] : 1.f;
-    bc.mg[k] = a.bn_bwd ? a.bn_bwd[k] : 0.f;
-    bc.mgx[k] = a.bn_bwd ? a.bn_bwd[3 + k] : 0.f;
+    bc.mg[k] = a.bn_bwd ? bc.istd[k] * a.bn_bwd[k] : 0.f;
+    bc.mgx[k] = a.bn_bwd ? bc.istd[k] * a.bn_bwd[3 + k] : 0.f;
   }
 #ifndef R2L_B1_ROW_MAJOR
   if (!RAGGED && PRE) {

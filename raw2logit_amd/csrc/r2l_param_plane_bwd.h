@@ -150,8 +150,7 @@ R2L_HD void r2l_bp_step(const R2LBwd1Args& a, R2LBpState& st, R2LBpAcc& A, const
         const r2l_p2 e = r2l_pmul(lg, r2l_splat2(F.inv_gamma));
         const r2l_p2 og = r2l_mk2(r2l_exp2(e[0]), r2l_exp2(e[1]));
         const r2l_p2 xhat = r2l_pmul(r2l_padd(og, r2l_splat2(-bc.mean[k])), r2l_splat2(bc.istd[k]));
-        r2l_p2 gx = r2l_padd(r2l_mk2(g[2 * p], g[2 * p + 1]), r2l_splat2(-bc.mg[k]));  // BatchNorm2d backward
-        gx = r2l_pmul(r2l_splat2(bc.istd[k]), r2l_pfma(xhat, r2l_splat2(-bc.mgx[k]), gx));
+        r2l_p2 gx = r2l_bn_bwd_pair(r2l_mk2(g[2 * p], g[2 * p + 1]), xhat, bc.istd[k], bc.mg[k], bc.mgx[k]);
         if (!store_ok) gx = r2l_splat2(0.f);  // lanes past the frame's last column, rows past the band's end
         const r2l_p2 gxo = r2l_pmul(gx, og);
         ggam = r2l_pfma(gxo, lg, ggam);
@@ -279,8 +278,8 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
   for (int k = 0; k < 3; ++k) {
     bc.mean[k] = a.bn ? a.bn[k] : 0.f;
     bc.istd[k] = a.bn ? a.bn[3 + k] : 1.f;
-    bc.mg[k] = a.bn_bwd ? a.bn_bwd[k] : 0.f;
-    bc.mgx[k] = a.bn_bwd ? a.bn_bwd[3 + k] : 0.f;
+    bc.mg[k] = a.bn_bwd ? bc.istd[k] * a.bn_bwd[k] : 0.f;
+    bc.mgx[k] = a.bn_bwd ? bc.istd[k] * a.bn_bwd[3 + k] : 0.f;
   }
   // the streaming kernels' argument block, for their raw-row fetch / convert (r2l_fa_fetch_raw, r2l_fs_convert)
   R2LFwdStreamArgs sa;

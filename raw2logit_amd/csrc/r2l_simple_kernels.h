@@ -244,19 +244,19 @@ R2L_BLOCKFN void r2l_add_bwd_block(const R2LAddBwdArgs& a, int bid, int nblk, fl
     const int k = (int)(e / hw);
     float istd = 1.f, mg = 0.f, mgx = 0.f;
     if (a.bn) istd = a.bn[3 + k];
-    if (a.bn_bwd) {
-      mg = a.bn_bwd[k];
-      mgx = a.bn_bwd[3 + k];
+    if (a.bn_bwd) {  // (istd * mean(g), istd * mean(g * xhat): the bias-free form of r2l_bn_bwd_pair)
+      mg = istd * a.bn_bwd[k];
+      mgx = istd * a.bn_bwd[3 + k];
     }
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < a.B; ++b) {
       const r2l_f4 g = *(const r2l_f4*)(a.gout + (size_t)b * 3 * hw + e);
       if (a.bn) {
         const r2l_f4 o = *(const r2l_f4*)(a.out + (size_t)b * 3 * hw + e);
-        s[0] += istd * (g.x - mg - o.x * mgx);
-        s[1] += istd * (g.y - mg - o.y * mgx);
-        s[2] += istd * (g.z - mg - o.z * mgx);
-        s[3] += istd * (g.w - mg - o.w * mgx);
+        s[0] += fmaf(o.x, -mgx, fmaf(istd, g.x, -mg));
+        s[1] += fmaf(o.y, -mgx, fmaf(istd, g.y, -mg));
+        s[2] += fmaf(o.z, -mgx, fmaf(istd, g.z, -mg));
+        s[3] += fmaf(o.w, -mgx, fmaf(istd, g.w, -mg));
       } else {
         s[0] += g.x;
         s[1] += g.y;

@@ -254,7 +254,7 @@ R2L_BLOCKFN void r2l_pconv_bwd_block(const R2LStageArgs& a, int bid, int nblk, f
 // op 0 clip fwd: y = clamp(x, 1e-5, 1)                 op 1 clip bwd: y = g * [1e-5 <= x <= 1]
 // op 2 gamma fwd: y = exp(log(x) / w[0])               op 3 gamma bwd: y = g * out / (gamma * x), acc: g*out*ln x
 // op 4 add fwd: y = x + w[(c,h,w)] (broadcast over B)
-// op 5 bn apply: y = (x - w[c]) * w[3+c]                op 6 bn bwd: y = w[3+c] * (g - aux2[c] - out * aux2[3+c])
+// op 5 bn apply: y = (x - w[c]) * w[3+c]                op 6 bn bwd: y = w[3+c] * g - w[3+c] * aux2[c] - out * w[3+c] * aux2[3+c]
 // op 7 bn stats: acc[c] += x - .5, acc[3+c] += (x - .5)^2
 // op 8 normalize: y = (x - w[c]) / w[3+c]  (torchvision T.Normalize(mean, std), train.py:157-171)
 struct R2LPointArgs {
@@ -301,7 +301,9 @@ R2L_BLOCKFN void r2l_point_block(const R2LPointArgs& a, int bid, int nblk, float
         case 4: o[q] = xv[q] + a.w[(e + q) % (3 * hw)]; break;
         case 5: o[q] = (xv[q] - a.w[c]) * a.w[3 + c]; break;
         case 8: o[q] = (xv[q] - a.w[c]) / a.w[3 + c]; break;
-        case 6: o[q] = a.w[3 + c] * (gv[q] - (a.aux2 ? a.aux2[c] : 0.f) - av[q] * (a.aux2 ? a.aux2[3 + c] : 0.f)); break;
+        case 6:  // (the bias-free form of r2l_bn_bwd_pair: istd * g first, then the two small terms)
+          o[q] = fmaf(av[q], -(a.aux2 ? a.w[3 + c] * a.aux2[3 + c] : 0.f), fmaf(a.w[3 + c], gv[q], -(a.aux2 ? a.w[3 + c] * a.aux2[c] : 0.f)));
+          break;
         default: {
           const float d = xv[q] - 0.5f;
           R2L_PRAGMA_UNROLL

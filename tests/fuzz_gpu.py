@@ -17,7 +17,9 @@ t0 = time.time()
 n = 0
 worst = {'out': 0.0, 'grad': 0.0}
 failures = []      # (FUZZ_KEEP_GOING=1: collect instead of stopping at the first one -- calibration runs)
-while time.time() - t0 < budget:
+max_cases = int(os.environ.get('FUZZ_CASES', '0'))      # A/B runs: stop after this many cases instead of after SECONDS
+force = set(filter(None, os.environ.get('FUZZ_FORCE', '').split(',')))   # A/B runs: e.g. additive,train,midtone
+while (n < max_cases) if max_cases else (time.time() - t0 < budget):
     B = int(rng.integers(1, 4))
     H = 2 * int(rng.integers(2, 90))
     W = 2 * int(rng.integers(2, 110))
@@ -25,6 +27,9 @@ while time.time() - t0 < budget:
     bn = ['none', 'train', 'eval'][int(rng.integers(0, 3))]
     kind = ['scene', 'uniform', 'dark', 'midtone', 'midtone'][int(rng.integers(0, 5))]
     additive = rng.integers(0, 12) == 0          # the additive layer is (1,3,256,256): frames of that size only
+    bn = ([b for b in ('none', 'train', 'eval') if b in force] or [bn])[0]
+    kind = ([k for k in ('scene', 'uniform', 'dark', 'midtone') if k in force] or [kind])[0]
+    additive = additive or 'additive' in force
     if additive:
         B, H, W = int(rng.integers(1, 3)), 256, 256
     u16 = bool(rng.integers(0, 2)) and W % 4 == 0
@@ -144,8 +149,10 @@ while time.time() - t0 < budget:
             if not os.environ.get('FUZZ_KEEP_GOING'):
                 raise SystemExit(1)
             failures.append((k, float(e / lim), (B, H, W, bn, kind, u16)))
-        worst['grad'] = max(worst['grad'], float(e / lim))
+        if float(e / lim) > worst['grad']:
+            worst['grad'], worst['grad_at'] = float(e / lim), (n, k, (B, H, W, bn, kind, u16, bool(additive)))
     n += 1
+print('worst gradient ratio %.3f at case' % worst['grad'], worst.get('grad_at'))
 for f in failures:
     print('over its limit (ratio %.2f):' % f[1], f[0], f[2])
 if failures:
