@@ -157,6 +157,45 @@ def test_plane_backward_at_the_dispatch_threshold(dev):
             assert e <= lim, (bn, k, e, lim)
 
 
+def test_plane_backward_beyond_one_round_of_workgroups(dev):
+    """72 x 512 x 512: the sums pass has 792 work-item quadruples for its 768 resident workgroups, so its workgroups loop over
+    items and the 14 helper workgroups (B1's partials) only find a slot when the first of them retires -- the launch's last
+    arrival may be a helper.  Size-independent property (eval-mode BatchNorm decouples the frames): all 132 gradients of the
+    whole batch equal the sum of the gradients of its two halves (396 workgroups each); two runs are bitwise identical."""
+    import copy
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+    B, H, W = 72, 512, 512
+    raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=3, kind='uniform')).to(dev)
+    m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).to(dev)
+    m.eval()
+    with torch.no_grad():
+        m.batch_norm.running_mean.copy_(torch.tensor([0.3, 0.35, 0.4]))
+        m.batch_norm.running_var.copy_(torch.tensor([0.02, 0.03, 0.025]))
+    g = torch.randn((B, 3, H, W), device=dev, generator=torch.Generator(dev).manual_seed(2))
+    runs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        m(raw).backward(g)
+        runs.append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    acc = {k: torch.zeros_like(v) for k, v in runs[0].items()}
+    for h in range(2):
+        mh = copy.deepcopy(m)
+        for p in mh.parameters():
+            p.grad = None
+        sl = slice(36 * h, 36 * (h + 1))
+        mh(raw[sl]).backward(g[sl])
+        for k, p in mh.named_parameters():
+            acc[k] += p.grad
+    for k in acc:
+        scale = runs[0][k].abs().max().item() + 1e-6
+        e = (acc[k] - runs[0][k]).abs().max().item()
+        pc.report(f'72x512x512/grad {k}: whole batch (looping workgroups, late helpers) vs sum of halves', e, 1e-4 * scale)
+        assert e <= 1e-4 * scale, (k, e, scale)
+
+
 def test_cpu_tensor_is_refused(dev):
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     from raw2logit_amd import _lib
