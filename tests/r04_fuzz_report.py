@@ -1,5 +1,5 @@
 """Assemble profiles/r04_fuzz.txt from the sweeps' outputs under gpurun_out/ (final build: r04_fuzz_b1 = seeds 101-103 + fuzz_more,
-r04_fuzz3 = seeds 111-113; earlier builds of the round: the text kept in profiles/r04_fuzz_earlier.txt)."""
+r04_fuzz_b2 = seeds 111-113, r04_fuzz3 = seeds 121-123; earlier builds of the round: the text kept in profiles/r04_fuzz_earlier.txt)."""
 import os, re
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(REPO, 'gpurun_out')
@@ -13,7 +13,8 @@ The literal per-pixel form the round-3 review asked for -- max(tolerance, 2 x |o
 float32 ORACLE leaves that envelope more often than the kernels.  FAIL lines on the final build: none.
 ''']
 totals = {m: [0, 0.0, 0.0, 0.0] for m, _ in MODES}
-for tag, d, secs in (('SEED 101-103, 300 s per mode', 'r04_fuzz_b1', 300), ('SEED 111-113, 250 s per mode', 'r04_fuzz3', 250)):
+for tag, d, secs in (('SEED 101-103, 300 s per mode', 'r04_fuzz_b1', 300), ('SEED 111-113, 250 s per mode', 'r04_fuzz_b2', 250),
+                     ('SEED 121-123, 480 s per mode', 'r04_fuzz3', 480)):
     out.append('--- ' + tag)
     for m, name in MODES:
         L = [l.rstrip() for l in open(os.path.join(G, d, m + '.txt')).read().splitlines() if l.strip() and 'amdgpu.ids' not in l]
