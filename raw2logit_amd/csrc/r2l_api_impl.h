@@ -797,7 +797,7 @@ int r2l_bn_bwd_reduce(const float* grad_out, const float* out, const double* tot
   const bool in_kernel = (flags & R2L_F_FOLDED_VALID) != 0 && !(r2l_env_int("R2L_EXP_NO_TREE", 0) & 2);
   R2LBnReduceArgs a{grad_out, out, ws.part_small, B, H, W,
                     R2LTree{ws.part_small, nullptr, ws.gpartial, in_kernel ? ws.counters : nullptr, 6, 0},
-                    sums, totals, bn_bwd};
+                    sums, totals, bn_bwd, r2l_env_int("R2L_BNR_ORDER", 0)};
   if (int e = r2l_launch_bn_reduce(a, grid, stream)) return e;
   if (in_kernel) return 0;
   R2LReduceRowsArgs r{ws.part_small, sums, grid, 1.0, bn_bwd, nullptr, 0.0, bn_bwd ? totals + 6 : nullptr};

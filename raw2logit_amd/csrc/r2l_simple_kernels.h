@@ -163,6 +163,7 @@ struct R2LBnReduceArgs {
   double* sums;
   const double* totals;  // optional: totals[6] = pixel count n of the global batch
   float* bn_bwd;         // optional (needs totals): mean_c(g)[3], mean_c(g*xhat)[3] = sums / n as float32
+  int order;             // 0: items in memory order; 1: from the end of the tensors to their start (diagnostic builds)
 };
 struct R2LAcc6 {
   float acc[6];
@@ -206,7 +207,8 @@ R2L_BLOCKFN void r2l_bn_reduce_block(const R2LBnReduceArgs& a, int bid, int nblk
   const int nsegpp = (int)((hw + R2L_SEG - 1) / R2L_SEG);
   const int nitems = 3 * a.B * nsegpp;
   R2L_PHASE_BEGIN  // one phase: the wavefronts stream independently (a barrier per item would cap the loads in flight)
-  for (int item = bid; item < nitems; item += nblk) r2l_bn_reduce_item(tid, a, item, nsegpp, R2L_TREG(regs));
+  for (int item = bid; item < nitems; item += nblk)
+    r2l_bn_reduce_item(tid, a, a.order ? nitems - 1 - item : item, nsegpp, R2L_TREG(regs));
   R2L_PHASE_END
   R2L_TAILST(10);
   R2L_BLOCK_REDUCE(6, regs, lds, a.partial, bid, nblk)
