@@ -37,7 +37,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-GRAPH_TRIAL_TIMEOUT_S = 90      # several ranks: capture + agreement + timing of the graph trial, or the eager line goes out
+# several ranks: capture + agreement + timing of the graph trial, or the eager line goes out (the environment variable: tests)
+GRAPH_TRIAL_TIMEOUT_S = float(os.environ.get('R2L_BENCH_TRIAL_TIMEOUT_S', '90'))
 PREROLL_S = float(os.environ.get('R2L_BENCH_PREROLL_S', '0.3'))   # untimed pre-roll of the step before the W warm-up steps
                                # (GPU clocks, see main(); counter-collection runs of the profiling scripts set 0)
 # algorithmic HBM bytes per raw pixel of each kernel family, by kernel-name prefix; the
@@ -777,7 +778,7 @@ def main():
 
         def give_up():
             if rank == 0:
-                print(json.dumps(line(None, 'watchdog: the graph trial did not finish in %d s' % GRAPH_TRIAL_TIMEOUT_S)), flush=True)
+                print(json.dumps(line(None, 'watchdog: the graph trial did not finish in %g s' % GRAPH_TRIAL_TIMEOUT_S)), flush=True)
             os._exit(0)
         dog = threading.Timer(GRAPH_TRIAL_TIMEOUT_S, give_up)
         dog.daemon = True

@@ -261,3 +261,20 @@ def test_bench_graph_trial_with_one_rccl_rank(dev):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, 'bench_rccl_x1_graph_trial.json'), 'w') as f:
             json.dump(out, f)
+
+
+def test_bench_graph_trial_watchdog(dev):
+    """The same branch with a watchdog of 1 ms: the timer fires while the capture is still under way, rank 0 prints the EAGER line with
+    the reason in `graph_error`, and the process ends with exit code 0 -- what a hanging capture or replay on a real multi-GPU node
+    would leave behind instead of no line at all."""
+    import json
+    e = dict(os.environ, R2L_BENCH_ONE_RANK_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(_free_port()),
+             R2L_BENCH_TRIAL_TIMEOUT_S='0.001')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '5', '--warmup', '2', '--batch', '16',
+                        '--size', '256', '--quick'], env=e, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out, = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{')]
+    assert 'watchdog' in out['graph_error'] and 'ms_per_step_graph' not in out
+    assert out['ms_per_step'] > 0 and out['value'] > 0
