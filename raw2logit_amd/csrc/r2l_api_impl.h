@@ -72,6 +72,46 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
   std::lock_guard<std::mutex> g(r2l_timing_mutex);
   r2l_timed.push_back(t);
 }
+// Diagnostic builds (-DR2L_TEST_HOOKS) can put something in front of a launch whose name contains one of the comma-separated
+// substrings of an environment variable, outside the launch's timing events (tests/experiments/mall_probe_step.py):
+//   R2L_EXP_FLUSH  a pass that reads and re-writes a 768 MB scratch allocation (evicts the L2s and the 256 MB memory-side
+//                  cache: what the kernel costs when its predecessor left it nothing);
+//   R2L_EXP_TWICE  an untimed launch of the same kernel (what it costs when everything it touches was touched just now).
+#ifdef R2L_TEST_HOOKS
+__global__ __launch_bounds__(256) void r2l_exp_flush_kernel(float4* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float4 v = p[i];
+    v.x += 1.f;
+    p[i] = v;
+  }
+}
+static bool r2l_exp_match(const char* env, const char* name) {
+  const char* s = getenv(env);
+  if (!s || !*s) return false;
+  std::string list(s), nm(name);
+  size_t pos = 0;
+  while (pos <= list.size()) {
+    size_t c = list.find(',', pos);
+    if (c == std::string::npos) c = list.size();
+    const std::string tok = list.substr(pos, c - pos);
+    if (!tok.empty() && (tok == "all" || nm.find(tok) != std::string::npos)) return true;
+    pos = c + 1;
+  }
+  return false;
+}
+static void r2l_exp_pre_launch(const char* name, hipStream_t s) {
+  if (!r2l_exp_match("R2L_EXP_FLUSH", name)) return;
+  static float4* buf = nullptr;
+  const size_t n = ((size_t)768 << 20) / sizeof(float4);
+  if (!buf && hipMalloc((void**)&buf, n * sizeof(float4)) != hipSuccess) return;
+  hipLaunchKernelGGL(r2l_exp_flush_kernel, dim3(4096), dim3(256), 0, s, buf, n);
+}
+#define R2L_PRE_LAUNCH(name, stream) r2l_exp_pre_launch(name, (hipStream_t)(stream))
+#define R2L_TWICE(name) r2l_exp_match("R2L_EXP_TWICE", name)
+#else
+#define R2L_PRE_LAUNCH(name, stream)
+#define R2L_TWICE(name) false
+#endif
 #define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS) R2L_KERNEL_OCC(name, ArgsT, blockfn, LDS_FLOATS, 1)
 // LDS-free kernels with their own workgroup size (independent wavefronts)
 #define R2L_KERNEL_NT(name, ArgsT, blockfn, NT, WAVES_PER_SIMD)                                 \
@@ -81,6 +121,8 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
   static int name(const ArgsT& a, int grid, void* stream) {                                    \
     R2LTimedLaunch t_;                                                                         \
     const bool timed_ = r2l_timing_on;                                                         \
+    if (R2L_TWICE(#name)) hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a); \
+    R2L_PRE_LAUNCH(#name, stream);                                                             \
     if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                      \
     hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);       \
     if (timed_) r2l_time_end((hipStream_t)stream, t_);                                         \
@@ -97,6 +139,8 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
   static int name(const ArgsT& a, int grid, void* stream) {                                    \
     R2LTimedLaunch t_;                                                                         \
     const bool timed_ = r2l_timing_on;                                                         \
+    if (R2L_TWICE(#name)) hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a); \
+    R2L_PRE_LAUNCH(#name, stream);                                                             \
     if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                      \
     hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);       \
     if (timed_) r2l_time_end((hipStream_t)stream, t_);                                         \
@@ -112,6 +156,8 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
   static int name(const ArgsT& a, int grid, void* stream) {                                    \
     R2LTimedLaunch t_;                                                                         \
     const bool timed_ = r2l_timing_on;                                                         \
+    if (R2L_TWICE(#name)) hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(R2L_NT), 0, (hipStream_t)stream, a); \
+    R2L_PRE_LAUNCH(#name, stream);                                                             \
     if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                      \
     hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(R2L_NT), 0, (hipStream_t)stream, a);   \
     if (timed_) r2l_time_end((hipStream_t)stream, t_);                                         \
@@ -127,6 +173,8 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
   static int name(const ArgsT& a, int grid, void* stream) {                                    \
     R2LTimedLaunch t_;                                                                         \
     const bool timed_ = r2l_timing_on;                                                         \
+    if (R2L_TWICE(#name)) hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(R2L_NT), 0, (hipStream_t)stream, a); \
+    R2L_PRE_LAUNCH(#name, stream);                                                             \
     if (timed_) r2l_time_begin(#name "_kernel", (hipStream_t)stream, t_);                      \
     hipLaunchKernelGGL(name##_kernel, dim3(grid), dim3(R2L_NT), 0, (hipStream_t)stream, a);   \
     if (timed_) r2l_time_end((hipStream_t)stream, t_);                                         \
@@ -432,6 +480,32 @@ static int r2l_band_rows(int B, int H, int W, long slots, const char* env) {
   return (r2l_env_int(env, bh) + 5) / 6 * 6;
 }
 
+// XCD windows of the band passes (r2l_xcd_window): neighbouring workgroups per XCD; measured per pass (profiles/r05_xcd_windows.txt)
+#ifndef R2L_XCDM_FS
+#define R2L_XCDM_FS 0   // statistics pass (row-streaming forward)
+#endif
+#ifndef R2L_XCDM_FA
+#define R2L_XCDM_FA 0   // apply pass / luma pass / statistics from the plane
+#endif
+#ifndef R2L_XCDM_BP
+#define R2L_XCDM_BP 0   // kernel B1's plane pass
+#endif
+#ifndef R2L_XCDM_HB
+#define R2L_XCDM_HB 0   // blur sums + blur adjoint
+#endif
+#ifndef R2L_XCDM_B2S
+#define R2L_XCDM_B2S 0  // kernel B2's sums pass
+#endif
+static int r2l_xcdm(const char* env, int dflt) {
+#ifdef R2L_TEST_HOOKS
+  const char* s = getenv(env);
+  if (s && *s) dflt = atoi(s);
+#else
+  (void)env;
+#endif
+  return (dflt > 0 && (dflt & (dflt - 1)) == 0) ? dflt : 0;  // a power of two, or off
+}
+
 // ---- workspace ----------------------------------------------------------------------------------
 struct R2LWorkspace {
   R2LFolded* folded;
@@ -660,6 +734,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
           r2l_launch_fwd_stream_epi_w8_u16}}};
     const bool epi = ep && ep->on && out;
     fa.ep = epi ? *ep : R2LEpi{0, 0, 0, 0};
+    fa.xcdm = r2l_xcdm("R2L_XCD_FS", R2L_XCDM_FS);
     // The passes on the kept luma plane (r2l_param_stream.h: r2l_fwd_luma_block, r2l_fwd_apply_block): independent
     // wavefronts, one per (image, band, 256-column strip); band heights: r2l_band_rows
     const long nstrip = (W + 255) / 256;
@@ -673,6 +748,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     if (!out && stats && (flags & R2L_F_SPLIT_STATS) && kept_ok && split) {
       R2LFwdStreamArgs la = fa;
       la.stat_partial = nullptr;
+      la.xcdm = fa.xcdm = r2l_xcdm("R2L_XCD_FA", R2L_XCDM_FA);
 #ifdef R2L_EXP_STAMPS
       la.tl = (unsigned long long*)ws.debug;
       fa.tl = (unsigned long long*)ws.debug + 8192;
@@ -705,6 +781,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
       fa.yp_in = ws.yp;
       fa.yp_out = nullptr;
       fa.stat_partial = nullptr;
+      fa.xcdm = r2l_xcdm("R2L_XCD_FA", R2L_XCDM_FA);
       fa.band_h = band_rows(256L * 4 * R2L_FA_OCC, "R2L_FA_BAND");
       fa.nband = (H + fa.band_h - 1) / fa.band_h;
       const long grid = (long)B * fa.nband * nstrip;
@@ -844,6 +921,8 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   a1.band_h = 0;
   a1.hp = nullptr;
   a1.band_hb = 0;
+  a1.xcdm = r2l_xcdm("R2L_XCD_BP", R2L_XCDM_BP);
+  a1.xcdm_hb = r2l_xcdm("R2L_XCD_HB", R2L_XCDM_HB);
   if (a1.ep.on && additive) return r2l_fail(-3, "r2l_isp_bwd: no output epilogue with an additive layer");
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
   int g1p = 0;  // workgroups of the plane passes, when they run
@@ -896,6 +975,7 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   const int g2 = r2l_tile_grid(ntiles2, r2l_env_int("R2L_GRID_BWD2", R2L_OCC_BWD2 >= 4 ? 512 : 256));
   R2LBwd2Args a2;
   a2.nmain = 0;
+  a2.xcdm = r2l_xcdm("R2L_XCD_B2S", R2L_XCDM_B2S);
   a2.b1_partial = nullptr;
   a2.b1_n = 0;
   a2.b1_tot = nullptr;

@@ -518,6 +518,15 @@ R2L_HD int r2l_xcd_contiguous(int bid, int nblk) {
 #endif
 }
 
+// The same map with the window size as a launch argument (the band passes of the parametrized step: `m` = neighbouring
+// workgroups per XCD, a power of two, 0 = off).  Only the WORK ITEMS follow the mapped id; partial-sum slots and the
+// reduction trees keep the hardware's workgroup id.
+R2L_HD int r2l_xcd_window(int bid, int nblk, int m) {
+  if (m <= 0) return bid;
+  const int G = 8 * m, w0 = bid & ~(G - 1);
+  return (w0 + G <= nblk) ? w0 + (bid & 7) * m + ((bid - w0) >> 3) : bid;
+}
+
 // Issue priority by PROGRESS.  The wavefronts of a SIMD start together (the band passes are sized for one round of resident
 // wavefronts) and the hardware favours the oldest one whenever several are ready: left alone they finish one after the
 // other, and the last one walks its rows alone with every scalar-load and memory wait exposed (the plane kernels'

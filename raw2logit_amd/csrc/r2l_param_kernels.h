@@ -1231,6 +1231,7 @@ struct R2LBwd1Args {
   int band_h;           // r2l_bwd1_plane_block: rows per work item (a multiple of 6)
   float* hp;            // r2l_bwd1_blur_hp_block: (B,H,W) the blur's adjoint of dL/dY'' (kernel B2's plane)
   int band_hb;          // r2l_bwd1_blur_hp_block: rows per work item (a multiple of 6)
+  int xcdm, xcdm_hb;    // plane passes: neighbouring workgroups per XCD (r2l_xcd_window; 0 = off)
 };
 
 // per-thread accumulators of B1, as pairs: element h of a pair belongs to the pixels in the even (h = 0) or
@@ -1805,6 +1806,7 @@ struct R2LBwd2Args {
   const float* b1_partial;
   int b1_n;
   double* b1_tot;  // [R2L_B1_NACC]
+  int xcdm;        // the sums pass: neighbouring workgroups per XCD (r2l_xcd_window; 0 = off)
 };
 
 enum { R2L_L2_GSHARP = 0, R2L_L2_GAY = 9, R2L_L2_SY = 27, R2L_L2_NACC = 29 };

@@ -293,7 +293,7 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
   static_assert(6 % PF == 0 && 6 % PFG == 0, "the prefetch rings are indexed by the unroll position");
   // the registers hold the bank of EVEN rows between items (every band starts on an even row, at K = 0)
   R2L_PRAGMA_NOUNROLL
-  for (int item = bid * NWV + wave; item < nitems; item += nblk * NWV) {
+  for (int item = r2l_xcd_window(bid, nblk, a.xcdm) * NWV + wave; item < nitems; item += nblk * NWV) {
     const int strip = item % nstrip, ib = item / nstrip;
     const int band = ib % nband, b = ib / nband;
     const int xs = strip * 256 + 4 * lane;
@@ -444,7 +444,7 @@ R2L_BLOCKFN void r2l_bwd1_blur_block(const R2LBwd1Args& a, int bid, int nblk, fl
   constexpr int PF = R2L_BB_PF;
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
   R2L_PRAGMA_NOUNROLL
-  for (int item = bid * NWV + wave; item < nitems; item += nblk * NWV) {
+  for (int item = r2l_xcd_window(bid, nblk, a.xcdm_hb) * NWV + wave; item < nitems; item += nblk * NWV) {
     const int strip = item % nstrip, ib = item / nstrip;
     const int band = ib % nband, b = ib / nband;
     const int xs = strip * 256 + 4 * lane;
@@ -764,7 +764,7 @@ R2L_BLOCKFN void r2l_bwd1_blur_hp_block(const R2LBwd1Args& a, int bid, int nblk,
   constexpr int PF = R2L_BB_PF;
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
   R2L_PRAGMA_NOUNROLL
-  for (int item = bid * NWV + wave; item < nitems; item += nblk * NWV) {
+  for (int item = r2l_xcd_window(bid, nblk, a.xcdm_hb) * NWV + wave; item < nitems; item += nblk * NWV) {
     const int strip = item % nstrip, ib = item / nstrip;
     const int band = ib % nband, b = ib / nband;
     const int xs = strip * 256 + 4 * lane;
@@ -1056,7 +1056,7 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_lau
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
   // the registers hold the bank of EVEN rows between items (bands start on even rows, at K = 0)
   R2L_PRAGMA_NOUNROLL
-  for (int item = bid * NWV + wave; item < nitems; item += nblk * NWV) {
+  for (int item = r2l_xcd_window(bid, nblk, a.xcdm) * NWV + wave; item < nitems; item += nblk * NWV) {
     const int strip = item % nstrip, ib = item / nstrip;
     const int band = ib % nband, b = ib / nband;
     const int xs = strip * 256 + 4 * lane;

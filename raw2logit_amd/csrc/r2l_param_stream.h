@@ -45,6 +45,7 @@ struct R2LFwdStreamArgs {
   double* stats_out;
   R2LBnFinalizeArgs fin;
   R2LEpi ep;  // EPI instantiations: where the output goes (R2LEpi)
+  int xcdm;   // neighbouring workgroups per XCD (r2l_xcd_window; 0 = off): the work items follow the mapped workgroup id
 #ifdef R2L_EXP_STAMPS
   unsigned long long* tl;  // diagnostic builds: (start, end) s_memrealtime of every workgroup's first wavefront
 #endif
@@ -621,7 +622,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
   if (lane < 6) tots[lane] = 0.0;
   constexpr int PF = R2L_FS_PF;
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
-  for (int item = bid; item < a.nitems; item += nblk) {
+  for (int item = r2l_xcd_window(bid, nblk, a.xcdm); item < a.nitems; item += nblk) {
     const int band = item % a.nband, b = item / a.nband;
     const int y0 = band * a.band_h;
     const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
@@ -948,7 +949,7 @@ R2L_BLOCKFN void r2l_fwd_apply_block(const R2LFwdStreamArgs& a, int bid, int nbl
     }
     // one item per wavefront; NWV wavefronts per workgroup only because the dispatcher starts ~250 workgroups per
     // microsecond: 4,096 single-wavefront workgroups take 15 us to launch (tests/timeline_fwd.py)
-    const int item = bid * NWV + wave;
+    const int item = r2l_xcd_window(bid, nblk, a.xcdm) * NWV + wave;
     if (item < a.nitems) r2l_fa_item<U16, EPI, false>(a, item, lane, mean, istd, nullptr);
     R2L_TL_END(a, bid)
   } else {
@@ -956,7 +957,7 @@ R2L_BLOCKFN void r2l_fwd_apply_block(const R2LFwdStreamArgs& a, int bid, int nbl
     double* tots = (double*)(lds + 16 + R2L_FS_RED_FLOATS(NWV)) + wave * 6;
     if (lane < 6) tots[lane] = 0.0;
     R2L_PRAGMA_NOUNROLL
-    for (int item = bid * NWV + wave; item < a.nitems; item += nblk * NWV)
+    for (int item = r2l_xcd_window(bid, nblk, a.xcdm) * NWV + wave; item < a.nitems; item += nblk * NWV)
       r2l_fa_item<U16, false, true>(a, item, lane, mean, istd, tots);
     R2L_TL_END(a, bid)
     r2l_fs_stats_finish<NWV, NWV * 64>(a, bid, nblk, tid, wave, tots, red);
@@ -1087,9 +1088,8 @@ R2L_HD void r2l_fl_step(const R2LFwdStreamArgs& a, R2LFlState& st, int y, bool l
 template <bool U16, int NWV>
 R2L_BLOCKFN void r2l_fwd_luma_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
   (void)lds;
-  (void)nblk;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int item = bid * NWV + wave;  // one item per wavefront (NWV per workgroup: see r2l_fwd_apply_block)
+  const int item = r2l_xcd_window(bid, nblk, a.xcdm) * NWV + wave;  // one item per wavefront (NWV per workgroup: see r2l_fwd_apply_block)
   if (item >= a.nitems) return;
   R2LFoldedRef F = R2L_FOLDED_REF(a.F);
   const int nstrip = (a.W + 255) >> 8;

@@ -1,0 +1,138 @@
+"""Memory-safety net for the branch-free kernels (test infrastructure, not product code).
+
+The row loops of the streaming / plane / static kernels fetch UNCONDITIONALLY from clamped addresses and predicate their
+stores: an off-by-one there reads or writes out of bounds without changing any checked output, and the GPU has no address
+sanitizer on this pool.  `guarded(device, poison)` therefore serves every device allocation the Python wrappers make
+(`torch.empty` / `empty_like` / `zeros` in raw2logit_amd.functional: outputs, gradients, the workspace with its three planes)
+and the inputs the test places (`arena.place`) from ONE allocation in which each payload sits between >= 64 KiB guard zones,
+everything -- guards and the not-yet-written payloads -- pre-filled with a poison pattern (float32 quiet NaNs, or zeros):
+
+  * after the run every byte outside the payloads must be unchanged   -> no out-of-bounds WRITE within 64 KiB of any buffer;
+  * the run is repeated with the other pattern and every result must be bit-identical -> no out-of-bounds READ (and no read
+    of an unwritten part of an output / the workspace) that feeds a result.
+
+The reference gets both properties from ATen's bounds-checked indexing (pipeline_torch.py:187-217)."""
+import contextlib
+
+import numpy as np
+import torch
+
+GUARD = 64 * 1024
+POISON = {'nan': 0x7FC00000, 'zero': 0}
+
+
+def _align(x, a=256):
+    return (x + a - 1) // a * a
+
+
+class Arena:
+    def __init__(self, device, nbytes, poison):
+        self.device = torch.device(device)
+        self.nbytes = _align(nbytes, 4096)
+        self.pattern = POISON[poison]
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.buf.view(torch.int32).fill_(self.pattern)
+        self.off = 0
+        self.blocks = []     # (start, end, label)
+
+    def alloc(self, shape, dtype, label=''):
+        shape = tuple(int(s) for s in shape)
+        n = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+        start = _align(self.off + GUARD)
+        end = start + n
+        if end + GUARD > self.nbytes:
+            raise MemoryError(f'guarded arena of {self.nbytes} bytes exhausted by {label or shape} ({n} bytes)')
+        self.off = end       # the next guard zone starts at the payload's last byte + 1 (not at an aligned address)
+        self.blocks.append((start, end, label or f'{shape} {dtype}'))
+        return self.buf[start:end].view(dtype).view(shape)
+
+    def place(self, array, label=''):
+        t = torch.from_numpy(np.ascontiguousarray(array)) if isinstance(array, np.ndarray) else array.contiguous()
+        dst = self.alloc(t.shape, t.dtype, label)
+        dst.copy_(t)
+        return dst
+
+    def check_guards(self, what=''):
+        """every byte that belongs to no payload still holds the poison pattern"""
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
+        ref = self.buf.new_empty(self.buf.shape)     # (Tensor.new_empty: not one of the patched entry points)
+        ref.view(torch.int32).fill_(self.pattern)
+        probe = self.buf.clone()
+        for s, e, _ in self.blocks:
+            probe[s:e] = ref[s:e]
+        if torch.equal(probe, ref):
+            return
+        bad = torch.nonzero(probe != ref)[:, 0]
+        first, last, count = int(bad[0]), int(bad[-1]), int(bad.numel())
+        near = min(self.blocks, key=lambda b: min(abs(first - b[0]), abs(first - b[1])))
+        raise AssertionError(f'{what}: {count} guard bytes overwritten, offsets {first} .. {last}; nearest payload '
+                             f'{near[2]} = [{near[0]}, {near[1]}): {first - near[1]} bytes past its end / '
+                             f'{near[0] - first} bytes before its start')
+
+
+@contextlib.contextmanager
+def guarded(device, nbytes, poison):
+    """device allocations made through torch.empty / empty_like / zeros / zeros_like come out of a poisoned, guarded arena"""
+    arena = Arena(device, nbytes, poison)
+    orig = {n: getattr(torch, n) for n in ('empty', 'empty_like', 'zeros', 'zeros_like')}
+
+    def on_dev(d):
+        return d is not None and torch.device(d).type == arena.device.type
+
+    def shape_of(size):
+        if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+            return tuple(size[0])
+        return tuple(size)
+
+    def empty(*size, dtype=None, device=None, **kw):
+        if on_dev(device) and not kw.get('pin_memory'):
+            return arena.alloc(shape_of(size), dtype or torch.get_default_dtype())
+        return orig['empty'](*size, dtype=dtype, device=device, **kw)
+
+    def zeros(*size, dtype=None, device=None, **kw):
+        if on_dev(device):
+            return arena.alloc(shape_of(size), dtype or torch.get_default_dtype()).zero_()
+        return orig['zeros'](*size, dtype=dtype, device=device, **kw)
+
+    def empty_like(t, **kw):
+        if on_dev(t.device) and not kw:
+            return arena.alloc(t.shape, t.dtype)
+        return orig['empty_like'](t, **kw)
+
+    def zeros_like(t, **kw):
+        if on_dev(t.device) and not kw:
+            return arena.alloc(t.shape, t.dtype).zero_()
+        return orig['zeros_like'](t, **kw)
+
+    torch.empty, torch.empty_like, torch.zeros, torch.zeros_like = empty, empty_like, zeros, zeros_like
+    try:
+        yield arena
+    finally:
+        for n, f in orig.items():
+            setattr(torch, n, f)
+
+
+def run_both(device, nbytes, fn, what):
+    """fn(arena) -> dict of tensors, once over NaN-poisoned and once over zero-filled memory: guards intact both times,
+    results bit-identical.  Returns the results of the NaN run (host copies)."""
+    res = {}
+    for poison in ('nan', 'zero'):
+        with guarded(device, nbytes, poison) as arena:
+            out = fn(arena)
+            if arena.device.type == 'cuda':
+                torch.cuda.synchronize()
+            n_blocks = len(arena.blocks)
+            arena.check_guards(f'{what} [{poison}]')
+            res[poison] = {k: v.detach().cpu().clone() for k, v in out.items()}
+        del arena, out
+    assert n_blocks > 0, what
+    for k in res['nan']:
+        a, b = res['nan'][k], res['zero'][k]
+        same = torch.equal(a, b)
+        if not same and a.is_floating_point():
+            same = bool(((a == b) | (a.isnan() & b.isnan())).all())
+        assert same, f'{what}: {k} depends on the contents of memory the kernels were never given ' \
+                     f'({int((a != b).sum())} of {a.numel()} elements differ between NaN-poisoned and zero-filled guards)'
+        assert not (a.is_floating_point() and bool(a.isnan().any())), f'{what}: {k} contains NaN (poison reached a result)'
+    return res['nan']

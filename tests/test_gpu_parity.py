@@ -101,7 +101,7 @@ def test_plane_backward_at_the_dispatch_threshold(dev):
     """The SHIPPED library at its own dispatch threshold: 16 x 512 x 512 = 4 Mi px is the smallest batch whose backward
     runs as plane passes (r2l_api_impl.h: `planes`).  BatchNorm in eval mode decouples the frames, the cotangent is zero
     except on frames 0 and 15 (the first and the last band items of the launch), so all 132 gradients equal the float64
-    oracle's on those two frames: DEFAULT_GRAD_RTOL of the gradient's scale + the clip-flip allowance.  Also without
+    oracle's on those two frames: 3e-5 of the gradient's scale + the clip-flip allowance (pc.tight_grad_limit).  Also without
     BatchNorm and from 16-bit containers (bit-identical).  Reference: pipeline_torch.py:187-217 under autograd."""
     from raw2logit_amd import _lib
     B, H, W = 16, 512, 512
@@ -150,8 +150,7 @@ def test_plane_backward_at_the_dispatch_threshold(dev):
         for k, ref in og.items():
             ref = np.asarray(ref)
             got = grads['f32'][k].reshape(ref.shape)
-            flip = max(np.abs(np.asarray(lo[k]) - ref).max(), np.abs(np.asarray(hi[k]) - ref).max())
-            lim = pc.DEFAULT_GRAD_RTOL * (np.abs(ref).max() + 1e-6) + flip
+            lim = pc.tight_grad_limit(ref, lo[k], hi[k])          # 3e-5 of the scale + the clip-flip allowance
             e = np.abs(got - ref).max()
             pc.report(f'threshold-16x512x512/bn={bn}/grad {k} vs float64 oracle (plane passes, shipped library)', e, lim)
             assert e <= lim, (bn, k, e, lim)
@@ -274,8 +273,7 @@ def test_full_size_config2_properties(dev):
     hi, _, _ = orc.parametrized_backward(P, c, cot_np, clip_shift=-1e-6)
     for k, og in og_all.items():
         got = pc.NAME2ATTR[k](ms).grad.detach().cpu().numpy().reshape(np.asarray(og).shape)
-        flip = max(np.abs(np.asarray(lo[k]) - og).max(), np.abs(np.asarray(hi[k]) - og).max())
-        lim = pc.DEFAULT_GRAD_RTOL * (np.abs(og).max() + 1e-6) + flip
+        lim = pc.tight_grad_limit(og, lo[k], hi[k])               # 3e-5 of the scale + the clip-flip allowance
         e = np.abs(got - og).max()
         pc.report(f'config2/2-frame slice: grad {k} vs float64 oracle', e, lim)
         assert e <= lim, (k, e, lim)
@@ -294,6 +292,41 @@ def test_full_size_config2_properties(dev):
         e = (acc[k] - g_full[k]).abs().max().item()
         pc.report(f'config2/grad {k}: whole batch vs sum of quarters', e, 1e-4 * scale)
         assert e <= 1e-4 * scale, (k, e, scale)
+
+
+def test_baseline_config1_exact_batch(dev):
+    """BASELINE config 1 itself on the HIP path: 16 synthetic 256 x 256 12-bit RGGB frames (uniform codes, seed 0 -- the
+    batch bench.py's cpu_baseline leg times on the host), Drone camera parameters, the static chain `train.py:96-101`
+    defaults to (bilinear + sharpening_filter + gaussian_denoising), EVERY frame against the oracle's restatement of
+    processing() (pipeline_numpy.py:70-141); through the batched module, through the per-image callable the reference's
+    datasets hold (RawProcessingPipeline.__call__, :55-67: (H,W) ndarray -> (3,H,W) float32 tensor), and from the 16-bit
+    containers (bit-identical).  Also the short chain of config 3 and the Malvar2004 variant on the same batch."""
+    from raw2logit_amd import functional as F_
+    from raw2logit_amd.processing import pipeline_numpy as ppn
+    B, H, W = 16, 256, 256
+    raw_np = orc.synth_raw(B, H, W, seed=0, kind='uniform')
+    u = np.rint(raw_np.astype(np.float64) * 4095).astype(np.uint16)
+    assert np.array_equal(u.astype(np.float32) / np.float32(4095), raw_np)      # 12-bit codes / (2**12 - 1), dataset.py:87
+    raw = torch.from_numpy(raw_np).to(dev)
+    for chain in (('bilinear', 'sharpening_filter', 'gaussian_denoising'), ('bilinear', 'none', 'none'),
+                  ('malvar2004', 'sharpening_filter', 'gaussian_denoising')):
+        ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, *chain)
+        out = F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, *chain)
+        assert out.shape == (B, 3, H, W) and out.dtype == torch.float32
+        e = np.abs(out.cpu().numpy() - ref).max()
+        pc.report(f'config1 16x256x256/{"+".join(chain)}/all frames vs oracle', e, 1e-5)
+        assert e <= 1e-5, (chain, e)
+        out16 = F_.static_pipeline(torch.from_numpy(u.view(np.int16)).to(dev), orc.DRONE_CAMERA_PARAMS, *chain, bits=12)
+        assert torch.equal(out16, out), (chain, '16-bit containers')
+    pipe = ppn.RawProcessingPipeline(orc.DRONE_CAMERA_PARAMS, debayer='bilinear', sharpening='sharpening_filter',
+                                     denoising='gaussian_denoising')
+    ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, 'bilinear', 'sharpening_filter', 'gaussian_denoising')
+    for k in (0, 7, 15):
+        t = pipe(raw_np[k].copy())
+        assert tuple(t.shape) == (3, H, W) and t.dtype == torch.float32
+        e = np.abs(t.cpu().numpy() - ref[k]).max()
+        pc.report(f'config1 16x256x256/RawProcessingPipeline.__call__ frame {k} vs oracle', e, 1e-5)
+        assert e <= 1e-5, (k, e)
 
 
 def test_full_size_static_config3_slice(dev):
@@ -560,10 +593,14 @@ def test_full_size_config4_microscopy(dev):
     g, _, _ = orc.parametrized_backward(P, c, cot_np[:2])
     lo, _, _ = orc.parametrized_backward(P, c, cot_np[:2], clip_shift=1e-6)
     hi, _, _ = orc.parametrized_backward(P, c, cot_np[:2], clip_shift=-1e-6)
+    # the float32 conditioning of the slice, measured: the oracle's formulas in float32 (the reference's own arithmetic)
+    P32 = orc.IspParams(orc.MICROSCOPY_CAMERA_PARAMS, dtype=np.float32)
+    _, _, c32 = orc.parametrized_forward(raw_np[:2], P32, bn=bn)
+    g32, _, _ = orc.parametrized_backward(P32, c32, cot_np[:2])
     for k, og in g.items():
         got = pc.NAME2ATTR[k](ms).grad.detach().cpu().numpy().reshape(np.asarray(og).shape)
-        flip = max(np.abs(np.asarray(lo[k]) - og).max(), np.abs(np.asarray(hi[k]) - og).max())
-        lim = 1e-2 * (np.abs(og).max() + 1e-6) + flip
+        # 3e-5 of the scale + the clip-flip allowance + twice the float32 oracle's own distance (round 4: 1e-2 of the scale)
+        lim = pc.tight_grad_limit(og, lo[k], hi[k], g32[k])
         e = np.abs(got - og).max()
         pc.report(f'config4/2-frame slice: grad {k} vs float64 oracle', e, lim)
         assert e <= lim, (k, e, lim)
