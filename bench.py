@@ -695,7 +695,7 @@ def main():
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                         'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
 
-    graph_ms = graph_err = None
+    graph_ms = graph_err = graph_local_ms = None
     static_c3 = small = None
     # (sub-records: a failure in one of them must not cost the headline line -- it is reported in its place)
     if world == 1 and dev.type == 'cuda' and not args.no_small_shapes:
@@ -711,10 +711,12 @@ def main():
         except Exception as e:                       # noqa: BLE001
             static_c3 = {'error': '%s: %s' % (type(e).__name__, e)}
 
-    def line(graph_ms, graph_err):
-        """the JSON line: the faster of the eager step and -- several RCCL ranks -- the step as one HIP graph is its value"""
-        use_graph = graph_ms is not None and graph_ms < 1e3 * dt / args.steps
-        ms = graph_ms if use_graph else 1e3 * dt / args.steps
+    def line(graph_ms, graph_err, graph_local_ms=None, watchdog=False):
+        """the JSON line.  Its value is the EAGER step's (what roofline / kernels describe); with several RCCL ranks the step as
+        one HIP graph with its collectives captured is timed too and reported BESIDE it (ms_per_step_graph / value_graph) --
+        that path has only ever run against a one-rank RCCL group, so it does not carry the headline until a multi-GPU run has
+        validated it (`--graph` makes it the timed step explicitly)."""
+        ms = 1e3 * dt / args.steps
         val = px_per_step / (ms * 1e-3) / 1e6
         out = {
             'metric': 'ISP Mpix/s (fwd+bwd) on 512x512 raw batches', 'value': round(val, 1),
@@ -751,10 +753,18 @@ def main():
             out['value_graph'] = round(px_per_step / (graph_ms * 1e-3) / 1e6, 1)
             out['ms_per_step_eager'] = round(1e3 * dt / args.steps, 4)
             out['value_eager'] = round(value, 1)
-            out['launch'] = ('one HIP graph per step, its RCCL collectives captured (raw2logit_amd/graphs.py: StepGraph)'
-                             if use_graph else 'eager (the graph was not faster)')
+            out['launch'] = ('eager step timed as the value; the same step as one HIP graph with its RCCL collectives captured '
+                             '(raw2logit_amd/graphs.py: StepGraph) beside it')
+        if graph_local_ms is not None and graph_ms is not None:
+            # what the three collectives cost INSIDE the captured step: the graph over the world's group minus the same graph
+            # over a group of this rank alone (same kernels, same RCCL calls, no hop) -- the number the ~50 us budget of
+            # the >= 6x target at config 5's step is about
+            out['ms_per_step_graph_local'] = round(graph_local_ms, 4)
+            out['graph_comm_us'] = round(1e3 * (graph_ms - graph_local_ms), 1)
         if graph_err is not None:
             out['graph_error'] = graph_err
+        if watchdog:
+            out['watchdog_fired'] = True
         if comm_us is not None:
             # wall time of each ISP collective per call (device events on the launch stream around the exchange, from the
             # instrumented pass): the two small all-gathers sit inside the step, the gradient all-reduce overlaps
@@ -775,10 +785,16 @@ def main():
     # back (a capture or a replay that hangs on one rank), and the ranks agree on success before anything collective is timed.
     if group_on and nccl and dev.type == 'cuda' and not args.graph and not args.no_graph_trial:
         import threading
+        printed = threading.Lock()                   # exactly one JSON line, whoever gets there first
 
         def give_up():
+            # the eager measurement is complete and valid: print it, tagged, and end the process (a capture or replay that hangs
+            # on one rank cannot be unwound; destroy_process_group() would hang with it)
+            if not printed.acquire(blocking=False):
+                return
             if rank == 0:
-                print(json.dumps(line(None, 'watchdog: the graph trial did not finish in %g s' % GRAPH_TRIAL_TIMEOUT_S)), flush=True)
+                print(json.dumps(line(None, 'watchdog: the graph trial did not finish in %g s' % GRAPH_TRIAL_TIMEOUT_S,
+                                      watchdog=True)), flush=True)
             os._exit(0)
         dog = threading.Timer(GRAPH_TRIAL_TIMEOUT_S, give_up)
         dog.daemon = True
@@ -787,6 +803,12 @@ def main():
             from raw2logit_amd.graphs import StepGraph
             finish()
             ok, g2 = 1.0, None
+            # a group of this rank alone (every rank creates every group): the same split step with its collectives going nowhere
+            solo = None
+            for r_ in range(world):
+                g_ = dist.new_group([r_])
+                if r_ == rank:
+                    solo = g_
             try:
                 m2 = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True).to(dev).train()
                 m2.raw_bits = 12
@@ -800,13 +822,32 @@ def main():
                 torch.cuda.synchronize()
                 clock.preroll(g2.replay, None, 0.05)
                 graph_ms = 1e3 * clock.time_steps(g2.replay, args.steps, args.warmup) / args.steps
+                try:
+                    old_split = os.environ.get('R2L_SPLIT_SINGLE_RANK')
+                    os.environ['R2L_SPLIT_SINGLE_RANK'] = '1'      # a one-rank group takes the N > 1 path (functional.py)
+                    m3 = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True).to(dev).train()
+                    m3.raw_bits = 12
+                    g3 = StepGraph(m3, raw, cot, process_group=solo)
+                    g3.replay()
+                    torch.cuda.synchronize()
+                    graph_local_ms = 1e3 * clock.time_steps(g3.replay, args.steps, args.warmup) / args.steps
+                except Exception as e:               # noqa: BLE001
+                    graph_local_ms = None
+                    graph_err = 'local-collectives graph: %s: %s' % (type(e).__name__, e)
+                finally:
+                    if old_split is None:
+                        os.environ.pop('R2L_SPLIT_SINGLE_RANK', None)
+                    else:
+                        os.environ['R2L_SPLIT_SINGLE_RANK'] = old_split
             elif graph_err is None:
                 graph_err = 'the capture failed on another rank'
         except Exception as e:                       # noqa: BLE001
             graph_ms, graph_err = None, '%s: %s' % (type(e).__name__, e)
         dog.cancel()
+        if not printed.acquire(blocking=False):      # the watchdog is printing: it ends the process
+            time.sleep(60)
     if rank == 0:
-        print(json.dumps(line(graph_ms, graph_err)), flush=True)
+        print(json.dumps(line(graph_ms, graph_err, graph_local_ms)), flush=True)
     if group_on:
         dist.barrier()
         dist.destroy_process_group()

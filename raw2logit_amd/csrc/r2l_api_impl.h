@@ -1023,7 +1023,16 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
     a2.params = params;
     a2.grad_params = grad_params;
     const int grid = (int)gs + (tree ? R2L_B2S_HELPERS : 0);
-    return raw.u16 ? r2l_launch_bwd2_sums_u16(a2, grid, stream) : r2l_launch_bwd2_sums(a2, grid, stream);
+    if (int e = raw.u16 ? r2l_launch_bwd2_sums_u16(a2, grid, stream) : r2l_launch_bwd2_sums(a2, grid, stream)) return e;
+    if (tree) return 0;
+    // (diagnostic builds with the in-kernel tree switched off: the three tiny launches of the tile kernels' fallback finish
+    // the sums, so that grad_params is never returned uninitialised)
+    R2LReduceRowsArgs r1{ws.part_b1, ws.sums, g1w, 1.0, nullptr};
+    if (int e = r2l_launch_reduce_rows(r1, R2L_B1_NACC, stream)) return e;
+    R2LReduceRowsArgs r2{ws.part_b2, ws.sums + R2L_B1_NACC, (int)gs, 1.0, nullptr};
+    if (int e = r2l_launch_reduce_rows(r2, R2L_B2_NACC, stream)) return e;
+    R2LUnfoldArgs ua{params, ws.sums, grad_params, 1.0f};
+    return r2l_launch_unfold(ua, 1, stream);
   }
 #endif
   const bool in_kernel = g1w <= g2;

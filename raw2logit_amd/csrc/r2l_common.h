@@ -473,9 +473,45 @@ struct R2LFolded {
 #ifdef R2L_EMUL
 typedef const R2LFolded& R2LFoldedRef;
 #define R2L_FOLDED_REF(ptr) (*(ptr))
+#define R2L_CONSTAS
+#elif defined(R2L_EXP_CONST_WEIGHTS)
+// DIAGNOSTIC BUILD, TIMING ONLY (results are wrong): every folded weight is a compile-time constant, so the kernels issue no
+// scalar loads for them at all -- the upper bound of what hiding the scalar-load waits of a row step could buy
+// (profiles/r05_const_weights.txt)
+constexpr R2LFolded r2l_exp_make_folded() {
+  R2LFolded f{};
+  float v = 0.0131f;
+  for (int i = 0; i < 4; ++i) f.bl[i] = (v += 0.0007f);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 9; ++j) {
+      f.AY[i][j] = (v += 0.0007f);
+      f.AU[i][j] = (v += 0.0007f);
+      f.AV[i][j] = (v += 0.0007f);
+    }
+  for (int j = 0; j < 9; ++j) f.sharp[j] = (v += 0.0007f);
+  for (int j = 0; j < 25; ++j) f.blur[j] = (v += 0.0007f);
+  for (int j = 0; j < 9; ++j) f.M2[j] = (v += 0.0007f);
+  f.inv_gamma = 0.4545f;
+  f.gamma = 2.2f;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 9; ++j)
+      for (int k = 0; k < 2; ++k) {
+        f.AY2[i][j][k] = (v += 0.0007f);
+        f.AU2[i][j][k] = (v += 0.0007f);
+        f.AV2[i][j][k] = (v += 0.0007f);
+      }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 25; ++j) f.blur_edge[i][j] = (v += 0.0007f);
+  return f;
+}
+static __device__ constexpr R2LFolded r2l_exp_folded = r2l_exp_make_folded();
+typedef const R2LFolded& R2LFoldedRef;
+#define R2L_FOLDED_REF(ptr) (((void)(ptr)), r2l_exp_folded)
+#define R2L_CONSTAS
 #else
 typedef const __attribute__((address_space(4))) R2LFolded& R2LFoldedRef;
 #define R2L_FOLDED_REF(ptr) (*(const __attribute__((address_space(4))) R2LFolded*)(ptr))
+#define R2L_CONSTAS __attribute__((address_space(4)))
 #endif
 #define R2L_FOLDED_FLOATS 0
 R2L_HD const R2LFolded* r2l_opaque(const R2LFolded* p) {

@@ -119,8 +119,13 @@ R2L_HD void r2l_bp_step(const R2LBwd1Args& a, R2LBpState& st, R2LBpAcc& A, const
   {
     R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, yw[2][2]));
     const int set = (y < 2) ? y : (y - (H - 2)) + 2;
-    const __attribute__((address_space(4))) float* w25 =
+#ifdef R2L_EXP_CONST_WEIGHTS
+    const float* w25 = &F.blur[0];  // (timing only: no border sets)
+    (void)set;
+#else
+    const R2L_CONSTAS float* w25 =
         (y >= 2 && y < H - 2) ? &F.blur[0] : &F.blur_edge[0][0] + 25 * set;
+#endif
     r2l_blur_row2w(yw, w25, ypp);
   }
   const float* vu = st.v[(K + 2) % 3];  // V(y-1)

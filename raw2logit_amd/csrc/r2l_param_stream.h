@@ -67,6 +67,13 @@ struct R2LFwdStreamArgs {
 #define R2L_TL_END(a, bid)
 #endif
 
+// the lane's index in its wavefront from the hardware (v_mbcnt), opaque to the optimiser: every call re-derives it (two
+// instructions) instead of keeping one value alive from the kernel's first instruction to its last
+R2L_HD int r2l_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 R2L_HD float r2l_wshr(float x, float edge) {  // previous lane's x; lane 0 of the wavefront gets `edge`
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
                                                                0x138, 0xf, 0xf, false));
@@ -456,8 +463,13 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
       // the first / last two image rows take the weight sets with the mirror padding folded in (a padding row past the
       // image's last row: any finite weights)
       const int set = (y < 2) ? y : (y - (H - 2)) + 2;
-      const __attribute__((address_space(4))) float* w25 =
+#ifdef R2L_EXP_CONST_WEIGHTS
+    const float* w25 = &Fh.blur[0];  // (timing only: no border sets)
+    (void)set;
+#else
+      const R2L_CONSTAS float* w25 =
           ((y >= 2 && y < H - 2) || y >= H) ? &Fh.blur[0] : &F.blur_edge[0][0] + 25 * set;
+#endif
       r2l_blur_row2w(yw, w25, ypp);
     }
     const r2l_f4* f = fifo + ((K + 2) % R2L_FS_FIFO_ROWS) * 2 * 64 + lane;  // row q-4
@@ -594,7 +606,11 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
 template <int NW, bool U16, bool EPI = false, bool SONLY = false>
 R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
   constexpr int NT = NW * 64;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // (wave: a scalar; lane: the hardware's lane id, re-derived wherever it is needed -- the thread id the kernel was handed
+  // in v0 would otherwise stay live across the row loop, which has no register to spare: 28 B of scratch in round 4)
+  // (the statistics instantiation only: in the others the same change ADDS 20 B of scratch)
+  const int wave = SONLY ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x >> 6;
+  const int lane = SONLY ? r2l_lane_id() : (int)threadIdx.x & 63;
   float* ex = lds;
   r2l_f4* fifo = (r2l_f4*)(lds + 2 * NW * R2L_FS_EX + 16) + (size_t)wave * R2L_FS_FIFO_F4;
   float* red = lds + 2 * NW * R2L_FS_EX + 16;  // reduction scratch: over the chroma rings, after the last item
@@ -620,6 +636,15 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
   // cost no registers
   double* tots = (double*)(lds + 2 * NW * R2L_FS_EX + 16 + R2L_FS_RING_FLOATS(NW)) + wave * 6;
   if (lane < 6) tots[lane] = 0.0;
+  // the chroma ring starts out as zeros: the padding steps of a band's last group (R2L_FS_FULL_GROUPS) read ring rows this item
+  // never wrote -- harmless garbage only as long as fmin(fmax(NaN, 1e-5), 1) clamps a NaN before the 0 / 1 mask multiplies it;
+  // with defined contents nothing depends on that (12 LDS stores per lane, once per kernel; later items see earlier items' rows)
+  {
+    r2l_f4 z;
+    z.x = z.y = z.z = z.w = 0.f;
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < R2L_FS_FIFO_ROWS * 2; ++i) fifo[i * 64 + lane] = z;
+  }
   constexpr int PF = R2L_FS_PF;
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
   for (int item = r2l_xcd_window(bid, nblk, a.xcdm); item < a.nitems; item += nblk) {
@@ -748,7 +773,10 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // exchange buffers free for the next item
     if (SONLY || a.stat_partial) r2l_fs_lane_sums(st.acc, st.piv, store_ok ? 4.0 * (double)(y1 - y0) : 0.0, store_ok, lane, tots);
   }
-  if (SONLY || a.stat_partial) r2l_fs_stats_finish<NW, NT>(a, bid, nblk, tid, wave, tots, red);
+  if (SONLY || a.stat_partial) {
+    const int tid = SONLY ? wave * 64 + r2l_lane_id() : (int)threadIdx.x;
+    r2l_fs_stats_finish<NW, NT>(a, bid, nblk, tid, wave, tots, red);
+  }
 }
 
 // ================================================================================================
@@ -846,8 +874,13 @@ R2L_HD void r2l_fa_step(const R2LFwdStreamArgs& a, R2LFaState& st, r2l_p2* acc, 
       R2L_PRAGMA_UNROLL
     for (int j = 0; j < 8; ++j) yw[i][j] = st.yp[(K + 4 + i) % 6][j];
     const int set = (y < 2) ? y : (y - (H - 2)) + 2;
-    const __attribute__((address_space(4))) float* w25 =
+#ifdef R2L_EXP_CONST_WEIGHTS
+    const float* w25 = &Fb.blur[0];  // (timing only: no border sets)
+    (void)set;
+#else
+    const R2L_CONSTAS float* w25 =
         (y >= 2 && y < H - 2) ? &Fb.blur[0] : &Fb.blur_edge[0][0] + 25 * set;
+#endif
     r2l_blur_row2w(yw, w25, ypp);
   }
   R2LFoldedRef Fc = R2L_FOLDED_REF(r2l_opaque_after(a.F, ypp[1][1]));

@@ -700,6 +700,9 @@ R2L_HD void r2l_stream_convert_row_s(const R2LStaticArgs& a, const R2LRowStageS<
 #ifndef R2L_STREAM_BF_PF_MALVAR
 #define R2L_STREAM_BF_PF_MALVAR 5
 #endif
+#ifndef R2L_STREAM_BF_MALVAR_LANES
+#define R2L_STREAM_BF_MALVAR_LANES 0  // 1: Malvar2004's two neighbour columns each side by lane shifts (one edge pair per lane and row in flight instead of two)
+#endif
 #ifndef R2L_STREAM_BF_BILINEAR_F32WIN
 #define R2L_STREAM_BF_BILINEAR_F32WIN 1
 #endif
@@ -710,7 +713,7 @@ template <int DEB, int RAWK>
 R2L_HD void r2l_static_stream_item_bf(const R2LStaticStreamArgs& sa, int item, int lane) {
   const R2LStaticArgs& a = sa.s;
   constexpr int HALO = DEB ? 2 : 1, NR = 2 * HALO + 1;
-  constexpr bool LANES = (DEB == 0) && R2L_HAVE_LANE_SHIFTS;
+  constexpr bool LANES = (DEB == 0 || R2L_STREAM_BF_MALVAR_LANES) && R2L_HAVE_LANE_SHIFTS;
   constexpr int PF = DEB ? R2L_STREAM_BF_PF_MALVAR : R2L_STREAM_BF_PF_BILINEAR;
   constexpr int U = (PF % NR == 0) ? PF : PF * NR;  // steps per unrolled group: a multiple of both ring sizes
   static_assert(U % NR == 0 && U % PF == 0, "ring slots are compile-time indices");

@@ -1,6 +1,7 @@
 """autograd-facing ops over the C ABI (include/r2l_isp.h).  PyTorch is plumbing here: it owns device
 memory, streams and torch.distributed; all image arithmetic happens in the HIP kernels."""
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -165,24 +166,45 @@ class CommTimer:
         return {k: {'calls': n, 'avg_us': round(t / n, 1)} for k, (n, t) in acc.items()}
 
 
-_HOST_STAGED = {}      # process group -> does its backend for DEVICE tensors move host memory only (gloo)?
+_HOST_STAGED = weakref.WeakKeyDictionary()     # process group object -> (backend string, staged); dies with the group
+_HOST_STAGED_DEFAULT = [None]                  # the default group (None): (backend string, staged), re-validated every call
+
+
+def _backend_for_device_tensors(group):
+    name = str(dist.get_backend(group))
+    if ',' in name or ':' in name:                   # "cpu:gloo,cuda:nccl": the entry of the cuda device type
+        per = dict(part.split(':', 1) for part in name.split(',') if ':' in part)
+        name = per.get('cuda', name)
+    return name.strip().lower()
 
 
 def _host_staged(group, t):
     """gloo moves host memory: device tensors of a gloo group (several ranks sharing one GPU -- the functional
     multi-rank check on a one-GPU box) cross through a host copy.  RCCL ("nccl") takes device pointers as they are.
-    The backend that serves the tensor's DEVICE decides ("cpu:gloo,cuda:nccl" groups hand device tensors to RCCL)."""
+    The backend that serves the tensor's DEVICE decides ("cpu:gloo,cuda:nccl" groups hand device tensors to RCCL).
+    Cached on the group OBJECT (weakly: an id() can be reused by a later group after destroy_process_group() and a
+    re-init with another backend in the same process); the default group's entry carries its backend string and is
+    re-validated against dist.get_backend() on every call."""
     if not t.is_cuda:
         return False
-    key = id(group) if group is not None else None
-    staged = _HOST_STAGED.get(key)
-    if staged is None:
-        name = str(dist.get_backend(group))
-        if ',' in name or ':' in name:                   # "cpu:gloo,cuda:nccl": the entry of the cuda device type
-            per = dict(part.split(':', 1) for part in name.split(',') if ':' in part)
-            name = per.get('cuda', name)
-        staged = _HOST_STAGED[key] = (name.strip().lower() == 'gloo')
-    return staged
+    if group is None:
+        name = _backend_for_device_tensors(None)
+        ent = _HOST_STAGED_DEFAULT[0]
+        if ent is None or ent[0] != name:
+            ent = _HOST_STAGED_DEFAULT[0] = (name, name == 'gloo')
+        return ent[1]
+    try:
+        ent = _HOST_STAGED.get(group)
+    except TypeError:                                # (a group object that cannot be weakly referenced: no cache)
+        return _backend_for_device_tensors(group) == 'gloo'
+    if ent is None:
+        name = _backend_for_device_tensors(group)
+        ent = (name, name == 'gloo')
+        try:
+            _HOST_STAGED[group] = ent
+        except TypeError:
+            pass
+    return ent[1]
 
 
 def split_single_rank(group):

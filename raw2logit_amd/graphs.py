@@ -20,45 +20,65 @@ the capture's side stream).
 Several ranks (`process_group`): the two small all-gathers that split the step's calls under train-mode BatchNorm and the
 flat all-reduce of the parameter gradients are issued on the capture stream and become nodes of the graph -- RCCL
 collectives (backend "nccl") are capturable; a gloo group moves host memory and is refused.  One replay is then the whole
-data-parallel step of the processor: statistics of the GLOBAL batch, gradients summed (or averaged) over the ranks.
+data-parallel step of the PROCESSOR: statistics of the global batch, the processor's gradients summed (or averaged) over
+the ranks.  The gradients of `loss_modules` (a classifier head) are NOT reduced here: they are DistributedDataParallel's
+business -- wrap the head in DDP inside `loss`, or pass `reduce_loss_modules=True` to put them into the same flat all-reduce.
 """
 import torch
 
 
 class StepGraph:
     def __init__(self, model, raw, cotangent, loss=None, loss_modules=(), warmup=3, process_group=None,
-                 average_grads=False):
+                 average_grads=False, reduce_loss_modules=False):
         """loss: optional callable out -> scalar (then `cotangent` is ignored and loss(out).backward() is captured);
         loss_modules: the modules `loss` runs (a classifier head ...): their parameters' gradients belong to the graph
         too -- like the processor's they are written by every replay into tensors the capture allocated; replay()
         re-attaches those tensors to `p.grad`, so optimizer.zero_grad(set_to_none=True) between replays is harmless.
-        process_group: data-parallel ranks (one process per GPU over RCCL): sets `model.process_group` and captures the
-        gradient all-reduce of the processor's parameters behind the backward (average_grads: divide by the ranks)."""
+        process_group: data-parallel ranks (one process per GPU over RCCL; default: the group the model already carries):
+        the model runs with it for the lifetime of this object's captures (`model.process_group` is restored when the
+        constructor returns) and the gradient all-reduce of the processor's parameters is captured behind the backward
+        (average_grads: divide by the ranks; reduce_loss_modules: the `loss_modules` parameters join that all-reduce --
+        otherwise several ranks with trainable loss modules raise unless those modules are DistributedDataParallel)."""
         from . import functional as F_
         self.model, self.raw, self.cotangent = model, raw, cotangent
         self.params = [p for m in (model,) + tuple(loss_modules) for p in m.parameters() if p.requires_grad]
         self._isp_params = [p for p in model.parameters() if p.requires_grad]
         self._loss = loss
-        self._group, self._average = process_group, average_grads
+        group = process_group if process_group is not None else getattr(model, 'process_group', None)
+        self._group, self._average = group, average_grads
         self._collectives = False
-        if process_group is not None:
-            if F_._host_staged(process_group, raw):
+        self._model_group = getattr(model, 'process_group', None)
+        if group is not None:
+            if F_._host_staged(group, raw):
                 raise RuntimeError('StepGraph: a gloo group moves its vectors through host memory, which a HIP graph cannot '
                                    'capture -- use the eager step with gloo, or an RCCL ("nccl") group')
-            model.process_group = process_group
-            self._collectives = F_._group_size(process_group) > 1 or F_.split_single_rank(process_group)
-        side = torch.cuda.Stream(device=raw.device)
-        side.wait_stream(torch.cuda.current_stream(raw.device))
-        with torch.cuda.stream(side):                     # warm-up off the default stream (allocator, autograd nodes,
-            for _ in range(warmup):                       # and the communicator's own first-call set-up)
-                self._step()
-        torch.cuda.current_stream(raw.device).wait_stream(side)
-        torch.cuda.synchronize(raw.device)
-        for p in self.params:                             # the captured step allocates the gradients in the graph's pool
-            p.grad = None
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._step()
+            self._collectives = F_._group_size(group) > 1 or F_.split_single_rank(group)
+        self._reduced = self._isp_params
+        if self._collectives:
+            extra = [p for m in loss_modules for p in m.parameters() if p.requires_grad]
+            if extra and reduce_loss_modules:
+                self._reduced = self.params
+            elif extra and F_._group_size(group) > 1 and not all(
+                    isinstance(m, torch.nn.parallel.DistributedDataParallel) for m in loss_modules):
+                raise RuntimeError('StepGraph: several ranks and trainable loss_modules -- their gradients would not be '
+                                   'reduced and the ranks would diverge: wrap them in DistributedDataParallel, or pass '
+                                   'reduce_loss_modules=True')
+        model.process_group = group                       # (for the warm-up and the capture only: restored below)
+        try:
+            side = torch.cuda.Stream(device=raw.device)
+            side.wait_stream(torch.cuda.current_stream(raw.device))
+            with torch.cuda.stream(side):                 # warm-up off the default stream (allocator, autograd nodes,
+                for _ in range(warmup):                   # and the communicator's own first-call set-up)
+                    self._step()
+            torch.cuda.current_stream(raw.device).wait_stream(side)
+            torch.cuda.synchronize(raw.device)
+            for p in self.params:                         # the captured step allocates the gradients in the graph's pool
+                p.grad = None
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._step()
+        finally:
+            model.process_group = self._model_group
         self._grads = [p.grad for p in self.params]       # tensors of the graph's pool: every replay writes them
 
     def _step(self):
@@ -70,7 +90,7 @@ class StepGraph:
         if self._collectives:
             # the data-parallel sum of the processor's 132-float gradient: one flat all-reduce on this stream
             from .functional import GradAllReduce
-            GradAllReduce(self._isp_params, self._group, average=self._average).wait()
+            GradAllReduce(self._reduced, self._group, average=self._average).wait()
         return out
 
     def replay(self):

@@ -97,20 +97,23 @@ def test_plane_backward_frame_shapes(mode, dev):
         pc.report(f'plane-backward/{mode}/{sorted(env.items())[0]}: worst gradient error (fraction of its limit)', w2, 1.0)
 
 
-def test_plane_backward_at_the_dispatch_threshold(dev):
-    """The SHIPPED library at its own dispatch threshold: 16 x 512 x 512 = 4 Mi px is the smallest batch whose backward
-    runs as plane passes (r2l_api_impl.h: `planes`).  BatchNorm in eval mode decouples the frames, the cotangent is zero
-    except on frames 0 and 15 (the first and the last band items of the launch), so all 132 gradients equal the float64
-    oracle's on those two frames: 3e-5 of the gradient's scale + the clip-flip allowance (pc.tight_grad_limit).  Also without
-    BatchNorm and from 16-bit containers (bit-identical).  Reference: pipeline_torch.py:187-217 under autograd."""
+def _shipped_plane_backward_vs_oracle(dev, B, tag):
+    """The SHIPPED library's plane-pass backward on B x 512 x 512 well-conditioned frames (pc.midtone_frames: no pixel within
+    0.05 of a clip threshold under 1 %-perturbed Drone parameters, so torch.clip's step gradient cannot flip and float32
+    round-off is all that separates a correct kernel from the float64 oracle).  BatchNorm in eval mode decouples the frames
+    and the cotangent is zero except on the first and the last frame (the first and the last band items of the launch), so
+    all 132 gradients of the batch equal the oracle's on those two frames: limit 3e-5 of the gradient's scale
+    (pc.tight_grad_limit -- the criterion of check_frame_shapes; round 4 allowed 1.5e-3 + a flip allowance, 450 x what the
+    kernels achieve).  Also without BatchNorm, and from 16-bit containers (bit-identical)."""
     from raw2logit_amd import _lib
-    B, H, W = 16, 512, 512
+    H = W = 512
     lib = _lib.device_library()
     assert lib.path == _lib.LIB_PATH
-    u = np.rint(orc.synth_raw(B, H, W, seed=4, kind='scene').astype(np.float64) * 4095).astype(np.uint16)
-    raw_np = u.astype(np.float32) / np.float32(4095)
+    raw_np = pc.midtone_frames(B, H, W, seed=4)
+    u = np.rint(raw_np.astype(np.float64) * 4095).astype(np.uint16)
+    assert np.array_equal(u.astype(np.float32) / np.float32(4095), raw_np)
     P = orc.IspParams(orc.DRONE_CAMERA_PARAMS)
-    P.perturb(23)
+    P.perturb(23, 0.01)
     sel = [0, B - 1]
     cot_np = np.zeros((B, 3, H, W), np.float32)
     cot_np[sel] = np.random.default_rng(5).standard_normal((2, 3, H, W)).astype(np.float32)
@@ -139,10 +142,11 @@ def test_plane_backward_at_the_dispatch_threshold(dev):
         for n in grads['f32']:
             assert np.array_equal(grads['f32'][n], grads['u16'][n]), (bn, n, '16-bit containers')
         o, _, c = orc.parametrized_forward(raw_np[sel], P64, bn=pc.oracle_bn(case))
+        assert c['rgb'].min() > 0.05 and c['rgb'].max() < 0.95, (c['rgb'].min(), c['rgb'].max())
         tol = pc.out_tolerance(c, bn)
         err = np.abs(y_sel - o)
         w = np.unravel_index((err / tol).argmax(), err.shape)
-        pc.report(f'threshold-16x512x512/bn={bn}/out (frames 0, 15) vs float64 oracle', err[w], tol[w])
+        pc.report(f'{tag}/bn={bn}/out (frames 0, {B - 1}) vs float64 oracle', err[w], tol[w])
         assert np.all(err <= tol), (bn, err.max())
         og, _, _ = orc.parametrized_backward(P64, c, cot_np[sel])
         lo, _, _ = orc.parametrized_backward(P64, c, cot_np[sel], clip_shift=1e-6)
@@ -150,10 +154,23 @@ def test_plane_backward_at_the_dispatch_threshold(dev):
         for k, ref in og.items():
             ref = np.asarray(ref)
             got = grads['f32'][k].reshape(ref.shape)
-            lim = pc.tight_grad_limit(ref, lo[k], hi[k])          # 3e-5 of the scale + the clip-flip allowance
+            lim = pc.tight_grad_limit(ref, lo[k], hi[k])          # 3e-5 of the scale (the clip-flip allowance is zero here)
+            assert lim <= 3.0001e-5 * (np.abs(ref).max() + 1e-6), (k, 'a pixel sits on a clip threshold', lim)
             e = np.abs(got - ref).max()
-            pc.report(f'threshold-16x512x512/bn={bn}/grad {k} vs float64 oracle (plane passes, shipped library)', e, lim)
+            pc.report(f'{tag}/bn={bn}/grad {k} vs float64 oracle (plane passes, shipped library)', e, lim)
             assert e <= lim, (bn, k, e, lim)
+
+
+def test_plane_backward_at_the_dispatch_threshold(dev):
+    """16 x 512 x 512 = 4 Mi px is the smallest batch whose backward the shipped library runs as plane passes
+    (r2l_api_impl.h: `planes`).  Reference: pipeline_torch.py:187-217 under autograd."""
+    _shipped_plane_backward_vs_oracle(dev, 16, 'threshold-16x512x512')
+
+
+def test_plane_backward_at_the_headline_shape(dev):
+    """the same at BASELINE config 2's shape, 64 x 512 x 512 -- the launch shapes (one round of resident wavefronts, band
+    heights, helper workgroups of the sums pass) behind bench.py's line"""
+    _shipped_plane_backward_vs_oracle(dev, 64, 'headline-64x512x512')
 
 
 def test_plane_backward_beyond_one_round_of_workgroups(dev):
@@ -918,14 +935,17 @@ def test_fused_forward_streaming_kernel(shape, dev):
             y16 = m16(torch.from_numpy(u).to(dev))
         assert torch.equal(y, y16), (shape, bn, '16-bit containers')
         o, _, c = orc.parametrized_forward(raw_np, P.astype(np.float64), bn=pc.oracle_bn(dict(case, bn=bn)))
-        tol = pc.out_tolerance(c, bn)
+        o32, _, c32 = orc.parametrized_forward(raw_np, P.astype(np.float32), bn=pc.oracle_bn(dict(case, bn=bn)))
+        # per pixel: BASELINE's 1e-5 (x 1/std under BatchNorm), or 6 standard deviations of the float32 oracle's own local
+        # error pushed through the power law, whichever is larger (pc.sigma_limit, the criterion of the randomised sweeps) --
+        # not the flat LOW_BAND_TOL of rounds 1-4 below a pre-gamma value of 3e-3
+        floor = 1e-5 * (np.maximum(1.0, c['istd']).reshape(1, 3, 1, 1) if bn else 1.0)
+        tol = np.broadcast_to(pc.sigma_limit(floor, P, c, c32, bn), o.shape)
         err = np.abs(y.cpu().numpy() - o)
         w = np.unravel_index((err / tol).argmax(), err.shape)
-        pc.report(f'fwd-stream/{shape}/bn={bn}/out vs float64 oracle', err[w], tol[w])
+        pc.report(f'fwd-stream/{shape}/bn={bn}/out vs float64 oracle (limit: max(1e-5, 6 sigma of the float32 oracle))', err[w], tol[w])
         assert np.all(err <= tol), (shape, bn, err.max(), np.unravel_index(err.argmax(), err.shape))
-        # ... and band by band at the distance the float32 oracle itself keeps from the float64 one (not only inside the
-        # hand-set LOW_BAND_TOL)
-        o32, _, _ = orc.parametrized_forward(raw_np, P.astype(np.float32), bn=pc.oracle_bn(dict(case, bn=bn)))
+        # ... and band by band at the distance the float32 oracle itself keeps from the float64 one
         pc.check_float32_distance(f'fwd-stream/{shape}/bn={bn}/out', y.cpu().numpy(), o, o32, c['rgb'] > pc.WELL_CONDITIONED)
         os.environ['R2L_FWD_TILED'] = '1'
         try:
