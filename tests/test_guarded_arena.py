@@ -84,4 +84,4 @@ def test_tile_kernels_of_the_host_emulation_inside_guard_zones():
             out = ga.run_both('cpu', 3 * 10 * 8 * 40 + (32 << 20), fn, 'emulation static ' + '+'.join(chain))['out']
             assert np.abs(out.numpy() - orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, *chain)).max() <= 1e-5
     finally:
-        emul_hook.enable(prev)
+        emul_hook.enable(prev.path if prev is not None else None)
