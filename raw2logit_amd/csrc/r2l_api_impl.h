@@ -29,7 +29,30 @@ static int r2l_fail(int code, const std::string& msg) {
   return code;
 }
 
-#ifdef R2L_EMUL
+#ifdef R2L_LOCKSTEP
+// the lock-step emulation (tests/emul/r2l_lockstep_rt.h): NT host threads per workgroup, the workgroups one after the other; a
+// launch record (name -> count) stands in for the device build's event timing, so that tests can assert which kernels ran
+static std::mutex r2l_ls_record_mutex;
+static bool r2l_ls_record_on = false;
+static std::map<std::string, int> r2l_ls_record;
+static void r2l_ls_note(const char* name) {
+  std::lock_guard<std::mutex> g(r2l_ls_record_mutex);
+  if (r2l_ls_record_on) r2l_ls_record[std::string(name) + "_kernel"] += 1;
+}
+#define R2L_LS_KERNEL(name, ArgsT, NT_, LDSF, ...)                                                        \
+  static int name(const ArgsT& a, int grid, void* stream) {                                               \
+    (void)stream;                                                                                         \
+    r2l_ls_note(#name);                                                                                   \
+    r2l_ls::launch(#name, grid, (NT_), (size_t)(LDSF), &a,                                                \
+                   [&](int b_, float* lds_) { __VA_ARGS__(a, b_, grid, lds_); });                         \
+    return 0;                                                                                             \
+  }
+#define R2L_KERNEL_V(name, ArgsT, LDS_FLOATS, W, ...) R2L_LS_KERNEL(name, ArgsT, R2L_NT, LDS_FLOATS, __VA_ARGS__)
+#define R2L_KERNEL_OCC(name, ArgsT, blockfn, LDS_FLOATS, W) R2L_LS_KERNEL(name, ArgsT, R2L_NT, LDS_FLOATS, blockfn)
+#define R2L_KERNEL(name, ArgsT, blockfn, LDS_FLOATS) R2L_LS_KERNEL(name, ArgsT, R2L_NT, LDS_FLOATS, blockfn)
+#define R2L_KERNEL_NT(name, ArgsT, blockfn, NT, W) R2L_LS_KERNEL(name, ArgsT, NT, 0, blockfn)
+#define R2L_KERNEL_NT_LDS(name, ArgsT, NT, LDS_FLOATS, W, ...) R2L_LS_KERNEL(name, ArgsT, NT, LDS_FLOATS, __VA_ARGS__)
+#elif defined(R2L_EMUL)
 #define R2L_KERNEL_V(name, ArgsT, LDS_FLOATS, W, ...)                        \
   static int name(const ArgsT& a, int grid, void* stream) {                  \
     (void)stream;                                                            \
@@ -215,7 +238,7 @@ R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 *
 R2L_KERNEL_V(r2l_launch_fwd, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, false>)
 R2L_KERNEL_V(r2l_launch_fwd_ragged, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true, false>)
 R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, true, true, false>)
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
 // the forward as a row-streaming kernel (r2l_param_stream.h): NW wavefronts side by side cover 256 * NW columns
 #ifndef R2L_FS_OCC
 #define R2L_FS_OCC 3
@@ -303,7 +326,7 @@ R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC
 R2L_KERNEL_V(r2l_launch_bwd1_saved_u16, R2LBwd1Args, R2L_LDS3(GBwd1) + GBwd1::PAD + R2L_B1_FRAME_FLOATS, R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, true, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, true, true, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
 // kernel B1 as two passes over planes (r2l_param_plane_bwd.h): where the forward kept Y' and no epilogue / additive layer
 R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<false, false>)
 R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane_u16, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<true, false>)
@@ -358,7 +381,7 @@ R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_f64, 1, R2L_RAW_F64, true, 2)
 R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
 R2L_KERNEL(r2l_launch_spec_mask, R2LSpecMaskArgs, r2l_spec_mask_block, 4)
 R2L_KERNEL(r2l_launch_static_finish, R2LStaticFinishArgs, r2l_static_finish_block, 4)
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
 // row-streaming luma chains (r2l_static_chain.h): NW wavefronts side by side cover frames up to 256 * NW columns
 #ifndef R2L_CHAIN_OCC
 #define R2L_CHAIN_OCC 2
@@ -370,6 +393,16 @@ R2L_KERNEL(r2l_launch_static_finish, R2LStaticFinishArgs, r2l_static_finish_bloc
 #endif
 // (the workgroup size and the LDS size follow the frame width at launch time: 64 threads and 16.1 KB per strip)
 #define R2L_MAX_DEVICES 64
+#ifdef R2L_LOCKSTEP
+#define R2L_CHAIN_KERNEL(name, RAWK, DEB, SH, DN)                                                             \
+  static int name(const R2LStaticChainArgs& a, int grid, void* stream) {                                      \
+    (void)stream;                                                                                             \
+    r2l_ls_note(#name);                                                                                       \
+    r2l_ls::launch(#name, grid, a.nw * 64, 2 * (size_t)R2L_CHAIN_LDS_DOUBLES(a.nw, SH), &a,                   \
+                   [&](int b_, float* lds_) { r2l_static_chain_block<RAWK, DEB, SH, DN>(a, b_, grid, lds_); }); \
+    return 0;                                                                                                 \
+  }
+#else
 #define R2L_CHAIN_KERNEL(name, RAWK, DEB, SH, DN)                                                             \
   __global__ __launch_bounds__((SH) ? 256 : 512, (SH) ? R2L_CHAIN_OCC_SH : R2L_CHAIN_OCC) void name##_kernel(const R2LStaticChainArgs a) { \
     extern __shared__ __attribute__((aligned(16))) float r2l_chain_lds[];                                     \
@@ -401,6 +434,7 @@ R2L_KERNEL(r2l_launch_static_finish, R2LStaticFinishArgs, r2l_static_finish_bloc
     if (e != hipSuccess) return r2l_fail(-10, std::string(#name ": ") + hipGetErrorString(e));                \
     return 0;                                                                                                 \
   }
+#endif
 // [16-bit / float64 frames] x [Malvar2004] x [unsharp_masking] x [median_denoising]
 #define R2L_CHAIN_KERNELS(sfx, RAWK)                                               \
   R2L_CHAIN_KERNEL(r2l_launch_static_chain##sfx, RAWK, 0, 0, 0)                    \
@@ -597,6 +631,10 @@ void r2l_timing_enable(int on) {
 #ifndef R2L_EMUL
   std::lock_guard<std::mutex> g(r2l_timing_mutex);
   r2l_timing_on = on != 0;
+#elif defined(R2L_LOCKSTEP)
+  std::lock_guard<std::mutex> g(r2l_ls_record_mutex);
+  r2l_ls_record_on = on != 0;
+  if (on) r2l_ls_record.clear();
 #else
   (void)on;
 #endif
@@ -604,6 +642,13 @@ void r2l_timing_enable(int on) {
 
 int r2l_timing_report(char* buf, size_t n) {
   std::string out;
+#ifdef R2L_LOCKSTEP
+  {  // the launch record: "name count 0" lines (no clock in the emulation)
+    std::lock_guard<std::mutex> g(r2l_ls_record_mutex);
+    for (auto& kv : r2l_ls_record) out += kv.first + " " + std::to_string(kv.second) + " 0\n";
+    r2l_ls_record.clear();
+  }
+#endif
 #ifndef R2L_EMUL
   std::vector<R2LTimedLaunch> v;
   {
@@ -653,7 +698,7 @@ static int r2l_check_raw(const R2LRaw& raw, int W, const char* who) {
 #define R2L_F_INTERNAL (R2L_F_LUMA_VALID | R2L_F_SPLIT_STATS)
 // where the row-streaming forward (r2l_param_stream.h) runs -- and with R2L_F_KEEP_LUMA leaves Y' for kernel B1
 static bool r2l_fwd_streams(const float* additive, int W) {
-#ifdef R2L_EMUL
+#ifdef R2L_SERIAL
   (void)additive; (void)W;
   return false;
 #else
@@ -679,7 +724,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     R2LFoldArgs fa{params, ws.folded, ws.counters};
     if (int e = r2l_launch_fold(fa, 1, stream)) return e;
   }
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
   if (r2l_fwd_streams(additive, W)) {
     // row-streaming forward: work item = (image, band of rows); short bands are cheap here (the 8 halo rows of a
     // band only compute their luma), so aim at ~2048 items (three wavefronts per SIMD: the kernel's row step is a
@@ -927,7 +972,7 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   const bool exact = (H % GBwd1::TH == 0) && (W % GBwd1::TW == 0);
   int g1p = 0;  // workgroups of the plane passes, when they run
   bool blur_hp = false;  // ... with r2l_bwd1_blur_hp_block doing kernel B2's first pass
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
   // ... where there is enough work for their launch tails: 128x256x256 (8.4 Mpx) 102 us against the tile kernels' 110+,
   // 64x256x256 (4.2 Mpx) 77.7 against 80.5 since the tails were shortened (profiles/r04_small.txt; round 3: 99 against 85,
   // and the threshold was 6 Mi px)
@@ -947,7 +992,7 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
 #endif
   int e1;
   if (g1p) {
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
     e1 = a1.ep.on ? (raw.u16 ? r2l_launch_bwd1_plane_epi_u16(a1, g1p, stream) : r2l_launch_bwd1_plane_epi(a1, g1p, stream))
                   : (raw.u16 ? r2l_launch_bwd1_plane_u16(a1, g1p, stream) : r2l_launch_bwd1_plane(a1, g1p, stream));
     // its second pass (the blur-weight sums) and kernel B2's first (the blur's adjoint) read the same plane: one pass
@@ -992,7 +1037,7 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
   // 132 gradients; if B1 ran MORE workgroups than B2 (R2L_GRID_* overrides of diagnostic builds) three tiny
   // launches do it
   const int g1w = g1p ? g1p : g1;  // workgroups that wrote B1's partials
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
   if (g1p && !r2l_env_int("R2L_BWD2_TILED", 0)) {
     // kernel B2 as two passes over planes (r2l_param_plane_bwd.h)
     const long nstrip = (W + 255) / 256;
@@ -1258,7 +1303,7 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
 // chains the row-streaming luma-chain kernel covers (r2l_static_chain.h): bilinear + [sharpening_filter] +
 // [gaussian_denoising], frames up to 2048 columns, W % 4 == 0
 static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoising) {
-#ifdef R2L_EMUL
+#ifdef R2L_SERIAL
   (void)W; (void)debayer; (void)sharpening; (void)denoising;
   return false;  // (lane shifts and wave-level exchange: not expressible in the one-lane-at-a-time emulation)
 #else
@@ -1386,7 +1431,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
   R2LStaticArgs a;
   r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, mean_std_host);
   const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
   if (r2l_static_is_chain(W, debayer, sharpening, denoising)) {
     R2LStaticChainArgs ca;
     ca.s = a;

@@ -16,6 +16,30 @@
 
 #define R2L_NT 512  // threads per workgroup: 8 wavefronts of 64 (two per SIMD)
 
+// Host builds (test infrastructure, tests/emul/):
+//   R2L_EMUL                  the SERIAL emulation (tests/emul/r2l_emul.cpp): every phase as a loop over tid, no operation
+//                             between lanes -- it compiles the tile forms of the kernels only (R2L_SERIAL below);
+//   R2L_EMUL + R2L_LOCKSTEP   the LOCK-STEP emulation (tests/emul/r2l_lockstep.cpp): one host thread per lane, the
+//                             workgroups of a launch one after the other; wave shifts / readfirstlane / shuffles / s_barrier
+//                             are rendezvous between the threads of a wavefront resp. workgroup (tests/emul/r2l_lockstep_rt.h).
+//                             It compiles EVERY kernel -- the row-streaming forward, the passes over planes, the branch-free
+//                             static loops -- in its device form, for -fsanitize=address,undefined runs of the CPU suite.
+// Both take the host forms of the leaf helpers (packed pairs, LDS reads, coherent loads: `#ifdef R2L_EMUL`).
+#if defined(R2L_EMUL) && !defined(R2L_LOCKSTEP)
+#define R2L_SERIAL 1
+#endif
+#ifdef R2L_LOCKSTEP
+#include "../../tests/emul/r2l_lockstep_rt.h"
+#endif
+// workgroup barrier that orders LDS traffic only (see R2L_PHASE_END)
+#if defined(R2L_LOCKSTEP)
+#define R2L_LDS_BARRIER() r2l_ls::wg_barrier()
+#elif defined(R2L_EMUL)
+#define R2L_LDS_BARRIER()
+#else
+#define R2L_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 #ifdef R2L_EMUL
 #define R2L_HD static inline
 #define R2L_HOSTDEV static inline
@@ -33,7 +57,8 @@ R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
 R2L_HD r2l_f4 r2l_stream_load_f4(const float* p) { return *(const r2l_f4*)p; }
 R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& v) { *(r2l_f4*)p = v; }
 R2L_HD r2l_f4 r2l_load_f4_nt(const float* p) { return *(const r2l_f4*)p; }
-// the emulation runs one lane at a time: kernels take their every-lane-loads form there
+#ifdef R2L_SERIAL
+// the serial emulation runs one lane at a time: kernels take their every-lane-loads form there
 #define R2L_HAVE_LANE_SHIFTS false
 #define R2L_LANE_ID 0
 R2L_HD float r2l_wave_shr1(float x) { return x; }
@@ -47,6 +72,26 @@ R2L_HD float r2l_row_shl1(float x, float edge) { return edge; }
 #define R2L_PHASE_END }
 #define R2L_TREG_DECL(type, name) type name##_all[R2L_NT]
 #define R2L_TREG(name) name##_all[tid]
+#else
+// the lock-step emulation: one host thread per lane -- the device's forms, the lane-to-lane moves as rendezvous
+#define R2L_HAVE_LANE_SHIFTS true
+#define R2L_LANE_ID ((int)(threadIdx.x & 63))
+R2L_HD float r2l_wave_shr1(float x) { return r2l_ls::dpp(x, x, 0x138); }
+R2L_HD float r2l_wave_shl1(float x) { return r2l_ls::dpp(x, x, 0x130); }
+R2L_HD float r2l_row_shr1(float x, float edge) { return r2l_ls::dpp(edge, x, 0x111); }
+R2L_HD float r2l_row_shl1(float x, float edge) { return r2l_ls::dpp(edge, x, 0x101); }
+#define R2L_PHASE_BEGIN \
+  {                     \
+    const int tid = threadIdx.x;
+#define R2L_PHASE_BEGIN_L R2L_PHASE_BEGIN
+#define R2L_PHASE_BEGIN_IF(L) R2L_PHASE_BEGIN
+#define R2L_PHASE_BEGIN_N(NT) R2L_PHASE_BEGIN
+#define R2L_PHASE_END \
+  }                   \
+  R2L_LDS_BARRIER();
+#define R2L_TREG_DECL(type, name) type name
+#define R2L_TREG(name) name
+#endif
 #define R2L_PRAGMA_UNROLL
 #define R2L_PRAGMA_NOUNROLL
 #define R2L_SCHED_FENCE()
@@ -153,9 +198,9 @@ R2L_HD int r2l_phase_tid() {
 // also wait for every outstanding global store (s_waitcnt vmcnt(0)), i.e. expose the full HBM write
 // latency of the previous tile's output at every barrier; the raw barrier below waits for LDS only.
 // (Global loads feeding a ds_write are waited for by the compiler at the ds_write itself.)
-#define R2L_PHASE_END                                               \
-  }                                                                 \
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#define R2L_PHASE_END \
+  }                   \
+  R2L_LDS_BARRIER();
 #define R2L_TREG_DECL(type, name) type name
 #define R2L_TREG(name) name
 #define R2L_PRAGMA_UNROLL _Pragma("unroll")
@@ -605,6 +650,11 @@ R2L_HD const __attribute__((address_space(4))) T* r2l_kernargs() {
       (const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));
   return p;
+}
+#elif defined(R2L_LOCKSTEP)
+template <class T>
+R2L_HD const T* r2l_kernargs() {
+  return (const T*)r2l_ls::kernarg();
 }
 #endif
 

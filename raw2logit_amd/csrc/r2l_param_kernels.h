@@ -676,8 +676,8 @@ struct R2LNoExtra {
   double fetch(int) const { return 0.0; }
   void put(int, double) const {}
 #else
-  __device__ double fetch(int) const { return 0.0; }
-  __device__ void put(int, double) const {}
+  R2L_MEMBER double fetch(int) const { return 0.0; }
+  R2L_MEMBER void put(int, double) const {}
 #endif
 };
 // `also`: something else the last workgroup reads from global memory -- also.fetch(tid) goes out with the batch of loads,

@@ -23,7 +23,7 @@
 #pragma once
 #include "r2l_param_stream.h"
 
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
 
 #ifndef R2L_BP_PF
 #define R2L_BP_PF 2   // rows of raw / Y' in flight
@@ -234,7 +234,7 @@ R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int sl
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < ROWS; ++i)
       if (base + i < NSLOTS) lds[i * (NT + 1) + tid] = val(base + i);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_LDS_BARRIER();
     {
       const int slot = tid >> 4, part = tid & 15;  // 16 lanes per slot add NT / 16 values each; NT / 16 slots per pass
       R2L_PRAGMA_UNROLL
@@ -250,7 +250,7 @@ R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int sl
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_LDS_BARRIER();
     if (tid < ROWS && base + tid < NSLOTS) {
       float s = 0.f;
       R2L_PRAGMA_UNROLL
@@ -258,7 +258,7 @@ R2L_BLOCKFN void r2l_bp_block_reduce(float* lds, int tid, float* partial, int sl
       r2l_store_coherent(&partial[(size_t)(slot0 + base + tid) * nblk + bid], s);
     }
     if (base + ROWS >= NSLOTS) R2L_STORES_DONE();  // B2's last workgroups finish the reduction
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_LDS_BARRIER();
   }
 }
 
@@ -377,7 +377,7 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
     O[4 * c + 2] = o4.z;
     O[4 * c + 3] = o4.w;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
+  R2L_LDS_BARRIER();  // the bank areas become reduction scratch
   // (not the blur-weight sums, slots < R2L_B1_GAU: the blur pass that runs behind this launch on the same grid writes them)
   r2l_bp_block_reduce<R2L_B1_NACC - R2L_B1_GAU, R2L_BP_NT, R2L_BP_ROWS>(
       lds, tid, a.partial, R2L_B1_GAU, bid, nblk, [&](int i) { return r2l_bp_slot(A, E, O, R2L_B1_GAU + i); });
@@ -985,8 +985,8 @@ R2L_HD float r2l_b2s_slot(const R2LSumAcc& A, const float* E, const float* O, in
 struct R2LB1Totals {  // (r2l_tree_level2's `also`: the last workgroup picks up the helpers' totals with its own loads)
   const double* tot;
   double* sums;
-  __device__ double fetch(int tid) const { return tid < R2L_B1_NACC ? r2l_load_coherent(tot + tid) : 0.0; }
-  __device__ void put(int tid, double v) const {
+  R2L_MEMBER double fetch(int tid) const { return tid < R2L_B1_NACC ? r2l_load_coherent(tot + tid) : 0.0; }
+  R2L_MEMBER void put(int tid, double v) const {
     if (tid < R2L_B1_NACC) sums[tid] = v;
   }
 };
@@ -1005,7 +1005,7 @@ R2L_BLOCKFN void r2l_b2s_helper(const R2LBwd2Args& a, int h, float* lds, int tid
     for (int k = 0; k < 16; ++k) acc += (m0 + 32 * k < n1) ? (double)v[k] : 0.0;
   }
   hd[tid] = acc;
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  R2L_LDS_BARRIER();
   if (tid < 8 && h * 8 + tid < R2L_B1_NACC) {
     double t = 0.0;
     R2L_PRAGMA_UNROLL
@@ -1013,7 +1013,7 @@ R2L_BLOCKFN void r2l_b2s_helper(const R2LBwd2Args& a, int h, float* lds, int tid
     r2l_store_coherent(a.b1_tot + h * 8 + tid, t);
   }
   R2L_STORES_DONE();
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  R2L_LDS_BARRIER();
 }
 template <bool U16>
 R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_launch, float* lds) {
@@ -1028,7 +1028,7 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_lau
     if (tid < R2L_P_COUNT) pl[tid] = a.params[tid];
     r2l_b2s_helper(a, bid - nblk, lds, tid);  // (its barriers also publish pl)
     r2l_unfold_tables_lane<NT>(tid, tg, pl);  // in case this workgroup turns out to be the launch's last
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_LDS_BARRIER();
     if (!r2l_tree_level2<R2L_B2_NACC, NT>(a.tree, nblk, R2L_B2S_HELPERS, lds, sums + R2L_B1_NACC, (double*)(lds + 1024),
                                           R2LB1Totals{a.b1_tot, sums}))
       return;
@@ -1154,7 +1154,7 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_lau
   // their own in the launch's last workgroup
   static_assert(R2L_P_COUNT <= NT, "one parameter per lane");
   const float pv = (a.tree.counters && tid < R2L_P_COUNT) ? a.params[tid] : 0.f;
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the bank areas become reduction scratch
+  R2L_LDS_BARRIER();  // the bank areas become reduction scratch
   r2l_bp_block_reduce<R2L_B2_NACC, NT, R2L_B2_NACC>(lds, tid, a.partial, 0, bid, nblk,
                                                     [&](int i) { return r2l_b2s_slot(A, E, O, i); });
   R2L_TAILST(21);
@@ -1165,7 +1165,7 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_lau
     // the packed parameters go to LDS, and what the unfold derives from them alone is computed while the first ticket
     // travels (by every workgroup: the vector unit has nothing else to do then; only the last one uses it)
     if (tid < R2L_P_COUNT) pl[tid] = pv;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_LDS_BARRIER();
     if (a.nmain > 0) {  // B2's slots here, B1's by the helper workgroups
       if (!r2l_tree_level1<R2L_B2_NACC, NT>(a.tree, bid, nblk, lds, [&](int t) { r2l_unfold_tables_lane<NT>(t, tg, pl); })) return;
       if (!r2l_tree_level2<R2L_B2_NACC, NT>(a.tree, nblk, R2L_B2S_HELPERS, lds, sums + R2L_B1_NACC, (double*)(lds + 1024),
@@ -1183,4 +1183,4 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_lau
   }
 }
 
-#endif  // !R2L_EMUL
+#endif  // !R2L_SERIAL

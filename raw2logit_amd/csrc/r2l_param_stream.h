@@ -19,7 +19,7 @@
 #pragma once
 #include "r2l_param_kernels.h"
 
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL  // (needs lane-to-lane moves: the device, or the lock-step emulation)
 
 #ifndef R2L_FS_PF
 #define R2L_FS_PF 2
@@ -70,9 +70,13 @@ struct R2LFwdStreamArgs {
 // the lane's index in its wavefront from the hardware (v_mbcnt), opaque to the optimiser: every call re-derives it (two
 // instructions) instead of keeping one value alive from the kernel's first instruction to its last
 R2L_HD int r2l_lane_id() {
+#ifdef R2L_EMUL
+  return (int)(threadIdx.x & 63u);
+#else
   int l;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
   return l;
+#endif
 }
 R2L_HD float r2l_wshr(float x, float edge) {  // previous lane's x; lane 0 of the wavefront gets `edge`
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x),
@@ -396,7 +400,7 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
   }
   if (EXCH) {
     float* mine = ex + ((q & 1) * NW + wave) * R2L_FS_EX;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_LDS_BARRIER();
     if (lane == 0 && wave > 0) {
       const float* o = mine - R2L_FS_EX;
       rl_y = o[3];
@@ -533,7 +537,7 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
                                      float* red) {
   (void)a_;
   // the arguments of this part are read here, not carried through the main loop in scalar registers (r2l_kernargs)
-  const __attribute__((address_space(4))) R2LFwdStreamArgs* ka = r2l_kernargs<R2LFwdStreamArgs>();
+  const R2L_CONSTAS R2LFwdStreamArgs* ka = r2l_kernargs<R2LFwdStreamArgs>();
   struct {
     float* stat_partial;
     R2LTree tree;
@@ -569,7 +573,7 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
     pre.nbt = 0;
     pre.rm = pre.rv = 0.f;
     if (a.tree.counters && a.fin.bn) pre = r2l_bn_finalize_fetch(a.fin, tid);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wavefront is done with its chroma ring
+    R2L_LDS_BARRIER();  // every wavefront is done with its chroma ring
     if (tid < 6) {  // the wavefronts' totals in wavefront order; (high, low) float32 halves in slots tid and 6 + tid
       double acc = 0.0;
       for (int w = 0; w < NW; ++w) acc += (tots - wave * 6)[w * 6 + tid];
@@ -578,17 +582,17 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
       r2l_store_coherent(&a.stat_partial[(size_t)(6 + tid) * nblk + bid], (float)(acc - (double)hi));
     }
     R2L_STORES_DONE();
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_LDS_BARRIER();
     R2L_TAILST(1);
     double* sl = (double*)(red + 4);  // totals in LDS: the bookkeeping below reads them back
     if (a.tree.counters &&
         r2l_tree_finish<12, NT>(a.tree, bid, nblk, red, sl, (double*)(red + 512), (R2L_FS_RED_FLOATS(NW) - 512) / 2)) {
       if (tid < 6) sl[tid] += sl[6 + tid];
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      R2L_LDS_BARRIER();
       if (tid == 0) sl[6] = (double)a.B * (double)a.H * (double)a.W;
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      R2L_LDS_BARRIER();
       if (tid < 7) a.stats_out[tid] = sl[tid];
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      R2L_LDS_BARRIER();
       if (a.fin.bn) {
         R2LBnFinalizeArgs f = a.fin;
         f.tot = sl;
@@ -770,7 +774,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
 #undef R2L_FS_STEP
     }
 #endif
-    if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // exchange buffers free for the next item
+    if (NW > 1) R2L_LDS_BARRIER();  // exchange buffers free for the next item
     if (SONLY || a.stat_partial) r2l_fs_lane_sums(st.acc, st.piv, store_ok ? 4.0 * (double)(y1 - y0) : 0.0, store_ok, lane, tots);
   }
   if (SONLY || a.stat_partial) {
@@ -845,7 +849,9 @@ R2L_HD void r2l_fa_build(const R2LFaStage& s, bool rin, bool le, bool re, float 
 // of its own (STATS: without a store or a branch the six unrolled steps are ONE block, scheduled as one: 215 VGPRs)
 R2L_HD bool r2l_opaque_true() {
   int one = 1;
+#ifndef R2L_EMUL
   asm volatile("" : "+s"(one));
+#endif
   return one != 0;
 }
 struct R2LFaState {
@@ -1168,4 +1174,4 @@ R2L_BLOCKFN void r2l_fwd_luma_block(const R2LFwdStreamArgs& a, int bid, int nblk
   R2L_TL_END(a, bid)
 }
 
-#endif  // !R2L_EMUL
+#endif  // !R2L_SERIAL

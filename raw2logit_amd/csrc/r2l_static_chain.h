@@ -40,7 +40,7 @@
 #define R2L_CHAIN_PRIO(d, t)
 #endif
 
-#ifndef R2L_EMUL
+#ifndef R2L_SERIAL
 
 #ifndef R2L_CHAIN_PF
 #define R2L_CHAIN_PF 3
@@ -100,12 +100,14 @@ R2L_HD double r2l_chain_med3(double a, double b, double c) { return fmax(fmin(a,
 // The chain's 45 float64 constants are kernel arguments.  Kept live across the row loop they overflow the scalar
 // registers and get parked in VGPR lanes (35 v_readlane per row); read through a laundered pointer to the kernarg
 // segment they are re-loaded (s_load, scalar cache) in front of the section that uses them.
-typedef const __attribute__((address_space(4))) R2LStaticArgs* R2LStaticArgsK;
+typedef const R2L_CONSTAS R2LStaticArgs* R2LStaticArgsK;
 R2L_HD R2LStaticArgsK r2l_chain_consts() {
 #if defined(__HIP_DEVICE_COMPILE__)
   R2LStaticArgsK p = (R2LStaticArgsK)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));
   return p;
+#elif defined(R2L_LOCKSTEP)
+  return (R2LStaticArgsK)r2l_ls::kernarg();  // (R2LStaticChainArgs starts with its R2LStaticArgs)
 #else
   return nullptr;
 #endif
@@ -121,7 +123,7 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, SH, DN>& 
 #ifdef R2L_CHAIN_ARGS_LIVE
   const R2LStaticArgs& a = a_;
 #else
-  const __attribute__((address_space(4))) R2LStaticArgs& a = *r2l_chain_consts();
+  const R2L_CONSTAS R2LStaticArgs& a = *r2l_chain_consts();
 #endif
   double yq[4];  // Y(q) (new)
   double yp[4];  // the sharpened row it completes
@@ -238,7 +240,7 @@ R2L_HD void r2l_chain_step(const R2LStaticArgs& a_, R2LChainState<DEB, SH, DN>& 
       mine[4] = yp[2];
       mine[5] = yp[3];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    R2L_LDS_BARRIER();
     if (lane == 0 && wave > 0) {
       const double* o = mine - R2L_CHAIN_EX;
       rl_y = o[3];
@@ -482,4 +484,4 @@ R2L_BLOCKFN void r2l_static_chain_block(const R2LStaticChainArgs& ca, int bid, i
 #undef R2L_CHAIN_FETCH
 }
 
-#endif  // !R2L_EMUL
+#endif  // !R2L_SERIAL

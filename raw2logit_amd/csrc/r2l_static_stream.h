@@ -819,7 +819,7 @@ R2L_BLOCKFN void r2l_static_stream_block(const R2LStaticStreamArgs& sa, int bid,
   bid = r2l_xcd_contiguous(bid, nblk);
   R2L_PHASE_BEGIN_N(R2L_STREAM_NT)
   const int item = bid * (R2L_STREAM_NT / 64) + (tid >> 6);  // one work item per wavefront
-#if R2L_STREAM_BF && !defined(R2L_EMUL)
+#if R2L_STREAM_BF && !defined(R2L_SERIAL)
   if constexpr (!LUMA && RAWK != R2L_RAW_F64 && (R2L_STREAM_BF == 1 || DEB == 1)) {
     // (the wavefront index as a SCALAR: the work item and its rows must not look lane-dependent)
     const int witem = bid * (R2L_STREAM_NT / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
