@@ -65,8 +65,8 @@ def algo_bytes_per_px(kernel):
     return None
 
 
-PMC_PARAM = 'r04_pmc_traffic.json'
-PMC_STATIC = 'r04_pmc_traffic_static.json'      # all three static kernels of static_c3, this round's build
+PMC_PARAM = 'r05_pmc_traffic.json'
+PMC_STATIC = 'r05_pmc_traffic_static.json'      # all three static kernels of static_c3, this round's build
 
 
 def pmc_traffic(kernel, B, S, name=PMC_PARAM, shape=(64, 512)):

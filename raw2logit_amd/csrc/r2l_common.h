@@ -31,6 +31,13 @@
 #ifdef R2L_LOCKSTEP
 #include "../../tests/emul/r2l_lockstep_rt.h"
 #endif
+// a lane whose EXEC bit goes off for the rest of the kernel while its wavefront goes on exchanging values between lanes (the
+// lock-step emulation has to be told; nothing on the device)
+#ifdef R2L_LOCKSTEP
+#define R2L_LANE_RETIRES() r2l_ls::retire_lane()
+#else
+#define R2L_LANE_RETIRES()
+#endif
 // workgroup barrier that orders LDS traffic only (see R2L_PHASE_END)
 #if defined(R2L_LOCKSTEP)
 #define R2L_LDS_BARRIER() r2l_ls::wg_barrier()

@@ -514,7 +514,10 @@ R2L_HD void r2l_static_stream_item(const R2LStaticStreamArgs& sa, int item, int 
   const int seg = item % sa.nseg, r = item / sa.nseg;
   const int band = r % sa.nband, b = r / sa.nband;
   const int x0 = seg * 256 + 4 * lane;
-  if (x0 >= a.W) return;
+  if (x0 >= a.W) {
+    R2L_LANE_RETIRES();
+    return;
+  }
   const int y0 = band * sa.band_h;
   const int y1 = (y0 + sa.band_h < a.H) ? y0 + sa.band_h : a.H;
   const bool le = x0 == 0, re = x0 + 4 >= a.W;
