@@ -58,7 +58,11 @@ R2L_HD void r2l_bp_fetch_g(const float* gimg, unsigned plane, int y, int H, int 
   }
   const float* p = gimg + (size_t)yc * W + x0;
   R2L_PRAGMA_UNROLL
+#ifdef R2L_BP_GOUT_PLAIN  // A/B builds
+  for (int k = 0; k < 3; ++k) s.g[k] = *(const r2l_f4*)(p + (size_t)k * plane);
+#else
   for (int k = 0; k < 3; ++k) s.g[k] = r2l_load_f4_nt(p + (size_t)k * plane);  // read once: nontemporal (as kernel B1)
+#endif
 }
 
 struct R2LBpState {

@@ -182,7 +182,11 @@ R2L_HD void r2l_bn_reduce_item(int tid, const R2LBnReduceArgs& a, int item, int 
     if (e < hw) {
       // nontemporal: 400 MB read once; plain loads also evict the raw frames and dL/dY'' that the two backward
       // kernels are about to re-read (82 -> 65 us here, -8 us in bwd1, -5 us in bwd2)
+#ifdef R2L_BNR_GOUT_PLAIN  // A/B builds: grad_out allocates in the caches on its way through (kernel B1 reads it again right away)
+      const r2l_f4 gv = *(const r2l_f4*)(g + e);
+#else
       const r2l_f4 gv = r2l_load_f4_nt(g + e);
+#endif
       const r2l_f4 ov = r2l_load_f4_nt(o + e);
       sg += (gv.x + gv.y) + (gv.z + gv.w);
       sgx = fmaf(gv.x, ov.x, sgx);

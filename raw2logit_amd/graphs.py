@@ -24,6 +24,8 @@ data-parallel step of the PROCESSOR: statistics of the global batch, the process
 the ranks.  The gradients of `loss_modules` (a classifier head) are NOT reduced here: they are DistributedDataParallel's
 business -- wrap the head in DDP inside `loss`, or pass `reduce_loss_modules=True` to put them into the same flat all-reduce.
 """
+import gc
+
 import torch
 
 
@@ -75,8 +77,18 @@ class StepGraph:
             for p in self.params:                         # the captured step allocates the gradients in the graph's pool
                 p.grad = None
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = self._step()
+            # no cyclic garbage collection while the stream is capturing: collecting an object that owns device resources (an
+            # older graph, an event, a large cached block) from inside a capture aborts the process on this stack -- it depends
+            # on what the caller left uncollected, i.e. on nothing this class controls (seen in the GPU suite, round 5)
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.out = self._step()
+            finally:
+                if gc_was_on:
+                    gc.enable()
         finally:
             model.process_group = self._model_group
         self._grads = [p.grad for p in self.params]       # tensors of the graph's pool: every replay writes them

@@ -13,6 +13,7 @@ everything -- guards and the not-yet-written payloads -- pre-filled with a poiso
 
 The reference gets both properties from ATen's bounds-checked indexing (pipeline_torch.py:187-217)."""
 import contextlib
+import gc
 
 import numpy as np
 import torch
@@ -126,6 +127,7 @@ def run_both(device, nbytes, fn, what):
             arena.check_guards(f'{what} [{poison}]')
             res[poison] = {k: v.detach().cpu().clone() for k, v in out.items()}
         del arena, out
+        gc.collect()      # (the arena is hundreds of MB and sits in reference cycles with the patched allocators' closures)
     assert n_blocks > 0, what
     for k in res['nan']:
         a, b = res['nan'][k], res['zero'][k]

@@ -444,7 +444,15 @@ def test_survives_hip_graph_capture(dev):
     cot = torch.randn((4, 3, 128, 128), device=dev, generator=torch.Generator(dev).manual_seed(3))
     m = ppt.ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).to(dev).train()
     m2 = copy.deepcopy(m)
-    graphed = torch.cuda.make_graphed_callables(m2, (raw,))
+    import gc
+    gc.collect()                    # (no cyclic garbage with device resources left for a collection in the middle of the captures)
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        graphed = torch.cuda.make_graphed_callables(m2, (raw,))
+    finally:
+        if gc_was_on:
+            gc.enable()
     for _ in range(3):          # replays
         for p in list(m.parameters()) + list(m2.parameters()):
             p.grad = None
