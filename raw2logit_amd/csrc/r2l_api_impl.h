@@ -1327,11 +1327,14 @@ static void r2l_stream_shape(R2LStaticStreamArgs& sa, int B, int H, int W, int d
   // compact in HBM (a few tens of MiB instead of a slice of every image of the batch), which is worth far more
   // than the halo rows every band re-reads (they come from L2): same-buffer A/B on 256x1024x1024, bilinear,
   // 128 rows per band 862 us, 32 rows 830, 16 rows 800, 8 rows 735-756, 5 rows 754, 4 rows 778, 2 rows 1012.
-  // Malvar (4 halo rows, 5-row window) is flat between 24 and 48 rows per band.
+  // Malvar (4 halo rows, 5-row window) is flat between 24 and 48 rows per band -- and, round 5, 6 % FASTER at 10 rows (two
+  // full groups of its 5-step unrolled loop): 883 -> 826 us on 256x1024x1024, same buffers (profiles/r05_static_ab.txt;
+  // 9 rows 835, 13 rows 848, 15 rows 836, 5 rows 867, 6 rows -- 4 wasted steps of 10 -- 1000): the same compactness, at
+  // 40 % more fetched rows.  Rounds 1-4 had only swept 24 .. 48.
   // Round 2, other frame widths (profiles/r02_j_stream_bands.txt): 6-row bands are as good on 1024-wide frames
   // (0.711 vs 0.709 of the HBM peak) and better on 512- and 256-wide ones (0.718 vs 0.692, 0.724 vs 0.700).
   sa.nseg = (W + 255) / 256;
-  const int rows = (debayer == R2L_DEBAYER_MALVAR2004) ? 32 : 6;
+  const int rows = (debayer == R2L_DEBAYER_MALVAR2004) ? 10 : 6;
   long nband = (H + rows - 1) / rows;
   nband = r2l_env_int("R2L_STREAM_BANDS", (int)nband);
   if (nband > H / 2) nband = H / 2;
