@@ -38,7 +38,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # several ranks: capture + agreement + timing of the graph trial, or the eager line goes out (the environment variable: tests)
-GRAPH_TRIAL_TIMEOUT_S = float(os.environ.get('R2L_BENCH_TRIAL_TIMEOUT_S', '90'))
+GRAPH_TRIAL_TIMEOUT_S = float(os.environ.get('R2L_BENCH_TRIAL_TIMEOUT_S', '180'))
 PREROLL_S = float(os.environ.get('R2L_BENCH_PREROLL_S', '0.3'))   # untimed pre-roll of the step before the W warm-up steps
                                # (GPU clocks, see main(); counter-collection runs of the profiling scripts set 0)
 # algorithmic HBM bytes per raw pixel of each kernel family, by kernel-name prefix; the
@@ -695,7 +695,7 @@ def main():
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                         'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
 
-    graph_ms = graph_err = graph_local_ms = None
+    graph_ms = graph_err = graph_local_ms = graph_local_err = None
     static_c3 = small = None
     # (sub-records: a failure in one of them must not cost the headline line -- it is reported in its place)
     if world == 1 and dev.type == 'cuda' and not args.no_small_shapes:
@@ -711,7 +711,7 @@ def main():
         except Exception as e:                       # noqa: BLE001
             static_c3 = {'error': '%s: %s' % (type(e).__name__, e)}
 
-    def line(graph_ms, graph_err, graph_local_ms=None, watchdog=False):
+    def line(graph_ms, graph_err, graph_local_ms=None, watchdog=False, graph_local_err=None):
         """the JSON line.  Its value is the EAGER step's (what roofline / kernels describe); with several RCCL ranks the step as
         one HIP graph with its collectives captured is timed too and reported BESIDE it (ms_per_step_graph / value_graph) --
         that path has only ever run against a one-rank RCCL group, so it does not carry the headline until a multi-GPU run has
@@ -763,6 +763,8 @@ def main():
             out['graph_comm_us'] = round(1e3 * (graph_ms - graph_local_ms), 1)
         if graph_err is not None:
             out['graph_error'] = graph_err
+        if graph_local_err is not None:
+            out['graph_local_error'] = graph_local_err      # (graph_comm_us is then missing; nothing else depends on it)
         if watchdog:
             out['watchdog_fired'] = True
         if comm_us is not None:
@@ -831,9 +833,9 @@ def main():
                     g3.replay()
                     torch.cuda.synchronize()
                     graph_local_ms = 1e3 * clock.time_steps(g3.replay, args.steps, args.warmup) / args.steps
-                except Exception as e:               # noqa: BLE001
+                except Exception as e:               # noqa: BLE001   (best effort: the graph's own numbers stand without it)
                     graph_local_ms = None
-                    graph_err = 'local-collectives graph: %s: %s' % (type(e).__name__, e)
+                    graph_local_err = '%s: %s' % (type(e).__name__, e)
                 finally:
                     if old_split is None:
                         os.environ.pop('R2L_SPLIT_SINGLE_RANK', None)
@@ -847,7 +849,7 @@ def main():
         if not printed.acquire(blocking=False):      # the watchdog is printing: it ends the process
             time.sleep(60)
     if rank == 0:
-        print(json.dumps(line(graph_ms, graph_err, graph_local_ms)), flush=True)
+        print(json.dumps(line(graph_ms, graph_err, graph_local_ms, graph_local_err=graph_local_err)), flush=True)
     if group_on:
         dist.barrier()
         dist.destroy_process_group()

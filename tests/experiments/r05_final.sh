@@ -19,6 +19,6 @@ PY
 bash tests/profile_round.sh r05_z > gpurun_out/r05_profile_round.log 2>&1
 cp gpurun_out/r05_z/pmc_traffic.json profiles/r05_pmc_traffic.json
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/r05_z/bench_final.json 2>> gpurun_out/r05_z/bench.err     # (with this round's PMC files in place)
-R2L_PARITY_LOG=$PWD/gpurun_out/r05_parity_gpu.tsv python -m pytest tests -x -q -m gpu 2>&1 | tail -12 > gpurun_out/r05_gputests.log
+R2L_PARITY_LOG=$PWD/gpurun_out/r05_parity_gpu.tsv python -m pytest tests -x -q -m gpu 2>&1 | tail -80 > gpurun_out/r05_gputests.log
 cp profiles/r05_pmc_traffic.json profiles/r05_pmc_traffic_static.json gpurun_out/r05_z/ 2>/dev/null
 tail -3 gpurun_out/r05_gputests.log; tail -c 900 gpurun_out/r05_z/bench_final.json
