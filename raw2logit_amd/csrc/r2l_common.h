@@ -38,6 +38,14 @@
 #else
 #define R2L_LANE_RETIRES()
 #endif
+// DIAGNOSTIC BUILDS, TIMING ONLY (-DR2L_EXP_NO_HALO; results are wrong): the band passes fetch their halo rows from inside the band
+// (the row clamped to [y0, y1 - 1]: a line the wavefront itself touched a few steps ago), i.e. every plane is fetched exactly once --
+// the upper bound of what bands that share their halo rows in time (odd bands walking bottom-up) could gain
+#ifdef R2L_EXP_NO_HALO
+#define R2L_NH(r) ((r) < y0 ? y0 : ((r) > y1 - 1 ? y1 - 1 : (r)))
+#else
+#define R2L_NH(r) (r)
+#endif
 // workgroup barrier that orders LDS traffic only (see R2L_PHASE_END)
 #if defined(R2L_LOCKSTEP)
 #define R2L_LDS_BARRIER() r2l_ls::wg_barrier()

@@ -321,16 +321,16 @@ R2L_BLOCKFN void r2l_bwd1_plane_block(const R2LBwd1Args& a, int bid, int nblk, f
     R2LBpStage pfg[PFG];  // grad_out row q
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < PF; ++i) {
-      r2l_fa_fetch_raw<U16>(sa, img, r2l_mirror(y0 - 3 + i, a.H), x0, le, re, lane, pf[(2 + i) % PF]);
-      r2l_fa_fetch(ypimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
+      r2l_fa_fetch_raw<U16>(sa, img, r2l_mirror(R2L_NH(y0 - 3 + i), a.H), x0, le, re, lane, pf[(2 + i) % PF]);
+      r2l_fa_fetch(ypimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
     }
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < PFG; ++i) r2l_bp_fetch_g<EPI>(gimg, plane, y0 + i, a.H, a.W, x0, a.ep, pfg[i % PFG]);  // (first used at K = 0)
 #define R2L_BP_LOAD_STEP(K, q)                                                                          \
   r2l_fs_convert<U16>(sa, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3]);                                \
   r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, st.yp[((K) + 2) % 6]);       \
-  r2l_fa_fetch_raw<U16>(sa, img, r2l_mirror((q) + 1 + PF, a.H), x0, le, re, lane, pf[(K) % PF]);        \
-  r2l_fa_fetch(ypimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);
+  r2l_fa_fetch_raw<U16>(sa, img, r2l_mirror(R2L_NH((q) + 1 + PF), a.H), x0, le, re, lane, pf[(K) % PF]);        \
+  r2l_fa_fetch(ypimg, R2L_NH((q) + 2 + PF), a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);
     R2L_BP_LOAD_STEP(2, y0 - 4)
     R2L_BP_LOAD_STEP(3, y0 - 3)
     R2L_BP_LOAD_STEP(4, y0 - 2)
@@ -470,13 +470,13 @@ R2L_BLOCKFN void r2l_bwd1_blur_block(const R2LBwd1Args& a, int bid, int nblk, fl
     R2LBbStage pfg[PF];  // dL/dY'' row q
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < PF; ++i) {
-      r2l_fa_fetch(ypimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
+      r2l_fa_fetch(ypimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
       const int yc = (y0 + i < a.H) ? y0 + i : a.H - 1;
       pfg[i % PF].g = r2l_stream_load_f4(gimg + (size_t)yc * a.W + x0);
     }
 #define R2L_BB_LOAD_STEP(K, q)                                                                          \
   r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, yp[((K) + 2) % 6]);          \
-  r2l_fa_fetch(ypimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);
+  r2l_fa_fetch(ypimg, R2L_NH((q) + 2 + PF), a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);
     R2L_BB_LOAD_STEP(2, y0 - 4)
     R2L_BB_LOAD_STEP(3, y0 - 3)
     R2L_BB_LOAD_STEP(4, y0 - 2)
@@ -628,10 +628,10 @@ R2L_BLOCKFN void r2l_bwd2_hp_block(const R2LBwd2Args& a, int bid, int nblk, floa
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
   R2LFaStage pf[PF];  // g row q + 2
   R2L_PRAGMA_UNROLL
-  for (int i = 0; i < PF; ++i) r2l_fa_fetch(gimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pf[(2 + i) % PF]);
+  for (int i = 0; i < PF; ++i) r2l_fa_fetch(gimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pf[(2 + i) % PF]);
 #define R2L_HP_LOAD_STEP(K, q)                                                                          \
   r2l_hp_build(pf[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, gw[((K) + 2) % 6]);           \
-  r2l_fa_fetch(gimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pf[(K) % PF]);
+  r2l_fa_fetch(gimg, R2L_NH((q) + 2 + PF), a.H, a.W, x0, le, re, lane, pf[(K) % PF]);
   R2L_HP_LOAD_STEP(2, y0 - 4)
   R2L_HP_LOAD_STEP(3, y0 - 3)
   R2L_HP_LOAD_STEP(4, y0 - 2)
@@ -791,13 +791,13 @@ R2L_BLOCKFN void r2l_bwd1_blur_hp_block(const R2LBwd1Args& a, int bid, int nblk,
     r2l_f4 pfy[PF];      // Y' row q
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < PF; ++i) {
-      r2l_fa_fetch(gimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfg[(2 + i) % PF]);
+      r2l_fa_fetch(gimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfg[(2 + i) % PF]);
       const int yc = (y0 + i < a.H) ? y0 + i : a.H - 1;
       pfy[i % PF] = r2l_stream_load_f4(ypimg + (size_t)yc * a.W + x0);
     }
 #define R2L_BH_LOAD_STEP(K, q)                                                                          \
   r2l_hp_build(pfg[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, gw[((K) + 2) % 6]);          \
-  r2l_fa_fetch(gimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pfg[(K) % PF]);
+  r2l_fa_fetch(gimg, R2L_NH((q) + 2 + PF), a.H, a.W, x0, le, re, lane, pfg[(K) % PF]);
     R2L_BH_LOAD_STEP(2, y0 - 4)
     R2L_BH_LOAD_STEP(3, y0 - 3)
     R2L_BH_LOAD_STEP(4, y0 - 2)
@@ -1086,14 +1086,14 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_lau
     // row finishes the sharpen-weight sums of that row.
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < PF; ++i) {
-      r2l_fl_fetch<U16>(sa, img, r2l_mirror(y0 - 2 + i, a.H), x0, le, re, lane, pf[(3 + i) % PF]);
-      r2l_b2s_fetch_hp(hpimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfh[(3 + i) % PF]);
+      r2l_fl_fetch<U16>(sa, img, r2l_mirror(R2L_NH(y0 - 2 + i), a.H), x0, le, re, lane, pf[(3 + i) % PF]);
+      r2l_b2s_fetch_hp(hpimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfh[(3 + i) % PF]);
     }
 #define R2L_B2S_LOAD_STEP(K, t)                                                                               \
   r2l_fl_convert<U16>(sa, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3], st.xp[((K) + 1) % 3]);                \
   r2l_b2s_build_hp(pfh[(K) % PF], (unsigned)((t) + 1) < (unsigned)a.H, le, re, st.hp[((K) + 1) % 3]);         \
-  r2l_fl_fetch<U16>(sa, img, r2l_mirror((t) + 1 + PF, a.H), x0, le, re, lane, pf[(K) % PF]);                  \
-  r2l_b2s_fetch_hp(hpimg, (t) + 1 + PF, a.H, a.W, x0, le, re, lane, pfh[(K) % PF]);
+  r2l_fl_fetch<U16>(sa, img, r2l_mirror(R2L_NH((t) + 1 + PF), a.H), x0, le, re, lane, pf[(K) % PF]);                  \
+  r2l_b2s_fetch_hp(hpimg, R2L_NH((t) + 1 + PF), a.H, a.W, x0, le, re, lane, pfh[(K) % PF]);
     R2L_B2S_LOAD_STEP(3, y0 - 3)
     R2L_B2S_LOAD_STEP(4, y0 - 2)
     R2L_B2S_LOAD_STEP(5, y0 - 1)

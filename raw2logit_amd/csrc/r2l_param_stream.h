@@ -681,8 +681,8 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
       const int qf = y0 - 3, q1 = y1 + 4;  // q1: exclusive, = the last raw row the band consumes
       {
         R2LFsStage s0, s1;
-        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(qf - 1, a.H), x0, le, re, lane, s0);
-        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(qf, a.H), x0, le, re, lane, s1);
+        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(R2L_NH(qf - 1), a.H), x0, le, re, lane, s0);
+        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(R2L_NH(qf), a.H), x0, le, re, lane, s1);
         r2l_fs_convert<U16>(a, F, s0, le, re, st.v[2]);
         r2l_fs_convert<U16>(a, F, s1, le, re, st.v[0]);
       }
@@ -690,7 +690,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
       R2L_PRAGMA_UNROLL
       for (int i = 0; i < PF; ++i) {
         const int rr = (qf + 1 + i < q1) ? qf + 1 + i : q1;
-        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(rr, a.H), x0, le, re, lane, pf[i]);
+        r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(R2L_NH(rr), a.H), x0, le, re, lane, pf[i]);
       }
       const int nsteps = q1 - qf;
       for (int sb = 0; sb < nsteps; sb += 6) {
@@ -701,7 +701,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
     {                                                                                                           \
       const int rr_ = (q + 1 + PF < q1) ? q + 1 + PF : q1;                                                      \
-      r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(rr_, a.H), x0, le, re, lane, pf[K % PF]);                         \
+      r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(R2L_NH(rr_), a.H), x0, le, re, lane, pf[K % PF]);                         \
     }                                                                                                           \
     r2l_fs_step<NW, U16, K, EPI, (K + 1) & 1, true>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo,             \
                                                    SONLY ? nullptr : ob, ypb, plane, x0, store_ok, mean, istd, smask); \
@@ -725,8 +725,8 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     const int q1 = y1 + 4;  // exclusive: output row y1-1 leaves at step q = y1+3
     {
       R2LFsStage s0, s1;
-      r2l_fs_fetch<U16>(a, img, r2l_mirror(qf - 1, a.H), x0, le, re, lane, s0);
-      r2l_fs_fetch<U16>(a, img, r2l_mirror(qf, a.H), x0, le, re, lane, s1);
+      r2l_fs_fetch<U16>(a, img, r2l_mirror(R2L_NH(qf - 1), a.H), x0, le, re, lane, s0);
+      r2l_fs_fetch<U16>(a, img, r2l_mirror(R2L_NH(qf), a.H), x0, le, re, lane, s1);
       switch (k0 % 3) {  // rows qf-1, qf -> slots (k0 + 2) % 3, k0 % 3
         case 0:
           r2l_fs_convert<U16>(a, F, s0, le, re, st.v[2]);
@@ -746,7 +746,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < PF; ++i) {
       R2LFsStage t;
-      r2l_fs_fetch<U16>(a, img, r2l_mirror(qf + 1 + i, a.H), x0, le, re, lane, t);
+      r2l_fs_fetch<U16>(a, img, r2l_mirror(R2L_NH(qf + 1 + i), a.H), x0, le, re, lane, t);
       R2L_PRAGMA_UNROLL
       for (int j = 0; j < PF; ++j)
         if ((k0 + i) % PF == j) pf[j] = t;
@@ -760,9 +760,9 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     r2l_fs_convert<U16>(a, F, pf[K % PF], le, re, st.v[(K + 1) % 3]);                                           \
     if (R2L_FS_BF_FETCH) {                                                                                      \
       const int rr_ = (q + 1 + PF < q1) ? q + 1 + PF : q1;                                                      \
-      r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(rr_, a.H), x0, le, re, lane, pf[K % PF]);                         \
+      r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(R2L_NH(rr_), a.H), x0, le, re, lane, pf[K % PF]);                         \
     } else if (q + 1 + PF <= q1)                                                                                \
-      r2l_fs_fetch<U16>(a, img, r2l_mirror(q + 1 + PF, a.H), x0, le, re, lane, pf[K % PF]);                     \
+      r2l_fs_fetch<U16>(a, img, r2l_mirror(R2L_NH(q + 1 + PF), a.H), x0, le, re, lane, pf[K % PF]);                     \
     r2l_fs_step<NW, U16, K, EPI>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo, ob, ypb, plane, x0, store_ok, mean, istd, smask); \
   }
       R2L_FS_STEP(0)
@@ -935,15 +935,15 @@ R2L_HD void r2l_fa_item(const R2LFwdStreamArgs& a, int item, int lane, const flo
   // step q builds V(q+1) and Y'(q+2); from q = y0 on it also finishes output row q.  Warm-up: q = y0-4 .. y0-1 = K 2 .. 5.
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < PF; ++i) {
-    r2l_fa_fetch_raw<U16>(a, img, r2l_mirror(y0 - 3 + i, a.H), x0, le, re, lane, pf[(2 + i) % PF]);
-    r2l_fa_fetch(ypimg, y0 - 2 + i, a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
+    r2l_fa_fetch_raw<U16>(a, img, r2l_mirror(R2L_NH(y0 - 3 + i), a.H), x0, le, re, lane, pf[(2 + i) % PF]);
+    r2l_fa_fetch(ypimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
   }
 #define R2L_FA_LOAD_STEP(K, q)                                                                          \
   {                                                                                                     \
     r2l_fs_convert<U16>(a, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3]);                               \
     r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, st.yp[((K) + 2) % 6]);     \
-    r2l_fa_fetch_raw<U16>(a, img, r2l_mirror((q) + 1 + PF, a.H), x0, le, re, lane, pf[(K) % PF]);       \
-    r2l_fa_fetch(ypimg, (q) + 2 + PF, a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);                       \
+    r2l_fa_fetch_raw<U16>(a, img, r2l_mirror(R2L_NH((q) + 1 + PF), a.H), x0, le, re, lane, pf[(K) % PF]);       \
+    r2l_fa_fetch(ypimg, R2L_NH((q) + 2 + PF), a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);                       \
   }
   R2L_FA_LOAD_STEP(2, y0 - 4)
   R2L_FA_LOAD_STEP(3, y0 - 3)
@@ -1150,11 +1150,11 @@ R2L_BLOCKFN void r2l_fwd_luma_block(const R2LFwdStreamArgs& a, int bid, int nblk
   // warm-up: y = y0-4 (V(y0-2)), y0-3 (V(y0-1)), y0-2 (V(y0), Y(y0-1)), y0-1 (V(y0+1), Y(y0)) = K 2 .. 5
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < PF; ++i)
-    r2l_fl_fetch<U16>(a, img, r2l_mirror(y0 - 2 + i, a.H), x0, le, re, lane, pf[(2 + i) % PF]);
+    r2l_fl_fetch<U16>(a, img, r2l_mirror(R2L_NH(y0 - 2 + i), a.H), x0, le, re, lane, pf[(2 + i) % PF]);
 #define R2L_FL_STEP(K, y, LUMA, OUT)                                                                    \
   {                                                                                                     \
     r2l_fl_convert<U16>(a, F, pf[(K) % PF], le, re, st.v[((K) + 2) % 3], st.xp[((K) + 2) % 3]);                      \
-    r2l_fl_fetch<U16>(a, img, r2l_mirror((y) + 2 + PF, a.H), x0, le, re, lane, pf[(K) % PF]);           \
+    r2l_fl_fetch<U16>(a, img, r2l_mirror(R2L_NH((y) + 2 + PF), a.H), x0, le, re, lane, pf[(K) % PF]);           \
     r2l_fl_step<K, LUMA, OUT>(a, st, y, le, re, in_w && (y) < y1, ypb, x0);                             \
   }
   R2L_FL_STEP(2, y0 - 4, false, false)

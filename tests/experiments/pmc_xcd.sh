@@ -7,7 +7,7 @@ ROOT=$PWD
 M=${1:-0}
 OUT=$ROOT/gpurun_out/${2:-pmc_xcd_$M}
 rm -rf $OUT; mkdir -p $OUT
-export R2L_LIB_PATH=$ROOT/tests/_build/libr2l_isp_hooks.so
+export R2L_LIB_PATH=${LIB:-$ROOT/tests/_build/libr2l_isp_hooks.so}
 if [ "$M" != "0" ]; then export R2L_XCD_FS=${XFS:-$M} R2L_XCD_FA=${XFA:-$M} R2L_XCD_BP=${XBP:-$M} R2L_XCD_HB=${XHB:-$M} R2L_XCD_B2S=${XB2S:-$M}; fi
 run() { n=$1; shift; (cd /tmp && R2L_BENCH_PREROLL_S=0 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $ROOT/bench.py --steps 3 --warmup 1 --quick --no-roofline > $OUT/$n.log 2>&1); }
 run tcc1 FETCH_SIZE
