@@ -121,9 +121,15 @@ typedef float4 r2l_f4;
 typedef float2 r2l_f2;
 // v_log_f32 / v_exp_f32 are base-2 and 1 ULP; inputs here are >= 1e-5 (or exactly 0) so the
 // denormal pre-scaling of logf()/expf() is not needed.  v_rcp_f32 is 1 ULP.
+#ifdef R2L_EXP_NO_TRANS  // DIAGNOSTIC BUILDS, TIMING ONLY (results are wrong): one multiply instead of each transcendental
+R2L_HD float r2l_log2(float x) { return x * 1.0001f; }
+R2L_HD float r2l_exp2(float x) { return x * 0.9999f; }
+R2L_HD float r2l_rcp(float x) { return x * 1.0002f; }
+#else
 R2L_HD float r2l_log2(float x) { return __builtin_amdgcn_logf(x); }
 R2L_HD float r2l_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 R2L_HD float r2l_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
 // value of the previous / next lane of the 64-lane wavefront (DPP wave shifts; lane 0 / 63 keep their own)
 #ifdef R2L_HAVE_LANE_SHIFTS_OFF  // A/B builds: every lane loads its neighbour columns
 #define R2L_HAVE_LANE_SHIFTS false
