@@ -53,6 +53,29 @@ def build_lockstep():
     return LOCKSTEP_LIB
 
 
+HOST_CHECK_SRC = os.path.join(REPO, 'tests', 'abi_host', 'r2l_host_check.c')
+HOST_CHECK = os.path.join(REPO, 'tests', '_build', 'r2l_host_check')
+
+
+def build_host_check():
+    """gcc -std=c11 build of the plain-C consumer of include/r2l_isp.h (tests/abi_host/r2l_host_check.c): the header compiles as C,
+    the gfx950 library links from C, and -- on the GPU box -- a host with no Python and no torch drives a training step and a
+    static chain (tests/test_gpu_abi_host.py).  The library is found relative to the executable ($ORIGIN): the tree travels."""
+    from raw2logit_amd import _lib
+    lib = _lib.build_device_library()
+    deps = [HOST_CHECK_SRC, os.path.join(REPO, 'include', 'r2l_isp.h'), lib]
+    if os.path.exists(HOST_CHECK) and all(os.path.getmtime(HOST_CHECK) >= os.path.getmtime(d) for d in deps):
+        return HOST_CHECK
+    os.makedirs(os.path.dirname(HOST_CHECK), exist_ok=True)
+    tmp = HOST_CHECK + f'.{os.getpid()}.tmp'
+    subprocess.run(['gcc', '-std=c11', '-O1', '-Wall', '-Wextra', '-Werror', '-I' + os.path.join(REPO, 'include'),
+                    '-isystem', '/opt/rocm/include', '-D__HIP_PLATFORM_AMD__', HOST_CHECK_SRC, '-o', tmp,
+                    '-L' + os.path.dirname(lib), '-lr2l_isp', '-L/opt/rocm/lib', '-lamdhip64', '-lm',
+                    '-Wl,-rpath,$ORIGIN/../../raw2logit_amd', '-Wl,-rpath,/opt/rocm/lib'], check=True)
+    os.replace(tmp, HOST_CHECK)
+    return HOST_CHECK
+
+
 HOOKS_LIB = os.path.join(REPO, 'tests', '_build', 'libr2l_isp_hooks.so')
 
 

@@ -100,3 +100,18 @@ def test_camera_constants_match_the_oracle():
     for mine, ref in ((cameras.DRONE, orc.DRONE_CAMERA_PARAMS), (cameras.MICROSCOPY, orc.MICROSCOPY_CAMERA_PARAMS),
                       (cameras.IDENTITY, orc.DEFAULT_CAMERA_PARAMS)):
         assert [list(map(float, p)) for p in mine] == [list(map(float, p)) for p in ref]
+
+
+def test_header_is_valid_c_and_the_library_links_from_c():
+    """include/r2l_isp.h through a C11 compiler with -Wall -Wextra -Werror, the gfx950 library linked from plain C
+    (tests/abi_host/r2l_host_check.c: the torch-free consumer tests/test_gpu_abi_host.py runs on the GPU); `--abi` needs no GPU"""
+    import subprocess
+    import conftest
+    exe = conftest.build_host_check()
+    r = subprocess.run([exe, '--abi'], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.split() == ['abi', '1', 'device_build', '1'], r.stdout + r.stderr
+    # no Python, no torch, no C++ runtime among what the executable itself needs
+    needed = subprocess.run(['readelf', '-d', exe], capture_output=True, text=True).stdout
+    libs = re.findall(r'\(NEEDED\)\s+Shared library: \[([^\]]+)\]', needed)
+    assert 'libr2l_isp.so' in libs and 'libamdhip64.so' in ' '.join(libs), libs
+    assert not any('python' in x or 'torch' in x or 'stdc++' in x for x in libs), libs
