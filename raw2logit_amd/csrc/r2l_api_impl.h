@@ -738,7 +738,7 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
     fa.yp_out = (flags & (R2L_F_KEEP_LUMA | R2L_F_SPLIT_STATS)) ? ws.yp : nullptr;
     fa.yp_in = nullptr;
 #ifdef R2L_EXP_STAMPS
-    fa.tl = nullptr;
+    fa.tl = r2l_env_int("R2L_TL_STREAM", 0) ? (unsigned long long*)ws.debug : nullptr;  // (tests/timeline_fwd.py)
 #endif
     fa.stat_partial = stats ? ws.part_small : nullptr;
     fa.B = B;

@@ -364,7 +364,11 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
   // ---- strip edges: Y(q) (1 column each side) and Y'(q-2) (2 columns each side) ------------------------------
   float* ypq2 = st.yp[(K + 4) % 6];  // Y'(q-2): own columns in [2..5], neighbours still missing
   float rl_y = 0.f, rl_p2 = 0.f, rl_p3 = 0.f, rr_y = 0.f, rr_p0 = 0.f, rr_p1 = 0.f;
+#ifdef R2L_EXP_NO_FS_EXCH  // (timing-only ablation: no strip-edge exchange at all)
+  constexpr bool EXCH = false;
+#else
   constexpr bool EXCH = NW > 1;
+#endif
   if (EXCH) {
     float* mine = ex + ((q & 1) * NW + wave) * R2L_FS_EX;
     if (lane == 0) {
@@ -400,7 +404,9 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
   }
   if (EXCH) {
     float* mine = ex + ((q & 1) * NW + wave) * R2L_FS_EX;
+#ifndef R2L_EXP_NO_FS_BARRIER  // (timing-only ablation: the strip edges read whatever the neighbour wrote last)
     R2L_LDS_BARRIER();
+#endif
     if (lane == 0 && wave > 0) {
       const float* o = mine - R2L_FS_EX;
       rl_y = o[3];
@@ -610,6 +616,9 @@ R2L_BLOCKFN void r2l_fs_stats_finish(const R2LFwdStreamArgs& a_, int bid, int nb
 template <int NW, bool U16, bool EPI = false, bool SONLY = false>
 R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nblk, float* lds) {
   constexpr int NT = NW * 64;
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+  const unsigned long long tls0_ = __builtin_amdgcn_s_memrealtime();
+#endif
   // (wave: a scalar; lane: the hardware's lane id, re-derived wherever it is needed -- the thread id the kernel was handed
   // in v0 would otherwise stay live across the row loop, which has no register to spare: 28 B of scratch in round 4)
   // (the statistics instantiation only: in the others the same change ADDS 20 B of scratch)
@@ -651,6 +660,11 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
   }
   constexpr int PF = R2L_FS_PF;
   static_assert(6 % PF == 0, "the prefetch ring is indexed by the unroll position");
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+  // diagnostic builds (tests/timeline_fwd.py, R2L_TL_STREAM=1): s_memrealtime at the workgroup's entry, in front of its item loop,
+  // behind it, and behind the statistics' tail -- 4 records per workgroup at tl[4 * bid]
+  const unsigned long long tls1_ = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int item = r2l_xcd_window(bid, nblk, a.xcdm); item < a.nitems; item += nblk) {
     const int band = item % a.nband, b = item / a.nband;
     const int y0 = band * a.band_h;
@@ -693,6 +707,14 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
         r2l_fs_fetch_bf<U16>(a, img, r2l_mirror(R2L_NH(rr), a.H), x0, le, re, lane, pf[i]);
       }
       const int nsteps = q1 - qf;
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+      // (diagnostic builds: the time every step of a few sampled workgroups ends, tl[8192 + 64 * (bid / 128) + step])
+#define R2L_FS_STEP_STAMP(s_)                                                                     \
+  if (a.tl && (bid & 127) == 5 && bid < 2048 && (s_) < 64 && wave == 0 && r2l_lane_id() == 0)      \
+    a.tl[8192 + 64 * (bid >> 7) + (s_)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define R2L_FS_STEP_STAMP(s_)
+#endif
       for (int sb = 0; sb < nsteps; sb += 6) {
         R2L_PROGRESS_PRIO(sb, nsteps);
 #define R2L_FS_STEP(K)                                                                                          \
@@ -705,6 +727,7 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     }                                                                                                           \
     r2l_fs_step<NW, U16, K, EPI, (K + 1) & 1, true>(a, st, q, y0, y1, le, re, wave, lane, ex, fifo,             \
                                                    SONLY ? nullptr : ob, ypb, plane, x0, store_ok, mean, istd, smask); \
+    R2L_FS_STEP_STAMP(sb + K)                                                                                   \
   }
         R2L_FS_STEP(0)
         R2L_FS_STEP(1)
@@ -777,10 +800,21 @@ R2L_BLOCKFN void r2l_fwd_stream_block(const R2LFwdStreamArgs& a, int bid, int nb
     if (NW > 1) R2L_LDS_BARRIER();  // exchange buffers free for the next item
     if (SONLY || a.stat_partial) r2l_fs_lane_sums(st.acc, st.piv, store_ok ? 4.0 * (double)(y1 - y0) : 0.0, store_ok, lane, tots);
   }
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+  const unsigned long long tls2_ = __builtin_amdgcn_s_memrealtime();
+#endif
   if (SONLY || a.stat_partial) {
     const int tid = SONLY ? wave * 64 + r2l_lane_id() : (int)threadIdx.x;
     r2l_fs_stats_finish<NW, NT>(a, bid, nblk, tid, wave, tots, red);
   }
+#if defined(R2L_EXP_STAMPS) && !defined(R2L_EMUL)
+  if (a.tl && bid < 2048 && wave == 0 && r2l_lane_id() == 0) {
+    a.tl[4 * bid] = tls0_;
+    a.tl[4 * bid + 1] = tls1_;
+    a.tl[4 * bid + 2] = tls2_;
+    a.tl[4 * bid + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ================================================================================================

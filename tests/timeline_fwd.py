@@ -20,6 +20,26 @@ lib.cdll.r2l_test_debug_offset.restype = ctypes.c_size_t
 off = lib.cdll.r2l_test_debug_offset(B, H, W)
 tl = y.grad_fn.ws[off:off + 8 * 24576].view(torch.int64).cpu()
 hw = y.grad_fn.ws[off + 8 * 24576:off + 8 * (24576 + 4096)].view(torch.int64).cpu()
+if os.environ.get('R2L_TL_STREAM'):
+    # the row-streaming statistics pass: entry / item loop begins / item loop ends / tail done, per workgroup (4 records at 4 * bid)
+    d = tl[:8192].view(-1, 4)
+    d = d[(d[:, 3] > 0) & (d[:, 3] - d[:, 0] < 100000000)]
+    d = d[d[:, 0] > d[:, 0].max() - 100000]
+    t00 = d[:, 0].min().item()
+    r = (d - t00).double() / 100
+    qq = torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)
+    print(f'streaming statistics pass: {len(d)} workgroups (us after the first workgroup\'s entry; min / 10 % / median / 90 % / max)')
+    for j, nm in enumerate(('entry', 'item loop begins', 'item loop ends', 'tail done')):
+        print(f'   {nm:18s}', [round(x, 2) for x in r[:, j].quantile(qq).tolist()])
+    print('   item loop duration', [round(x, 2) for x in (r[:, 2] - r[:, 1]).quantile(qq).tolist()],
+          ' tail duration', [round(x, 2) for x in (r[:, 3] - r[:, 2]).quantile(qq).tolist()])
+    ps = tl[8192:8192 + 64 * 16].view(16, 64)
+    for w in range(16):
+        row = ps[w][ps[w] > 0]
+        if len(row) > 3:
+            dt = ((row[1:] - row[:-1]).double() / 100).tolist()
+            print(f'   sampled workgroup {5 + 128 * w}: us per step', ' '.join(f'{x:.2f}' for x in dt))
+    tl[:8192] = 0
 t0 = None
 for k, name in enumerate(('luma', 'stats', 'apply')):
     d = tl[8192 * k:8192 * (k + 1)].view(-1, 2)
