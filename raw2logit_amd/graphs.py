@@ -83,8 +83,14 @@ class StepGraph:
             gc.collect()
             gc_was_on = gc.isenabled()
             gc.disable()
+            # With collectives in the step the capture must not be of the GLOBAL kind: the process group's watchdog thread polls the
+            # events of the warm-up's collectives (hipEventQuery, every ~100 ms, until it has seen each of them complete) -- under a
+            # global-mode capture that query from ANOTHER thread is "not permitted when stream is capturing", the watchdog thread
+            # throws and the process aborts (seen in 1 of ~6 runs of bench.py's graph trial, round 5).  Thread-local mode restricts
+            # the capturing thread only; torch does not hand the collectives issued DURING a capture to the watchdog.
+            mode = 'thread_local' if self._collectives else 'global'
             try:
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode=mode):
                     self.out = self._step()
             finally:
                 if gc_was_on:
