@@ -2,7 +2,7 @@
 the parity checks of the GPU suite on host memory, served by tests/_build/libr2l_lockstep.so -- every kernel in its device form,
 one host thread per lane, built with -fsanitize=address,undefined (tests/emul/r2l_lockstep_rt.h).
 
-    python tests/lockstep_checks.py <library> [group ...]        groups: planes shapes stream passes static canary
+    python tests/lockstep_checks.py <library> [group ...]        groups: planes shapes stream passes static canary [fuzz]
 
 Prints one line per check; exit code 0 only if every check passed (AddressSanitizer aborts the process at the first bad access;
 UBSan reports are fatal through UBSAN_OPTIONS=halt_on_error=1)."""
@@ -119,6 +119,36 @@ def main():
                     run(f'guard zones + poison, plane passes {H}x{W} u16={u16}',
                         lambda: ga.run_both('cpu', tc._step_bytes(2, H, W), tc._param_step('cpu', 2, H, W, True, u16, seed=50 + n,
                                                                                            kind='scene'), f'{H}x{W}'))
+    if 'fuzz' in groups:
+        # random frame shapes and band heights for a time budget (not part of the default run: R2L_LOCKSTEP_FUZZ_S seconds, SEED):
+        # the plane passes / streaming forward at shapes nobody listed, every access under ASan, every result against the oracle
+        rng = np.random.default_rng(int(os.environ.get('SEED', '1')))
+        t_end = time.time() + float(os.environ.get('R2L_LOCKSTEP_FUZZ_S', '120'))
+        n = 0
+        while time.time() < t_end:
+            n += 1
+            B = int(rng.integers(1, 4))
+            H = 2 * int(rng.integers(2, 24))
+            W = 4 * int(rng.integers(1, 70)) if rng.random() < 0.8 else int(rng.choice([260, 508, 512, 516, 772, 1028]))
+            bands = {k: 6 * int(rng.integers(1, 5)) for k in ('R2L_BP_BAND', 'R2L_HB_BAND', 'R2L_B2S_BAND', 'R2L_HP_BAND', 'R2L_FA_BAND',
+                                                              'R2L_FL_BAND', 'R2L_FST_BAND')}
+            bands['R2L_FS_BAND'] = 2 * int(rng.integers(2, 16))
+            if rng.random() < 0.3:
+                bands = {}
+            kind = rng.random()
+            with env(R2L_BWD_PLANES=1, **bands):
+                if kind < 0.6:
+                    run(f'fuzz {n}: plane passes {B}x{H}x{W} {bands}',
+                        lambda: pc.check_frame_shapes('cpu', shapes=[(H, W)], B=B, conditioning=True), PLANE_KERNELS)
+                elif kind < 0.8:
+                    # (the apply pass against the streaming forward, bit for bit.  NOT the plane passes against the tile kernels at
+                    # 2e-4 of the scale: on frames of 4-8 rows under BatchNorm two correct float32 evaluations differ by more -- the
+                    # float32 oracle is 2.4e-4 from its float64 run on 3x4x772 -- and check_frame_shapes judges against the oracle)
+                    run(f'fuzz {n}: apply pass on the kept luma plane {B}x{H}x{W} {bands}',
+                        lambda: tg.test_apply_pass_reads_the_luma_plane_the_statistics_pass_kept((B, H, W), 'cpu'), ('r2l_launch_fwd_apply',))
+                else:
+                    run(f'fuzz {n}: static luma chains {B}x{H}x{W}',
+                        lambda: tg.test_static_luma_chain_streaming_kernel((B, H, W), 'cpu'), ('r2l_launch_static_chain',))
     bad = [n for n, ok in results if not ok]
     print(f'{len(results) - len(bad)} of {len(results)} lock-step checks passed' + (': FAILED ' + '; '.join(bad) if bad else ''), flush=True)
     sys.exit(1 if bad else 0)

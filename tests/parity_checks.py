@@ -594,11 +594,12 @@ def check_frame_shapes(device, shapes=FRAME_SHAPES, B=2, conditioning=False):
             glo, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=1e-6)
             ghi, _, _ = orc.parametrized_backward(Pm, cache, cot, clip_shift=-1e-6)
             g32 = None
-            if conditioning and bn:
+            if conditioning:
                 # float32 conditioning of the case, measured: the same formulas evaluated in float32 by the oracle (what the
                 # reference's own arithmetic does) against their float64 run -- on frames of a few hundred pixels the
                 # BatchNorm backward cancels so far that this, not 3e-5 of the scale, is what a correct float32 kernel can
-                # reach (the fixed 1e-7 * cot.size below is a guess at the same thing)
+                # reach (the fixed 1e-7 * cot.size below is a guess at the same thing); without BatchNorm it is small but not
+                # nothing for a gradient whose terms cancel
                 _, _, c32 = orc.parametrized_forward(raw_np, P.astype(np.float32), bn=obn)
                 g32, _, _ = orc.parametrized_backward(P.astype(np.float32), c32, cot)
             assert cache['rgb'].min() > 0.05 and cache['rgb'].max() < 0.95, (cache['rgb'].min(), cache['rgb'].max())
@@ -613,6 +614,10 @@ def check_frame_shapes(device, shapes=FRAME_SHAPES, B=2, conditioning=False):
                     lim += 1e-7 * cot.size
                 if g32 is not None:
                     lim += 2 * np.abs(np.asarray(g32[k], dtype=np.float64).reshape(ref.shape) - ref).max()
+                    # ... and the random walk of the float32 roundings of cot.size terms of magnitude <= ~1/4 each: a gradient whose
+                    # terms cancel (gamma_correct under a random cotangent: |ref| 2e-3 from terms summing to 400 in magnitude) has no
+                    # 3e-5 of ITSELF to spend (random frame shapes on the lock-step emulation, round 5: 1e-6 absolute on 34x16)
+                    lim += 7e-8 * np.sqrt(cot.size)
                 worst = max(worst, np.abs(got - ref).max() / lim)
                 assert np.abs(got - ref).max() <= lim, (H, W, bn, k, np.abs(got - ref).max(), lim)
     return worst
