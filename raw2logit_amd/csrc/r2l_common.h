@@ -72,6 +72,7 @@ R2L_HD float r2l_rcp(float x) { return 1.0f / x; }
 R2L_HD r2l_f4 r2l_stream_load_f4(const float* p) { return *(const r2l_f4*)p; }
 R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& v) { *(r2l_f4*)p = v; }
 R2L_HD r2l_f4 r2l_load_f4_nt(const float* p) { return *(const r2l_f4*)p; }
+R2L_HD void r2l_store_f4_nt(float* p, const r2l_f4& v) { *(r2l_f4*)p = v; }
 #ifdef R2L_SERIAL
 // the serial emulation runs one lane at a time: kernels take their every-lane-loads form there
 #define R2L_HAVE_LANE_SHIFTS false
@@ -157,8 +158,11 @@ R2L_HD float r2l_row_shl1(float x, float edge) {
 }
 // Touched-once streams (a frame read once, an output written once) can take the nontemporal policy.  A pure
 // 4 B : 12 B copy of the static chain's shape gains 5 % from it (tests/probes/stream_probe.hip: 5.2 -> 5.5-5.7
-// TB/s); the kernels themselves do not (profiles/r01_e_static_ab.txt), so both switches are OFF by default:
-// -DR2L_NT_LOADS / -DR2L_NT_STORES build the nontemporal forms for A/B runs.
+// TB/s).  Round 1's tile kernels did not (profiles/r01_e_static_ab.txt); the row-streaming kernels do, for their
+// STORES (round 5, same buffers, interleaved: bilinear 767 -> 758 us, Malvar2004 830 -> 810, default luma chain 941 -> 927,
+// Malvar2004 + median 1084 -> 1050-1073; profiles/r05_nt_stores.txt), and lose 9-22 % with nontemporal LOADS (the halo rows a
+// neighbouring band re-reads must stay cached): stores nontemporal by default (-DR2L_NT_STORES=0: plain), loads plain
+// (-DR2L_NT_LOADS: the A/B form).
 typedef float r2l_v4 __attribute__((ext_vector_type(4)));
 R2L_HD r2l_f4 r2l_stream_load_f4(const float* p) {
 #ifndef R2L_NT_LOADS
@@ -183,8 +187,20 @@ R2L_HD r2l_f4 r2l_load_f4_nt(const float* p) {
   o.w = v.w;
   return o;
 }
-R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& s) {
+// a 16-byte store around the caches (nontemporal): for planes written once and read much later, or not by this step at all
+R2L_HD void r2l_store_f4_nt(float* p, const r2l_f4& s) {
+  r2l_v4 v;
+  v.x = s.x;
+  v.y = s.y;
+  v.z = s.z;
+  v.w = s.w;
+  __builtin_nontemporal_store(v, (r2l_v4*)p);
+}
 #ifndef R2L_NT_STORES
+#define R2L_NT_STORES 1
+#endif
+R2L_HD void r2l_stream_store_f4(float* p, const r2l_f4& s) {
+#if !R2L_NT_STORES
   *(r2l_f4*)p = s;
 #else
   r2l_v4 v;

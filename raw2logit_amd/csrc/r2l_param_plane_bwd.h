@@ -184,7 +184,11 @@ R2L_HD void r2l_bp_step(const R2LBwd1Args& a, R2LBpState& st, R2LBpAcc& A, const
     s4.y = gy2[0][1];
     s4.z = gy2[1][0];
     s4.w = gy2[1][1];
+#ifdef R2L_EXP_GY_NT
+    r2l_store_f4_nt(gyb + (unsigned)y * (unsigned)a.W + (unsigned)x0, s4);
+#else
     *(r2l_f4*)(gyb + (unsigned)y * (unsigned)a.W + (unsigned)x0) = s4;
+#endif
   }
   // ---- folded chroma stencils of this row's parity ----------------------------------------------------------------------
   const float* rows[3] = {vu, vm, vl};
@@ -597,7 +601,11 @@ R2L_HD void r2l_hp_step(const ArgsT& a, const float gw[6][8], int q, bool le, bo
     s4.y = h1;
     s4.z = h2;
     s4.w = h3;
+#ifdef R2L_EXP_HP_NT
+    r2l_store_f4_nt(hpb + (unsigned)q * (unsigned)a.W + (unsigned)x0, s4);
+#else
     *(r2l_f4*)(hpb + (unsigned)q * (unsigned)a.W + (unsigned)x0) = s4;
+#endif
   }
 }
 #ifndef R2L_HP_PF
@@ -755,7 +763,11 @@ R2L_HD void r2l_hb_step(const R2LBwd1Args& a, const float gw[6][8], r2l_p2 blur[
     s4.y = h1;
     s4.z = h2;
     s4.w = h3;
+#ifdef R2L_EXP_HP_NT
+    r2l_store_f4_nt(hpb + (unsigned)q * (unsigned)a.W + (unsigned)x0, s4);
+#else
     *(r2l_f4*)(hpb + (unsigned)q * (unsigned)a.W + (unsigned)x0) = s4;
+#endif
   }
 }
 #ifndef R2L_HB_OCC

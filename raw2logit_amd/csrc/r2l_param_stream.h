@@ -271,6 +271,9 @@ R2L_HD void r2l_fs_stencil_plain(const float* r0, const float* r1, const float* 
 // lane's pivot], [BatchNorm], store (EPI: at the augmented position, R2LEpi)
 // STATS: 0 none; 1 the streaming kernel's form (under `a.stat_partial && store_ok`); 2 branch-free, weighted with smask
 // (1 for the pixels that count, 0 for the others), the pivot taken in the band's first row (`first`)
+#ifndef R2L_OUT_NT
+#define R2L_OUT_NT 1
+#endif
 template <bool EPI, int STATS>
 R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc, float* piv, const r2l_p2 ypp[2],
                           const r2l_p2 u[2], const r2l_p2 v[2], int y, int y0, int x0, float* ob, unsigned plane,
@@ -313,18 +316,34 @@ R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc
       s4.z = x[1][0];
       s4.w = x[1][1];
       if (!EPI) {
+        // the output goes AROUND the caches (nontemporal): 12 B/px that this pass never reads again would otherwise push the raw
+        // frames and Y' -- which the neighbouring bands and the backward re-read -- out of the memory-side cache: apply pass
+        // 72.8 -> 64.9 us at 64x512x512, bn_reduce (which reads the output later) +0.5 (profiles/r05_nt_stores.txt;
+        // -DR2L_OUT_NT=0: the plain store).  The kept planes Y', dL/dY'', HP stay cached: their readers follow at once.
+#if R2L_OUT_NT
+        r2l_store_f4_nt(ob + (unsigned)k * plane + off0, s4);
+#else
         *(r2l_f4*)(ob + (unsigned)k * plane + off0) = s4;
+#endif
       } else {  // the augmented position of this lane's 4 pixels (R2LEpi)
         float* o = ob + (unsigned)k * plane + (a.ep.s0 + a.ep.sr * y + a.ep.sc * x0);
         if (a.ep.sc == 1) {
+#if R2L_OUT_NT
+          r2l_store_f4_nt(o, s4);
+#else
           *(r2l_f4*)o = s4;
+#endif
         } else if (a.ep.sc == -1) {
           r2l_f4 r4;
           r4.x = s4.w;
           r4.y = s4.z;
           r4.z = s4.y;
           r4.w = s4.x;
+#if R2L_OUT_NT
+          r2l_store_f4_nt(o - 3, r4);
+#else
           *(r2l_f4*)(o - 3) = r4;
+#endif
         } else {
           o[0] = s4.x;
           o[a.ep.sc] = s4.y;
@@ -501,7 +520,11 @@ R2L_HD void r2l_fs_step(const R2LFwdStreamArgs& a, R2LFsState& st, int q, int y0
       s4.y = ypy[3];
       s4.z = ypy[4];
       s4.w = ypy[5];
+#ifdef R2L_EXP_YP_NT
+      r2l_store_f4_nt(ypb + off0, s4);
+#else
       *(r2l_f4*)(ypb + off0) = s4;
+#endif
     }
   }
   // rows of Y' that lie outside the image only ever meet zero weights, but must stay finite

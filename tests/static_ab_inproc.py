@@ -10,6 +10,7 @@ for a in sys.argv[1:]:
     k, v = a.split('=')
     libs[k] = os.path.join(HERE, '_build', v) if not os.path.isabs(v) else v
 deb = int(os.environ.get('DEB', '0'))
+sharp, den = int(os.environ.get('SHARP', '0')), int(os.environ.get('DENOISE', '0'))   # (1, 1: the train.py default chain)
 B, S = 256, 1024
 dev = torch.device('cuda', 0)
 n = B * S * S
@@ -31,7 +32,7 @@ def run(f, reps=10):
     ts = []
     for r in range(reps):
         e0.record()
-        rc = f(raw.data_ptr(), out.data_ptr(), B, S, S, cam, deb, 0, 0, 2.2, None, 0, stream)
+        rc = f(raw.data_ptr(), out.data_ptr(), B, S, S, cam, deb, sharp, den, 2.2, None, 0, stream)
         e1.record(); torch.cuda.synchronize()
         assert rc == 0
         if r >= 2: ts.append(e0.elapsed_time(e1) * 1e3)
@@ -53,7 +54,7 @@ for (k, b), v in res.items():
 ref = None
 for k, f in fns.items():
     out.fill_(-7.0)
-    assert f(raw.data_ptr(), out.data_ptr(), B, S, S, cam, deb, 0, 0, 2.2, None, 0, stream) == 0
+    assert f(raw.data_ptr(), out.data_ptr(), B, S, S, cam, deb, sharp, den, 2.2, None, 0, stream) == 0
     torch.cuda.synchronize()
     if ref is None:
         ref = out.clone()
