@@ -46,6 +46,30 @@
 struct R2LBpStage {  // grad_out of one row in flight: 3 channels x the lane's 4 pixels
   r2l_f4 g[3];
 };
+// The LAST reader of a kept plane may take it around the caches (nontemporal loads), so that what it leaves in the 256 MiB memory-side
+// cache is what the next passes want (profiles/r05_nt_stores.txt, 64x512x512, alternating processes):
+//   HP in the sums pass (the step's last kernel): the NEXT step's apply pass 63.5 -> 60.1 us, blur pass 43.3 -> 41.5, statistics -0.9
+//     -- 67 MB less dead weight in the cache when the forward starts.  ADOPTED (R2L_B2S_HP_NT 1).
+//   dL/dY'' in the blur pass, Y' in the blur pass, the raw frames in the sums pass: nothing, nothing, +1 us.  Switches kept for A/B runs.
+#ifndef R2L_B2S_HP_NT
+#define R2L_B2S_HP_NT 1
+#endif
+#ifdef R2L_EXP_HB_GY_NT
+#define R2L_HB_GY_LOAD(p) r2l_load_f4_nt(p)
+#else
+#define R2L_HB_GY_LOAD(p) r2l_stream_load_f4(p)
+#endif
+#ifndef R2L_HB_YP_NT
+#define R2L_HB_YP_NT false   // Y' in the blur pass (its last reader)
+#endif
+#ifndef R2L_B2S_RAW_NT
+#define R2L_B2S_RAW_NT false  // the raw frames in the sums pass (their last reader in the step)
+#endif
+#if R2L_B2S_HP_NT
+#define R2L_B2S_HP_LOAD(p) r2l_load_f4_nt(p)
+#else
+#define R2L_B2S_HP_LOAD(p) r2l_stream_load_f4(p)
+#endif
 template <bool EPI>
 R2L_HD void r2l_bp_fetch_g(const float* gimg, unsigned plane, int y, int H, int W, int x0, const R2LEpi& ep,
                            R2LBpStage& s) {
@@ -474,13 +498,13 @@ R2L_BLOCKFN void r2l_bwd1_blur_block(const R2LBwd1Args& a, int bid, int nblk, fl
     R2LBbStage pfg[PF];  // dL/dY'' row q
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < PF; ++i) {
-      r2l_fa_fetch(ypimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
+      r2l_fa_fetch<R2L_HB_YP_NT>(ypimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
       const int yc = (y0 + i < a.H) ? y0 + i : a.H - 1;
-      pfg[i % PF].g = r2l_stream_load_f4(gimg + (size_t)yc * a.W + x0);
+      pfg[i % PF].g = R2L_HB_GY_LOAD(gimg + (size_t)yc * a.W + x0);
     }
 #define R2L_BB_LOAD_STEP(K, q)                                                                          \
   r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, yp[((K) + 2) % 6]);          \
-  r2l_fa_fetch(ypimg, R2L_NH((q) + 2 + PF), a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);
+  r2l_fa_fetch<R2L_HB_YP_NT>(ypimg, R2L_NH((q) + 2 + PF), a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);
     R2L_BB_LOAD_STEP(2, y0 - 4)
     R2L_BB_LOAD_STEP(3, y0 - 3)
     R2L_BB_LOAD_STEP(4, y0 - 2)
@@ -495,7 +519,7 @@ R2L_BLOCKFN void r2l_bwd1_blur_block(const R2LBwd1Args& a, int bid, int nblk, fl
     const R2LBbStage g_ = pfg[(K) % PF];                                                                \
     {                                                                                                   \
       const int yc = (q + PF < a.H) ? q + PF : a.H - 1;                                                 \
-      pfg[(K) % PF].g = r2l_stream_load_f4(gimg + (size_t)yc * a.W + x0);                               \
+      pfg[(K) % PF].g = R2L_HB_GY_LOAD(gimg + (size_t)yc * a.W + x0);                               \
     }                                                                                                   \
     if (r2l_opaque_true()) r2l_bb_step<K>(a, yp, blur, g_, q, in_w && q < y1);                          \
   }
@@ -858,7 +882,7 @@ R2L_HD void r2l_b2s_fetch_hp(const float* hpimg, int r, int H, int W, int x0, bo
   const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);
   const float* p = hpimg + (size_t)rc * W + x0;
   const int eo = (lane < 32) ? (le ? 0 : -1) : (re ? 3 : 4);
-  s.c = r2l_stream_load_f4(p);
+  s.c = R2L_B2S_HP_LOAD(p);
   s.e = p[eo];
 }
 // staged row -> 6 values, columns x0-1 .. x0+4, zero outside the image (the sharpen's zero padding has no adjoint there)
@@ -1098,13 +1122,13 @@ R2L_BLOCKFN void r2l_bwd2_sums_block(const R2LBwd2Args& a, int bid, int nblk_lau
     // row finishes the sharpen-weight sums of that row.
     R2L_PRAGMA_UNROLL
     for (int i = 0; i < PF; ++i) {
-      r2l_fl_fetch<U16>(sa, img, r2l_mirror(R2L_NH(y0 - 2 + i), a.H), x0, le, re, lane, pf[(3 + i) % PF]);
+      r2l_fl_fetch<U16, R2L_B2S_RAW_NT>(sa, img, r2l_mirror(R2L_NH(y0 - 2 + i), a.H), x0, le, re, lane, pf[(3 + i) % PF]);
       r2l_b2s_fetch_hp(hpimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfh[(3 + i) % PF]);
     }
 #define R2L_B2S_LOAD_STEP(K, t)                                                                               \
   r2l_fl_convert<U16>(sa, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3], st.xp[((K) + 1) % 3]);                \
   r2l_b2s_build_hp(pfh[(K) % PF], (unsigned)((t) + 1) < (unsigned)a.H, le, re, st.hp[((K) + 1) % 3]);         \
-  r2l_fl_fetch<U16>(sa, img, r2l_mirror(R2L_NH((t) + 1 + PF), a.H), x0, le, re, lane, pf[(K) % PF]);                  \
+  r2l_fl_fetch<U16, R2L_B2S_RAW_NT>(sa, img, r2l_mirror(R2L_NH((t) + 1 + PF), a.H), x0, le, re, lane, pf[(K) % PF]);                  \
   r2l_b2s_fetch_hp(hpimg, R2L_NH((t) + 1 + PF), a.H, a.W, x0, le, re, lane, pfh[(K) % PF]);
     R2L_B2S_LOAD_STEP(3, y0 - 3)
     R2L_B2S_LOAD_STEP(4, y0 - 2)

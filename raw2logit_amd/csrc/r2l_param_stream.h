@@ -880,11 +880,14 @@ R2L_HD void r2l_fa_fetch_raw(const R2LFwdStreamArgs& a, size_t img0, int ym, int
     s.e = r[eo];
   }
 }
+// NT: the caller is the LAST reader of this plane in the step -- the row goes around the caches (the edge pair, which the neighbouring
+// strip's wavefront also loads as part of its row, stays a plain load)
+template <bool NT = false>
 R2L_HD void r2l_fa_fetch(const float* ypimg, int r, int H, int W, int x0, bool le, bool re, int lane, R2LFaStage& s) {
   const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);  // rows outside the image are zeroed when the row is built
   const float* p = ypimg + (size_t)rc * W + x0;
   const int eo = (lane < 32) ? (le ? 0 : -2) : (re ? 2 : 4);
-  s.c = r2l_stream_load_f4(p);
+  s.c = NT ? r2l_load_f4_nt(p) : r2l_stream_load_f4(p);
   s.e = *(const r2l_f2*)(p + eo);
 }
 // staged row -> 8 values, columns x0-2 .. x0+5 (mirror padding of the blur at the image edges, :165 reflect)
@@ -1073,7 +1076,7 @@ struct R2LFlStage {
   r2l_f2 e;  // columns (x0-2, x0-1) in the first half of the wavefront, (x0+4, x0+5) in the second: (even, odd)
   int ym;
 };
-template <bool U16>
+template <bool U16, bool NT = false>
 R2L_HD void r2l_fl_fetch(const R2LFwdStreamArgs& a, size_t img0, int ym, int x0, bool le, bool re, int lane,
                          R2LFlStage& s) {
   const size_t e = img0 + (size_t)ym * a.W + x0;
@@ -1087,7 +1090,7 @@ R2L_HD void r2l_fl_fetch(const R2LFwdStreamArgs& a, size_t img0, int ym, int x0,
     s.e.x = *(const float*)(r + eo);  // two 16-bit values
   } else {
     const float* r = a.raw.f32 + e;
-    s.c = r2l_stream_load_f4(r);
+    s.c = NT ? r2l_load_f4_nt(r) : r2l_stream_load_f4(r);
     s.e = *(const r2l_f2*)(r + eo);
   }
 }
