@@ -55,6 +55,7 @@ ALGO_BYTES_PER_PX = (
     ('r2l_launch_bwd1', 20.0),       # tile kernels: raw 4 + grad_out 12 in, dL/dY'' 4 out
     ('r2l_launch_bwd2', 8.0),        # raw 4 + dL/dY'' 4 in
     ('r2l_launch_bn_reduce', 24.0),  # grad_out 12 + saved output 12 in
+    ('r2l_launch_bnr_planes', 20.0),  # the same sums with xhat recomputed: grad_out 12 + raw 4 + Y' 4 in
 )
 
 

@@ -338,6 +338,18 @@ R2L_KERNEL_NT_LDS(r2l_launch_bwd1_blur_hp, R2LBwd1Args, R2L_BP_NT, R2L_BP_RED_FL
 R2L_KERNEL_NT_LDS(r2l_launch_bwd2_hp, R2LBwd2Args, R2L_BP_NT, 4, 4, r2l_bwd2_hp_block)
 R2L_KERNEL_NT_LDS(r2l_launch_bwd2_sums, R2LBwd2Args, R2L_B2S_NT, R2L_B2S_LDS_FLOATS, 3, r2l_bwd2_sums_block<false>)
 R2L_KERNEL_NT_LDS(r2l_launch_bwd2_sums_u16, R2LBwd2Args, R2L_B2S_NT, R2L_B2S_LDS_FLOATS, 3, r2l_bwd2_sums_block<true>)
+// BatchNorm's backward sums from the raw frame, Y' and grad_out (xhat recomputed, the output not read back): r2l_bnr_planes_block
+#ifndef R2L_BNR_OCC
+#define R2L_BNR_OCC 3
+#endif
+#define R2L_BNR_NWV 4
+#define R2L_BNR_KERNEL(name, U16, EPI)                                                                          \
+  R2L_KERNEL_NT_LDS(name, R2LBnrArgs, 64 * R2L_BNR_NWV, R2L_FA_LDS_FLOATS(R2L_BNR_NWV, true), R2L_BNR_OCC,      \
+                    r2l_bnr_planes_block<U16, EPI, R2L_BNR_NWV>)
+R2L_BNR_KERNEL(r2l_launch_bnr_planes, false, false)
+R2L_BNR_KERNEL(r2l_launch_bnr_planes_u16, true, false)
+R2L_BNR_KERNEL(r2l_launch_bnr_planes_epi, false, true)
+R2L_BNR_KERNEL(r2l_launch_bnr_planes_epi_u16, true, true)
 #endif
 R2L_KERNEL_V(r2l_launch_bwd2, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bwd2_block<GBwd2, false>)
 R2L_KERNEL_V(r2l_launch_fwd_u16, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, true>)
@@ -1214,6 +1226,58 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
                           workspace_bytes, B, H, W,
                           R2L_F_FOLDED_VALID | keep | (bn_mode == R2L_BN_TRAIN ? R2L_F_LUMA_VALID : 0), stream, nullptr, &ep);
 }
+// BatchNorm's backward sums of a step whose forward kept Y' (R2L_F_KEEP_LUMA on the row-streaming path): recomputed from the raw
+// frame and Y' (r2l_bnr_planes_block) where the plane passes run, i.e. on batches of >= 4 Mi px -- the forward's output is then
+// not read at all by the backward.  Returns 1 when it did not run (the caller falls back to r2l_bn_bwd_reduce).
+static int r2l_bn_bwd_reduce_planes(const R2LRaw& raw, const float* additive, const float* grad_out, const R2LWorkspace& ws,
+                                    const R2LEpi& ep, float* bn_bwd, int B, int H, int W, int keep, void* stream) {
+#ifdef R2L_SERIAL
+  (void)raw; (void)additive; (void)grad_out; (void)ws; (void)ep; (void)bn_bwd; (void)B; (void)H; (void)W; (void)keep; (void)stream;
+  return 1;
+#else
+  const bool planes = r2l_env_int("R2L_BWD_PLANES", 0) || (size_t)B * H * W >= ((size_t)4 << 20);
+  if (!keep || !r2l_fwd_streams(additive, W) || !planes || r2l_env_int("R2L_BNR_READ_OUT", 0) ||
+      (r2l_env_int("R2L_EXP_NO_TREE", 0) & 2))
+    return 1;
+  R2LBnrArgs a;
+  a.s.raw = raw;
+  a.s.F = ws.folded;
+  a.s.bn = ws.bn;
+  a.s.out = nullptr;
+  a.s.yp_out = nullptr;
+  a.s.yp_in = ws.yp;
+#ifdef R2L_EXP_STAMPS
+  a.s.tl = nullptr;
+#endif
+  a.s.stat_partial = ws.part_small;
+  a.s.B = B;
+  a.s.H = H;
+  a.s.W = W;
+  // (band height as kernel B1's: 36 rows at 64x512x512 -- 61.4 us against 63.2 at 24 rows, 71-73 at 12 / 18 / 30, 68.4 at 48)
+  a.s.band_h = r2l_band_rows(B, H, W, 256L * 4 * 2, "R2L_BNR_BAND");
+  a.s.nband = (H + a.s.band_h - 1) / a.s.band_h;
+  const long nstrip = (W + 255) / 256;
+  const long items = (long)B * a.s.nband * nstrip;
+  if (items > (1L << 30)) return r2l_fail(-1, "r2l_isp_step_bwd: batch too large");
+  a.s.nitems = (int)items;
+  a.s.tree = R2LTree{ws.part_small, nullptr, ws.gpartial, ws.counters, 12, 0};
+  a.s.stats_out = nullptr;
+  a.s.fin.bn = nullptr;
+  a.s.ep = ep.on ? ep : R2LEpi{0, 0, 0, 0};
+  a.s.xcdm = 0;
+  a.gout = grad_out;
+  a.sums = ws.bsums;
+  a.totals = ws.moments;
+  a.bn_bwd = bn_bwd;
+  long g = (items + R2L_BNR_NWV - 1) / R2L_BNR_NWV;
+  const long gcap = r2l_env_int("R2L_GRID_BNR", R2L_MAX_BLOCKS);
+  if (g > gcap) g = gcap;
+  if (g > R2L_MAX_BLOCKS) g = R2L_MAX_BLOCKS;
+  return ep.on ? (raw.u16 ? r2l_launch_bnr_planes_epi_u16(a, (int)g, stream) : r2l_launch_bnr_planes_epi(a, (int)g, stream))
+               : (raw.u16 ? r2l_launch_bnr_planes_u16(a, (int)g, stream) : r2l_launch_bnr_planes(a, (int)g, stream));
+#endif
+}
+
 int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* additive, const float* grad_out,
                      const float* out, float* grad_params, float* grad_additive, int bn_mode, void* workspace,
                      size_t workspace_bytes, int B, int H, int W, int nranks, int phase,
@@ -1239,9 +1303,11 @@ int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* add
   const float* bn = bn_mode == R2L_BN_NONE ? nullptr : ws.bn;
   const float* bn_bwd = bn_mode == R2L_BN_TRAIN ? ws.bn_bwd : nullptr;
   if (bn_mode == R2L_BN_TRAIN && phase != R2L_STEP_B) {
-    if (int e = r2l_bn_bwd_reduce(grad_out, out, ws.moments, ws.bsums, phase == R2L_STEP_ALL ? ws.bn_bwd : nullptr,
-                                  workspace, workspace_bytes, B, H, W, R2L_F_FOLDED_VALID, stream))
-      return e;
+    float* means = phase == R2L_STEP_ALL ? ws.bn_bwd : nullptr;
+    int e = r2l_bn_bwd_reduce_planes(rw, additive, grad_out, ws, ep, means, B, H, W, keep, stream);
+    if (e == 1) e = r2l_bn_bwd_reduce(grad_out, out, ws.moments, ws.bsums, means, workspace, workspace_bytes, B, H, W,
+                                      R2L_F_FOLDED_VALID, stream);
+    if (e) return e;
     if (phase == R2L_STEP_A) return 0;
   }
   if (phase == R2L_STEP_B) {

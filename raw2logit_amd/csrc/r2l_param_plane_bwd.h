@@ -89,6 +89,150 @@ R2L_HD void r2l_bp_fetch_g(const float* gimg, unsigned plane, int y, int H, int 
 #endif
 }
 
+// ================================================================================================
+// BatchNorm's backward sums WITHOUT reading the forward's output back (round 5).  sum_c g and sum_c g * xhat need xhat, the
+// normalised output -- 12 B/px that the apply pass wrote around the caches and that, in training, left them long before the
+// backward starts.  The raw frame (4 B/px) and the kept plane Y' (4 B/px) determine it: this pass walks them exactly like the
+// apply pass (r2l_fa_step: chroma stencils, blur of Y', colour code, the same functions on the same numbers -- xhat is the
+// apply pass's stored value bit for bit), reads grad_out once (nontemporal) and keeps six sums per lane.  HBM traffic 20 B/px
+// instead of 24, 12 of them -- grad_out -- from memory, the rest out of the memory-side cache when the forward just ran:
+// 66 -> 4x us at 64x512x512 (profiles/r05_bnr_recompute.txt).  Kernel B1 recomputes the forward from the same two planes.
+// Reduction: per band the lanes' float32 pair sums -> float64, butterfly over the wavefront in a fixed order, added to the
+// wavefront's float64 totals in LDS; per workgroup (high, low) float32 halves of the six totals -> the shared tree
+// (12 slots, as the statistics pass: r2l_fs_stats_finish).
+struct R2LBnrArgs {
+  R2LFwdStreamArgs s;    // raw, F, bn (mean, 1/std), yp_in, B, H, W, nband, band_h, nitems, stat_partial, tree, ep, xcdm
+  const float* gout;
+  double* sums;          // [6]
+  const double* totals;  // optional: totals[6] = pixel count n of the global batch
+  float* bn_bwd;         // optional (needs totals): sums / n as float32
+};
+R2L_HD void r2l_bnr_lane_sums(const r2l_p2* acc, bool ok, int lane, double* tots) {
+  double part[6];
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 6; ++k) {
+    double v = ok ? (double)acc[k][0] + (double)acc[k][1] : 0.0;  // (lanes beyond the frame's last column computed nothing real)
+    R2L_PRAGMA_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    part[k] = v;
+  }
+  if (lane == 0) {
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 6; ++i) tots[i] += part[i];
+  }
+}
+template <bool U16, bool EPI>
+R2L_HD void r2l_bnr_item(const R2LBnrArgs& ba, int item, int lane, const float mean[3], const float istd[3], double* tots) {
+  const R2LFwdStreamArgs& a = ba.s;
+  R2LFoldedRef F = R2L_FOLDED_REF(a.F);
+  const int nstrip = (a.W + 255) >> 8;
+  const unsigned plane = (unsigned)a.H * (unsigned)a.W;
+  const int strip = item % nstrip, ib = item / nstrip;
+  const int band = ib % a.nband, b = ib / a.nband;
+  const int xs = strip * 256 + 4 * lane;
+  const bool in_w = xs < a.W;
+  const int x0 = in_w ? xs : a.W - 4;
+  const bool le = x0 == 0, re = x0 + 4 >= a.W;
+  const int y0 = band * a.band_h;  // a multiple of 6 (the host rounds band_h)
+  const int y1 = (y0 + a.band_h < a.H) ? y0 + a.band_h : a.H;
+  const size_t img = (size_t)b * plane;
+  const float* ypimg = a.yp_in + img;
+  const float* gimg = ba.gout + (size_t)b * 3 * plane;
+  R2LFaState st;
+  r2l_p2 acc[6];
+  float piv[3] = {0.5f, 0.5f, 0.5f};  // (unused by this mode)
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < 6; ++i) acc[i] = r2l_splat2(0.f);
+  constexpr int PF = R2L_FA_PF;
+  R2LFsStage pf[PF];   // raw row q + 1
+  R2LFaStage pfy[PF];  // Y' row q + 2
+  R2LBpStage pfg[PF];  // grad_out row q
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i) {
+    r2l_fa_fetch_raw<U16>(a, img, r2l_mirror(R2L_NH(y0 - 3 + i), a.H), x0, le, re, lane, pf[(2 + i) % PF]);
+    r2l_fa_fetch(ypimg, R2L_NH(y0 - 2 + i), a.H, a.W, x0, le, re, lane, pfy[(2 + i) % PF]);
+  }
+#define R2L_BNR_LOAD_STEP(K, q)                                                                          \
+  {                                                                                                      \
+    r2l_fs_convert<U16>(a, F, pf[(K) % PF], le, re, st.v[((K) + 1) % 3]);                                \
+    r2l_fa_build(pfy[(K) % PF], (unsigned)((q) + 2) < (unsigned)a.H, le, re, st.yp[((K) + 2) % 6]);      \
+    r2l_fa_fetch_raw<U16>(a, img, r2l_mirror(R2L_NH((q) + 1 + PF), a.H), x0, le, re, lane, pf[(K) % PF]); \
+    r2l_fa_fetch(ypimg, R2L_NH((q) + 2 + PF), a.H, a.W, x0, le, re, lane, pfy[(K) % PF]);                \
+  }
+  R2L_BNR_LOAD_STEP(2, y0 - 4)
+  R2L_BNR_LOAD_STEP(3, y0 - 3)
+  R2L_BNR_LOAD_STEP(4, y0 - 2)
+  R2L_BNR_LOAD_STEP(5, y0 - 1)
+  R2L_PRAGMA_UNROLL
+  for (int i = 0; i < PF; ++i) r2l_bp_fetch_g<EPI>(gimg, plane, y0 + i, a.H, a.W, x0, a.ep, pfg[i % PF]);
+  for (int qb = y0; qb < y1; qb += 6) {
+    R2L_PROGRESS_PRIO(qb - y0, y1 - y0);
+#define R2L_BNR_STEP(K)                                                                                   \
+  {                                                                                                       \
+    const int q = qb + K;                                                                                 \
+    R2L_BNR_LOAD_STEP(K, q)                                                                               \
+    r2l_p2 gk[3][2];                                                                                      \
+    R2L_PRAGMA_UNROLL                                                                                     \
+    for (int k = 0; k < 3; ++k) {                                                                         \
+      gk[k][0] = r2l_mk2(pfg[K % PF].g[k].x, pfg[K % PF].g[k].y);                                         \
+      gk[k][1] = r2l_mk2(pfg[K % PF].g[k].z, pfg[K % PF].g[k].w);                                         \
+    }                                                                                                     \
+    r2l_bp_fetch_g<EPI>(gimg, plane, q + PF, a.H, a.W, x0, a.ep, pfg[K % PF]); /* (rows past H: clamped, never counted) */ \
+    if (r2l_opaque_true())                                                                                \
+      r2l_fa_step<K, false, false, true>(a, st, acc, piv, q, y0, false, nullptr, plane, x0, mean, istd, gk, \
+                                          q < y1 ? 1.f : 0.f);                                            \
+  }
+    R2L_BNR_STEP(0)
+    R2L_BNR_STEP(1)
+    R2L_BNR_STEP(2)
+    R2L_BNR_STEP(3)
+    R2L_BNR_STEP(4)
+    R2L_BNR_STEP(5)
+#undef R2L_BNR_STEP
+  }
+#undef R2L_BNR_LOAD_STEP
+  r2l_bnr_lane_sums(acc, in_w, lane, tots);
+}
+template <bool U16, bool EPI, int NWV>
+R2L_BLOCKFN void r2l_bnr_planes_block(const R2LBnrArgs& ba, int bid, int nblk, float* lds) {
+  const R2LFwdStreamArgs& a = ba.s;
+  constexpr int NT = NWV * 64;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  float mean[3], istd[3];
+  R2L_PRAGMA_UNROLL
+  for (int k = 0; k < 3; ++k) {
+    mean[k] = a.bn[k];
+    istd[k] = a.bn[3 + k];
+  }
+  float* red = lds + 16;
+  double* tots = (double*)(lds + 16 + R2L_FS_RED_FLOATS(NWV)) + wave * 6;
+  if (lane < 6) tots[lane] = 0.0;
+  R2L_PRAGMA_NOUNROLL
+  for (int item = r2l_xcd_window(bid, nblk, a.xcdm) * NWV + wave; item < a.nitems; item += nblk * NWV)
+    r2l_bnr_item<U16, EPI>(ba, item, lane, mean, istd, tots);
+  // ---- the wavefronts' float64 totals -> (high, low) float32 halves per workgroup -> the shared tree (as r2l_fs_stats_finish)
+  R2L_LDS_BARRIER();
+  if (tid < 6) {
+    double acc = 0.0;
+    for (int w = 0; w < NWV; ++w) acc += (tots - wave * 6)[w * 6 + tid];
+    const float hi = (float)acc;
+    r2l_store_coherent(&a.stat_partial[(size_t)tid * nblk + bid], hi);
+    r2l_store_coherent(&a.stat_partial[(size_t)(6 + tid) * nblk + bid], (float)(acc - (double)hi));
+  }
+  R2L_STORES_DONE();
+  R2L_LDS_BARRIER();
+  double* sl = (double*)(red + 4);
+  if (a.tree.counters &&
+      r2l_tree_finish<12, NT>(a.tree, bid, nblk, red, sl, (double*)(red + 512), (R2L_FS_RED_FLOATS(NWV) - 512) / 2)) {
+    if (tid < 6) sl[tid] += sl[6 + tid];
+    R2L_LDS_BARRIER();
+    if (tid < 6) {
+      ba.sums[tid] = sl[tid];
+      if (ba.bn_bwd && ba.totals) ba.bn_bwd[tid] = (float)(sl[tid] / ba.totals[6]);
+    }
+  }
+}
+
 struct R2LBpState {
   float v[3][6];   // V rows (slot = row mod 3)
   float yp[6][8];  // Y' rows (slot = row mod 6)

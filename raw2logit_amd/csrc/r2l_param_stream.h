@@ -270,7 +270,8 @@ R2L_HD void r2l_fs_stencil_plain(const float* r0, const float* r1, const float* 
 // the colour code of one output row (:203-217): Y'', U, V of the lane's 4 pixels -> RGB, clip, gamma, [statistics about the
 // lane's pivot], [BatchNorm], store (EPI: at the augmented position, R2LEpi)
 // STATS: 0 none; 1 the streaming kernel's form (under `a.stat_partial && store_ok`); 2 branch-free, weighted with smask
-// (1 for the pixels that count, 0 for the others), the pivot taken in the band's first row (`first`)
+// (1 for the pixels that count, 0 for the others), the pivot taken in the band's first row (`first`); 3 the sums of BatchNorm's
+// backward over grad_out (gk: this row's grad_out as pairs)
 #ifndef R2L_OUT_NT
 #define R2L_OUT_NT 1
 #endif
@@ -278,7 +279,7 @@ template <bool EPI, int STATS>
 R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc, float* piv, const r2l_p2 ypp[2],
                           const r2l_p2 u[2], const r2l_p2 v[2], int y, int y0, int x0, float* ob, unsigned plane,
                           bool store_ok, const float mean[3], const float istd[3], float smask = 0.f,
-                          bool first = false) {
+                          bool first = false, const r2l_p2 (*gk)[2] = nullptr) {
   const unsigned off0 = (unsigned)y * (unsigned)a.W + (unsigned)x0;
   R2L_PRAGMA_UNROLL
   for (int k = 0; k < 3; ++k) {
@@ -297,6 +298,15 @@ R2L_HD void r2l_fs_colour(const R2LFwdStreamArgs& a, R2LFoldedRef F, r2l_p2* acc
         const r2l_p2 d = r2l_padd(x[p], r2l_splat2(-piv[k]));
         acc[k] = r2l_padd(acc[k], d);
         acc[3 + k] = r2l_pfma(d, d, acc[3 + k]);
+      }
+      if (STATS == 3) {
+        // BatchNorm's backward sums (:217 backward): sum g and sum g * xhat, xhat = the value the apply pass stored -- the same
+        // expression on the same numbers -- RECOMPUTED from the raw frame and Y' instead of read back (r2l_bnr_planes_block);
+        // smask: the wave-uniform 1 / 0 of the row (lanes beyond the frame are taken out once, after the band)
+        const r2l_p2 xh = r2l_pmul(r2l_padd(x[p], r2l_splat2(-mean[k])), r2l_splat2(istd[k]));
+        const r2l_p2 t = r2l_pmul(gk[k][p], r2l_splat2(smask));
+        acc[k] = r2l_padd(acc[k], t);
+        acc[3 + k] = r2l_pfma(t, xh, acc[3 + k]);
       }
       if (STATS == 2) {
         if (p == 0) piv[k] = first ? x[0][0] : piv[k];
@@ -918,12 +928,13 @@ struct R2LFaState {
   float v[3][6];   // V rows (slot = row mod 3)
   float yp[6][8];  // Y' rows (slot = row mod 6)
 };
-template <int K, bool EPI, bool STATS>
+template <int K, bool EPI, bool STATS, bool BNR = false>
 R2L_HD void r2l_fa_step(const R2LFwdStreamArgs& a, R2LFaState& st, r2l_p2* acc, float* piv, int y, int y0,
-                        bool store_ok, float* ob, unsigned plane, int x0, const float mean[3], const float istd[3]) {
+                        bool store_ok, float* ob, unsigned plane, int x0, const float mean[3], const float istd[3],
+                        const r2l_p2 (*gk)[2] = nullptr, float rowf = 0.f) {
   // (the weights of one section at a time: chroma, blur, colour code -- r2l_opaque_after)
   // the previous step's last result (STATS: there is no store to end a step with) / this step's newest window value
-  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, STATS ? acc[5][1] : st.yp[(K + 2) % 6][2]));
+  R2LFoldedRef F = R2L_FOLDED_REF(r2l_opaque_after(a.F, (STATS || BNR) ? acc[5][1] : st.yp[(K + 2) % 6][2]));
   constexpr int PY = K & 1;
   const int H = a.H;
   const float* vu = st.v[(K + 2) % 3];  // V(y-1)
@@ -950,8 +961,11 @@ R2L_HD void r2l_fa_step(const R2LFwdStreamArgs& a, R2LFaState& st, r2l_p2* acc, 
     r2l_blur_row2w(yw, w25, ypp);
   }
   R2LFoldedRef Fc = R2L_FOLDED_REF(r2l_opaque_after(a.F, ypp[1][1]));
-  r2l_fs_colour<EPI, STATS ? 2 : 0>(a, Fc, acc, piv, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd,
-                                    store_ok ? 1.f : 0.f, K == 0 && y == y0);
+  if (BNR)
+    r2l_fs_colour<false, 3>(a, Fc, acc, piv, ypp, u, v, y, y0, x0, nullptr, plane, false, mean, istd, rowf, false, gk);
+  else
+    r2l_fs_colour<EPI, STATS ? 2 : 0>(a, Fc, acc, piv, ypp, u, v, y, y0, x0, ob, plane, store_ok, mean, istd,
+                                      store_ok ? 1.f : 0.f, K == 0 && y == y0);
 }
 
 #ifndef R2L_FA_PF
