@@ -1227,7 +1227,7 @@ int r2l_isp_step_fwd(const void* raw, int raw_u16, float denom, const float* con
                           R2L_F_FOLDED_VALID | keep | (bn_mode == R2L_BN_TRAIN ? R2L_F_LUMA_VALID : 0), stream, nullptr, &ep);
 }
 // BatchNorm's backward sums of a step whose forward kept Y' (R2L_F_KEEP_LUMA on the row-streaming path): recomputed from the raw
-// frame and Y' (r2l_bnr_planes_block) where the plane passes run, i.e. on batches of >= 4 Mi px -- the forward's output is then
+// frame and Y' (r2l_bnr_planes_block) on batches of >= 6 Mi px where the plane passes run -- the forward's output is then
 // not read at all by the backward.  Returns 1 when it did not run (the caller falls back to r2l_bn_bwd_reduce).
 static int r2l_bn_bwd_reduce_planes(const R2LRaw& raw, const float* additive, const float* grad_out, const R2LWorkspace& ws,
                                     const R2LEpi& ep, float* bn_bwd, int B, int H, int W, int keep, void* stream) {
@@ -1235,7 +1235,9 @@ static int r2l_bn_bwd_reduce_planes(const R2LRaw& raw, const float* additive, co
   (void)raw; (void)additive; (void)grad_out; (void)ws; (void)ep; (void)bn_bwd; (void)B; (void)H; (void)W; (void)keep; (void)stream;
   return 1;
 #else
-  const bool planes = r2l_env_int("R2L_BWD_PLANES", 0) || (size_t)B * H * W >= ((size_t)4 << 20);
+  // (from 6 Mi px: at 64x256x256 = 4 Mi px the whole step, output included, lives in the memory-side cache and reading the output back
+  //  is cheaper than recomputing it -- bn_reduce 22.4-23.8 us against 27.1; at 128x256x256 37.2 against 37.5, the step 2 % faster)
+  const bool planes = r2l_env_int("R2L_BWD_PLANES", 0) || (size_t)B * H * W >= ((size_t)6 << 20);
   if (!keep || !r2l_fwd_streams(additive, W) || !planes || r2l_env_int("R2L_BNR_READ_OUT", 0) ||
       (r2l_env_int("R2L_EXP_NO_TREE", 0) & 2))
     return 1;
