@@ -784,12 +784,18 @@ def test_backward_kernels_as_passes_over_planes(shape, dev):
                 worst = max(worst, e / lim)
                 assert e <= lim, (shape, bn, env, frames, n, e, lim)
         pc.report(f'bwd1-planes/{shape}/bn={bn}/all gradients vs tile kernel (fraction of 2e-4 relative)', worst, 1.0)
-        if not bn:   # the output epilogue through the plane pass's fetch: the same sums from the same numbers, bit for bit
-            plain = run({}, 'f32')
-            for epilogue in ((True, False, 0), (False, True, 2)) + (((True, True, 1),) if H == W else ()):
-                ge = run({}, 'f32', epilogue)
-                for n in plain:
-                    assert np.array_equal(ge[n], plain[n]), (shape, epilogue, n)
+        # the output epilogue through the plane passes' fetch of grad_out: the same sums from the same numbers, bit for bit -- with
+        # train-mode BatchNorm too since its backward sums are a plane pass (r2l_bnr_planes_block reads grad_out through the same
+        # affine map as kernel B1; round 5.  bn_reduce, which it replaces here, walked the augmented tensors in memory order)
+        plain = run({}, 'f32')
+        for epilogue in ((True, False, 0), (False, True, 2)) + (((True, True, 1),) if H == W else ()):
+            ge = run({}, 'f32', epilogue)
+            for n in plain:
+                assert np.array_equal(ge[n], plain[n]), (shape, bn, epilogue, n)
+        if bn:       # ... and 16-bit frames through the epilogue form (r2l_launch_bnr_planes_epi_u16)
+            plain16, ge16 = run({}, 'u16'), run({}, 'u16', (True, False, 0))
+            for n in plain16:
+                assert np.array_equal(ge16[n], plain16[n]), (shape, 'u16', n)
 
 
 @pytest.mark.parametrize('shape', [(2, 70, 520), (1, 40, 1028), (1, 36, 2048), (3, 66, 260), (1, 200, 256),
