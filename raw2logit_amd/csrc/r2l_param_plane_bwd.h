@@ -100,6 +100,9 @@ R2L_HD void r2l_bp_fetch_g(const float* gimg, unsigned plane, int y, int H, int 
 // Reduction: per band the lanes' float32 pair sums -> float64, butterfly over the wavefront in a fixed order, added to the
 // wavefront's float64 totals in LDS; per workgroup (high, low) float32 halves of the six totals -> the shared tree
 // (12 slots, as the statistics pass: r2l_fs_stats_finish).
+#ifndef R2L_BNR_PF
+#define R2L_BNR_PF 2  // rows in flight per stream (raw, Y', grad_out): 3 takes the kernel past 168 registers
+#endif
 struct R2LBnrArgs {
   R2LFwdStreamArgs s;    // raw, F, bn (mean, 1/std), yp_in, B, H, W, nband, band_h, nitems, stat_partial, tree, ep, xcdm
   const float* gout;
@@ -143,7 +146,7 @@ R2L_HD void r2l_bnr_item(const R2LBnrArgs& ba, int item, int lane, const float m
   float piv[3] = {0.5f, 0.5f, 0.5f};  // (unused by this mode)
   R2L_PRAGMA_UNROLL
   for (int i = 0; i < 6; ++i) acc[i] = r2l_splat2(0.f);
-  constexpr int PF = R2L_FA_PF;
+  constexpr int PF = R2L_BNR_PF;
   R2LFsStage pf[PF];   // raw row q + 1
   R2LFaStage pfy[PF];  // Y' row q + 2
   R2LBpStage pfg[PF];  // grad_out row q

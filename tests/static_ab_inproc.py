@@ -11,7 +11,7 @@ for a in sys.argv[1:]:
     libs[k] = os.path.join(HERE, '_build', v) if not os.path.isabs(v) else v
 deb = int(os.environ.get('DEB', '0'))
 sharp, den = int(os.environ.get('SHARP', '0')), int(os.environ.get('DENOISE', '0'))   # (1, 1: the train.py default chain)
-B, S = 256, 1024
+B, S = int(os.environ.get('B', '256')), int(os.environ.get('S', '1024'))
 dev = torch.device('cuda', 0)
 n = B * S * S
 raw = torch.randint(0, 4096, (n,), device=dev, dtype=torch.int32).to(torch.float32) / 4095.0
