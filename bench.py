@@ -38,43 +38,84 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # several ranks: capture + agreement + timing of the graph trial, or the eager line goes out (the environment variable: tests)
+WATCHDOG_EXIT = 17             # exit code of a process whose graph-trial watchdog fired (never 0 on a hang)
 GRAPH_TRIAL_TIMEOUT_S = float(os.environ.get('R2L_BENCH_TRIAL_TIMEOUT_S', '180'))
 PREROLL_S = float(os.environ.get('R2L_BENCH_PREROLL_S', '0.3'))   # untimed pre-roll of the step before the W warm-up steps
                                # (GPU clocks, see main(); counter-collection runs of the profiling scripts set 0)
-# algorithmic HBM bytes per raw pixel of each kernel family, by kernel-name prefix; the
-# `_u16` instantiations (16-bit containers) read 2 B/px less raw
+# Bytes per raw pixel of each kernel family, by kernel-name prefix: (prefix, DESIGN bytes, SURVEY.md section 8d pass,
+# section 8d ALGORITHMIC bytes).  `roofline.achieved` / `frac` use the ALGORITHMIC figure of the section-8d pass the kernel
+# belongs to (what an ideal split would move: stats 4; forward main 4 + 12; reduction pass 12 + 4; backward main pass 12 + 4);
+# the DESIGN figure -- what this kernel moves by construction, kept planes included -- goes to
+# `design_bytes_per_px` / `design_frac` beside it.  The `_u16` instantiations (16-bit containers) read 2 B/px less raw.
+# The luma path's adjoint passes (bwd1_blur*, bwd2_*) exist only because this design splits the backward main pass: section
+# 8d gives them no bytes of their own (None) -- they can never be the roofline's kernel, their time is in `step_roofline`.
 ALGO_BYTES_PER_PX = (
-    ('r2l_launch_fwd_apply', 20.0),  # apply pass on the kept luma plane: raw 4 + Y' 4 in, RGB 12 out
-    ('r2l_launch_fwd', 16.0),        # raw 4 in, RGB 12 out (the stats-only pass reads 4, writes 0 -- or Y', 4, when the
-                                     # backward / the apply pass will read it); tile or row-streaming
-    ('r2l_launch_bwd1_plane', 24.0),  # plane pass of kernel B1: raw 4 + Y' 4 + grad_out 12 in, dL/dY'' 4 out
-    ('r2l_launch_bwd1_blur_hp', 12.0),  # B1's second pass + B2's first in one: dL/dY'' 4 + Y' 4 in, the blur's adjoint 4 out
-    ('r2l_launch_bwd1_blur', 8.0),   # its second pass (blur-weight sums): dL/dY'' 4 + Y' 4 in
-    ('r2l_launch_bwd2_hp', 8.0),     # plane passes of kernel B2: dL/dY'' 4 in, the blur's adjoint 4 out ...
-    ('r2l_launch_bwd2_sums', 8.0),   # ... that plane 4 + raw 4 in
-    ('r2l_launch_bwd1', 20.0),       # tile kernels: raw 4 + grad_out 12 in, dL/dY'' 4 out
-    ('r2l_launch_bwd2', 8.0),        # raw 4 + dL/dY'' 4 in
-    ('r2l_launch_bn_reduce', 24.0),  # grad_out 12 + saved output 12 in
-    ('r2l_launch_bnr_planes', 20.0),  # the same sums with xhat recomputed: grad_out 12 + raw 4 + Y' 4 in
+    ('r2l_launch_fwd_apply', 20.0, 'forward main pass', 16.0),   # apply pass on the kept luma plane: raw 4 + Y' 4 in, RGB 12 out
+    ('r2l_launch_fwd', 16.0, 'forward main pass', 16.0),         # raw 4 in, RGB 12 out; the stats-only pass: see pass_bytes()
+    ('r2l_launch_bwd1_plane', 24.0, 'backward main pass', 16.0),  # raw 4 + Y' 4 + grad_out 12 in, dL/dY'' 4 out
+    ('r2l_launch_bwd_luma', 16.0, 'backward main pass (luma adjoints)', None),  # dL/dY'' 4 + Y' 4 + raw 4 in (+ HP through LDS)
+    ('r2l_launch_bwd1_blur_hp', 12.0, 'backward main pass (luma adjoints)', None),  # dL/dY'' 4 + Y' 4 in, the blur's adjoint 4 out
+    ('r2l_launch_bwd1_blur', 8.0, 'backward main pass (luma adjoints)', None),      # blur-weight sums: dL/dY'' 4 + Y' 4 in
+    ('r2l_launch_bwd2_hp', 8.0, 'backward main pass (luma adjoints)', None),        # dL/dY'' 4 in, the blur's adjoint 4 out ...
+    ('r2l_launch_bwd2_sums', 8.0, 'backward main pass (luma adjoints)', None),      # ... that plane 4 + raw 4 in
+    ('r2l_launch_bwd1', 20.0, 'backward main pass', 16.0),       # tile kernels: raw 4 + grad_out 12 in, dL/dY'' 4 out
+    ('r2l_launch_bwd2', 8.0, 'backward main pass (luma adjoints)', None),           # raw 4 + dL/dY'' 4 in
+    ('r2l_launch_bn_reduce', 24.0, 'reduction pass', 16.0),      # grad_out 12 + saved output 12 in
+    ('r2l_launch_bnr_planes', 20.0, 'reduction pass', 16.0),     # the same sums with xhat recomputed: grad_out 12 + raw 4 + Y' 4 in
 )
 
 
-def algo_bytes_per_px(kernel):
-    for prefix, bpp in ALGO_BYTES_PER_PX:
-        if kernel.startswith(prefix):
-            return bpp - (2.0 if '_u16' in kernel and 'bn_reduce' not in kernel else 0.0)
+def _family(kernel):
+    for fam in ALGO_BYTES_PER_PX:
+        if kernel.startswith(fam[0]):
+            return fam
     return None
 
 
-PMC_PARAM = 'r05_pmc_traffic.json'
-PMC_STATIC = 'r05_pmc_traffic_static.json'      # all three static kernels of static_c3, this round's build
+def _u16_less(kernel):
+    return 2.0 if '_u16' in kernel and 'bn_reduce' not in kernel else 0.0
+
+
+def design_bytes_per_px(kernel):
+    """bytes per raw pixel this kernel moves by its own design (kept planes included), or None for kernels outside the table"""
+    fam = _family(kernel)
+    return None if fam is None else fam[1] - _u16_less(kernel)
+
+
+def algo_bytes_per_px(kernel):
+    """SURVEY.md section 8d's algorithmic bytes per raw pixel of the pass `kernel` belongs to (None: the pass has none of its own)"""
+    fam = _family(kernel)
+    return None if fam is None or fam[3] is None else fam[3] - _u16_less(kernel)
+
+
+def pass_bytes(kernel, launches_per_step, kernels):
+    """(section-8d pass name, algorithmic B/px, design B/px) of `kernel` as it runs in THIS step.  The streaming forward kernel
+    serves three roles: the train-mode statistics pass (section 8d: 4 B/px -- raw in; by design it also writes the kept luma
+    plane, 8), both passes of a step in one kernel name (average), or the single forward pass (16)."""
+    fam = _family(kernel)
+    algo, design = algo_bytes_per_px(kernel), design_bytes_per_px(kernel)
+    name = fam[2]
+    if kernel.startswith('r2l_launch_fwd') and not kernel.startswith('r2l_launch_fwd_apply'):
+        if launches_per_step == 2:
+            # two launches per step: stats-only (raw only) and apply (raw + 12 B/px out): average bytes
+            algo, design, name = (4.0 - _u16_less(kernel) + algo) / 2, ((design - 12.0) + design) / 2, 'statistics + forward main pass'
+        elif any(k.startswith('r2l_launch_fwd_apply') for k in kernels):
+            algo, design, name = 4.0 - _u16_less(kernel), design - 12.0 + 4.0, 'statistics pass'
+    return name, algo, design
+
+
+PMC_PARAM = 'r06_pmc_traffic.json'
+PMC_STATIC = 'r06_pmc_traffic_static.json'      # the three static kernels of static_c3
 
 
 def pmc_traffic(kernel, B, S, name=PMC_PARAM, shape=(64, 512)):
     """(HBM bytes per launch of `kernel`, where the number comes from).  PMC counters cannot be read inside a
     timed run, so this is NOT measured here: it is taken from the committed rocprofv3 --pmc passes (FETCH_SIZE /
     WRITE_SIZE in their own runs, gfx950 correction applied; profiles/<name>) and only for the workload shape
-    those passes were collected on (64x512x512 parametrized, 256x1024x1024 static); (None, reason) otherwise."""
+    those passes were collected on (64x512x512 parametrized, 256x1024x1024 static); (None, reason) otherwise.
+    The file says which build it was collected on (`_meta.library_digest`, written by the collecting script from
+    raw2logit_amd._lib.source_digest()); the source string reports that tag next to the digest of the sources this
+    process runs -- it is read, never asserted."""
     path = os.path.join(REPO, 'profiles', name)
     if (B, S) != shape:
         return None, f'no PMC profile for this shape (profiles/{name} covers {shape[0]}x{shape[1]}x{shape[1]})'
@@ -85,7 +126,23 @@ def pmc_traffic(kernel, B, S, name=PMC_PARAM, shape=(64, 512)):
     v = t.get(kernel, {}).get('total_bytes')
     if v is None:
         return None, f'profiles/{name} has no entry for {kernel}'
-    return v, f'committed rocprofv3 --pmc profile profiles/{name} (this round\'s build, same shape; not measured in this run)'
+    meta = t.get('_meta') or {}
+    tag = meta.get('library_digest')
+    try:
+        from raw2logit_amd import _lib
+        now = _lib.source_digest()
+    except Exception:                                # noqa: BLE001
+        now = None
+    if tag is None:
+        build = 'the file carries no build tag'
+    elif now is None:
+        build = f'collected on library sources {tag}'
+    elif tag == now:
+        build = f'collected on library sources {tag} = the sources of this run'
+    else:
+        build = f'collected on library sources {tag}; THIS run is built from {now} (kernels changed since: treat as indicative)'
+    return v, (f'committed rocprofv3 --pmc profile profiles/{name} ({meta.get("round", "round unknown")}, '
+               f'{meta.get("collected", "date unknown")}; {build}; same shape; not measured in this run)')
 
 
 def parse():
@@ -117,13 +174,15 @@ def parse():
                     help='replay the whole step as ONE HIP graph (raw2logit_amd/graphs.py: StepGraph): the step costs the '
                          'host one graph launch instead of two C-ABI calls + autograd; matters below ~8 Mpix per step, '
                          'where the host is the bound (single GPU)')
-    ap.add_argument('--graph-also', action='store_true', help='(accepted for compatibility: the graph trial is the default now)')
-    ap.add_argument('--no-graph-trial', action='store_true',
-                    help='several ranks over RCCL: skip the graph trial.  By default, after the eager measurement, the same '
-                         'data-parallel step is captured as ONE HIP graph with its collectives (raw2logit_amd/graphs.py) and '
-                         'timed the same way; the ranks agree on whether every capture succeeded, a watchdog prints the eager '
-                         'line and ends the process if the trial does not finish in time, and the faster of the two is the '
-                         "line's value (the other one is reported beside it)")
+    ap.add_argument('--graph-also', action='store_true', help='(accepted for compatibility; see --graph-trial)')
+    ap.add_argument('--no-graph-trial', action='store_true', help='(accepted for compatibility: the trial is opt-in since round 6)')
+    ap.add_argument('--graph-trial', action='store_true',
+                    help='several ranks over RCCL: after the eager measurement, capture the same data-parallel step as ONE HIP '
+                         'graph with its collectives (raw2logit_amd/graphs.py) and time it the same way; reported BESIDE the eager '
+                         "line's value.  OPT-IN: the capture of RCCL collectives has only ever run against a one-rank group on a "
+                         'one-GPU box, so the default N > 1 run does nothing that has not run before.  The ranks agree on whether '
+                         'every capture succeeded; a watchdog prints the eager line tagged `watchdog_fired` and ends the process '
+                         f'with exit code {WATCHDOG_EXIT} (every rank) if the trial does not finish in time')
     ap.add_argument('--no-small-shapes', action='store_true',
                     help="skip the small_shapes sub-records (the datasets' 256x256 tiles: BASELINE configs 4 / 5 per GPU)")
     ap.add_argument('--raw-u16', action='store_true',
@@ -676,25 +735,42 @@ def main():
         comm_us = F_.CommTimer.report() if group_on else None
         F_.CommTimer.enable(False)
 
+    passes = None
     if kernels:
+        # roofline: the kernel with the most time among those that ARE a section-8d pass, priced at that pass's algorithmic
+        # bytes (VERDICT r5 #1b); what the kernel moves by its own design sits beside it as design_*
         cand = {k: v for k, v in kernels.items() if algo_bytes_per_px(k) is not None}
         if cand:
             total = {k: v['launches'] * v['avg_us'] for k, v in cand.items()}
             dom = max(total, key=total.get)
             avg_us = cand[dom]['avg_us']
-            bpp = algo_bytes_per_px(dom)
-            if dom.startswith('r2l_launch_fwd') and not dom.startswith('r2l_launch_fwd_apply'):
-                if cand[dom]['launches'] == 2 * args.steps:
-                    # two launches per step: stats-only (raw only) and apply (raw + 12 B/px out): average bytes
-                    bpp = ((bpp - 12.0) + bpp) / 2
-                elif any(k.startswith('r2l_launch_fwd_apply') for k in cand):
-                    bpp = bpp - 12.0 + 4.0   # the statistics pass alone: raw in, the kept luma plane out
+            pname, bpp, dbpp = pass_bytes(dom, cand[dom]['launches'] // max(args.steps, 1), cand)
             achieved = B * S * S * bpp / (avg_us * 1e-6) / 1e9
+            design = B * S * S * dbpp / (avg_us * 1e-6) / 1e9
             traffic, source = pmc_traffic(dom, B, S) if not args.raw_u16 else \
                 (None, 'no PMC profile for 16-bit containers')
-            roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1),
+            roofline = {'bound': 'hbm', 'kernel': dom, 'pass': pname, 'achieved': round(achieved, 1),
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                        'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp}
+                        'traffic': traffic, 'traffic_source': source, 'avg_us': avg_us, 'algo_bytes_per_px': bpp,
+                        'algo_bytes_source': 'SURVEY.md section 8d, per pass',
+                        'design_bytes_per_px': dbpp, 'design_achieved': round(design, 1),
+                        'design_frac': round(design / HBM_PEAK_GBS, 4)}
+        # every section-8d pass of the step: its kernels' summed time against its algorithmic bytes
+        acc = {}
+        for k, v in kernels.items():
+            fam = _family(k)
+            if fam is None:
+                continue
+            name, algo, _ = pass_bytes(k, v['launches'] // max(args.steps, 1), kernels)
+            key = name.split(' (')[0]
+            a = acc.setdefault(key, {'us': 0.0, 'algo_bytes_per_px': 0.0, 'kernels': []})
+            a['us'] += v['launches'] * v['avg_us'] / max(args.steps, 1)
+            a['algo_bytes_per_px'] = max(a['algo_bytes_per_px'], algo or 0.0)
+            a['kernels'].append(k.replace('r2l_launch_', '').replace('_kernel', ''))
+        passes = [{'pass': n, 'kernels': a['kernels'], 'us_per_step': round(a['us'], 1),
+                   'algo_bytes_per_px': a['algo_bytes_per_px'],
+                   'frac': round(B * S * S * a['algo_bytes_per_px'] / (a['us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                  for n, a in acc.items() if a['us'] > 0]
 
     graph_ms = graph_err = graph_local_ms = graph_local_err = None
     static_c3 = small = None
@@ -740,6 +816,8 @@ def main():
             'step_roofline': {'algo_bytes_per_px': 52.0, 'achieved': round(px_per_step / world * 52.0 / (ms * 1e-3) / 1e9, 1),
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(px_per_step / world * 52.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            # per section-8d pass: the time of ALL kernels this design spends on it against the pass's algorithmic bytes
+            'pass_rooflines': passes,
             'kernels': kernels,
             # the kernels' HIP events sit between the launches of the instrumented pass: each event pair costs the queue
             # ~2 us, so that pass runs slower than the timed one -- its own wall clock is the one the kernel sum must fit in
@@ -786,19 +864,21 @@ def main():
     # step pays the host three more times (two statistics all-gathers, the gradient all-reduce) and is host-bound; the graph costs
     # one launch.  The eager line is complete at this point: a watchdog prints it and ends the process should the trial not come
     # back (a capture or a replay that hangs on one rank), and the ranks agree on success before anything collective is timed.
-    if group_on and nccl and dev.type == 'cuda' and not args.graph and not args.no_graph_trial:
+    if group_on and nccl and dev.type == 'cuda' and not args.graph and args.graph_trial:
         import threading
         printed = threading.Lock()                   # exactly one JSON line, whoever gets there first
 
         def give_up():
             # the eager measurement is complete and valid: print it, tagged, and end the process (a capture or replay that hangs
-            # on one rank cannot be unwound; destroy_process_group() would hang with it)
+            # on one rank cannot be unwound; destroy_process_group() would hang with it) -- with a NON-ZERO code on every rank:
+            # the GPU work of this process is wedged, and a launcher must be able to tell that from a clean run
             if not printed.acquire(blocking=False):
                 return
             if rank == 0:
                 print(json.dumps(line(None, 'watchdog: the graph trial did not finish in %g s' % GRAPH_TRIAL_TIMEOUT_S,
                                       watchdog=True)), flush=True)
-            os._exit(0)
+            sys.stdout.flush()
+            os._exit(WATCHDOG_EXIT)
         dog = threading.Timer(GRAPH_TRIAL_TIMEOUT_S, give_up)
         dog.daemon = True
         dog.start()

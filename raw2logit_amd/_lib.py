@@ -195,6 +195,20 @@ def hipcc_command(out_path=LIB_PATH, extra=()):
             *extra, os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path, '-lrocfft']      # rocFFT: fft_denoising only
 
 
+def source_digest():
+    """12 hex digits over the kernel sources and the C-ABI header: the build tag profiling scripts write into
+    profiles/*pmc_traffic*.json (`_meta.library_digest`) and bench.py reports beside the traffic it reads from them"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + [os.path.join(REPO_ROOT, 'include', 'r2l_isp.h')]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            with open(path, 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def build_device_library(verbose=True, out_path=LIB_PATH, extra=()):
     """compile libr2l_isp.so in-tree for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \

@@ -133,3 +133,80 @@ def test_single_rank_takes_the_split_path_when_asked(emulation, tmp_path):
     assert np.abs(r['g'] - g).max() <= 2e-4 * (np.abs(g).max() + 1e-6)
     np.testing.assert_allclose(r['rm'], m.batch_norm.running_mean.numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(r['rv'], m.batch_norm.running_var.numpy(), rtol=1e-5, atol=1e-7)
+
+
+# ---- BASELINE config 5's partition: 512 frames -> 8 ranks x 64 frames (train.py:361-368 runs the same batch on ONE GPU: the
+# single-process batch statistics are the yardstick).  H, W scaled down (8 x 12 instead of 256 x 256); the batch and the rank
+# count are config 5's own.
+C5_WORLD, C5_BATCH, C5_HW = 8, 512, (8, 12)
+
+
+def _c5_inputs():
+    from oracle import isp_oracle as orc
+    B, (H, W) = C5_BATCH, C5_HW
+    raw = orc.synth_raw(B, H, W, seed=11, kind='uniform')
+    cot = np.random.default_rng(12).standard_normal((B, 3, H, W)).astype(np.float32)
+    return torch.from_numpy(raw), torch.from_numpy(cot)
+
+
+def _c5_worker(rank, world, port, emul_path, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import emul_hook
+    emul_hook.enable(emul_path)
+    from oracle import isp_oracle as orc
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+    from raw2logit_amd import functional as F_
+    raw, cot = _c5_inputs()
+    per = C5_BATCH // world
+    lo, hi = rank * per, (rank + 1) * per
+    m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).train()
+    m.process_group = dist.group.WORLD
+    out = {}
+    for step in range(2):                      # two steps: running statistics after two updates, num_batches_tracked
+        for p in m.parameters():
+            p.grad = None
+        y = m(raw[lo:hi])
+        y.backward(cot[lo:hi])
+        F_.GradAllReduce(list(m.parameters()), dist.group.WORLD).wait()
+        out[f'y{step}'] = y.detach().numpy()
+        out[f'g{step}'] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), rm=m.batch_norm.running_mean.numpy(),
+             rv=m.batch_norm.running_var.numpy(), nbt=m.batch_norm.num_batches_tracked.numpy(), **out)
+    dist.destroy_process_group()
+
+
+def test_config5_partition_eight_ranks(emulation, tmp_path):
+    """BASELINE config 5 as it is sharded: 512 frames over EIGHT ranks, 64 each (gloo, kernels served by the host emulation).
+    Every rank must hold bit-identical BatchNorm running statistics and bit-identical summed gradients (the kernels add the
+    gathered rows in rank order), and the sharded run must equal ONE process on the whole batch -- what the reference's single
+    GPU computes (train.py:361-368)."""
+    from oracle import isp_oracle as orc
+    from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
+    import conftest
+    world = C5_WORLD
+    mp.spawn(_c5_worker, args=(world, _free_port(), conftest.EMUL_LIB, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), f'rank{k}.npz')) for k in range(world)]
+    raw, cot = _c5_inputs()
+    m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).train()
+    for step in range(2):
+        for p in m.parameters():
+            p.grad = None
+        y = m(raw)
+        y.backward(cot)
+        g = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()
+        for k in range(1, world):
+            assert np.array_equal(r[0][f'g{step}'], r[k][f'g{step}']), (step, k)      # same sum on every rank, bit for bit
+        ys = np.concatenate([r[k][f'y{step}'] for k in range(world)])
+        assert ys.shape == (C5_BATCH, 3) + C5_HW
+        assert np.abs(ys - y.detach().numpy()).max() < 2e-5, step
+        assert np.abs(r[0][f'g{step}'] - g).max() <= 2e-4 * (np.abs(g).max() + 1e-6), step
+    for k in range(world):
+        assert np.array_equal(r[k]['rm'], r[0]['rm']) and np.array_equal(r[k]['rv'], r[0]['rv'])      # statistics: bit-identical
+        assert int(r[k]['nbt']) == 2
+    np.testing.assert_allclose(r[0]['rm'], m.batch_norm.running_mean.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r[0]['rv'], m.batch_norm.running_var.numpy(), rtol=1e-5, atol=1e-7)

@@ -248,7 +248,8 @@ def test_bench_graph_trial_with_one_rccl_rank(dev):
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         e.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '10', '--warmup', '3', '--batch', '64',
-                        '--size', '256', '--quick'], env=e, capture_output=True, text=True, timeout=900, cwd=REPO)
+                        '--size', '256', '--quick', '--graph-trial'], env=e, capture_output=True, text=True, timeout=900,
+                       cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     out, = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{')]
     assert 'graph_error' not in out, (out.get('graph_error'), r.stderr[-1500:])
@@ -270,16 +271,24 @@ def test_bench_graph_trial_with_one_rccl_rank(dev):
 
 def test_bench_graph_trial_watchdog(dev):
     """The same branch with a watchdog of 1 ms: the timer fires while the capture is still under way, rank 0 prints the EAGER line with
-    the reason in `graph_error`, and the process ends with exit code 0 -- what a hanging capture or replay on a real multi-GPU node
-    would leave behind instead of no line at all."""
+    the reason in `graph_error`, and the process ends with bench.WATCHDOG_EXIT (17), never 0: its GPU work is wedged -- what a
+    hanging capture or replay on a real multi-GPU node would leave behind instead of no line at all, and a launcher can tell it
+    from a clean run.  Without --graph-trial (the default since round 6) the same run makes no trial at all."""
     import json
     e = dict(os.environ, R2L_BENCH_ONE_RANK_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(_free_port()),
              R2L_BENCH_TRIAL_TIMEOUT_S='0.001')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         e.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '5', '--warmup', '2', '--batch', '16',
-                        '--size', '256', '--quick'], env=e, capture_output=True, text=True, timeout=900, cwd=REPO)
-    assert r.returncode == 0, r.stderr[-3000:]
+                        '--size', '256', '--quick', '--graph-trial'], env=e, capture_output=True, text=True, timeout=900,
+                       cwd=REPO)
+    assert r.returncode == 17, (r.returncode, r.stderr[-3000:])
     out, = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{')]
     assert 'watchdog' in out['graph_error'] and 'ms_per_step_graph' not in out and out['watchdog_fired'] is True
     assert out['ms_per_step'] > 0 and out['value'] > 0
+    # the default: no trial, no watchdog, a plain eager line and exit code 0
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '5', '--warmup', '2', '--batch', '16',
+                        '--size', '256', '--quick'], env=e, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out, = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{')]
+    assert 'ms_per_step_graph' not in out and 'watchdog_fired' not in out and 'graph_error' not in out
