@@ -507,6 +507,72 @@ def small_shape_records(torch, lib, clock, dev, cameras, ParametrizedProcessing)
     return recs
 
 
+def cold_record(torch, lib, clock, dev, model, raw, cot, steps):
+    """the headline step under TRAINING conditions: a classifier runs between the processor's forward and its
+    backward, so nothing the forward left in the 256 MiB memory-side cache survives.  Here an untimed scrub (a 768 MiB buffer read
+    and rewritten) runs between forward and backward and again before the next forward; the kernels' own time comes from the
+    library's HIP-event hooks (the scrub is a torch kernel: not counted).  Reported next to the back-to-back number, which is the
+    cache's best case."""
+    scrub = torch.empty(768 << 18, dtype=torch.float32, device=dev)      # 768 MiB
+    scrub.zero_()
+    params = list(model.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        y = model(raw)
+        scrub.add_(1.0)
+        y.backward(cot)
+        scrub.add_(1.0)
+    for _ in range(5):
+        step()
+    k = kernel_times(lib, clock, step, steps)
+    us = sum(v['launches'] * v['avg_us'] for v in k.values()) / max(steps, 1)
+    px = raw.shape[0] * raw.shape[1] * raw.shape[2]
+    ach = px * 52.0 / (us * 1e-6) / 1e9
+    del scrub
+    torch.cuda.empty_cache()
+    return {'what': 'the same step with an untimed 768 MiB scrub (read + rewrite) between forward and backward and before the '
+                    'next forward: nothing survives in the 256 MiB memory-side cache across the scrubs (the regime of a training '
+                    'step, whose task model runs there); kernel times from the library HIP-event hooks, scrub excluded',
+            'ms_per_step_kernels': round(us * 1e-3, 4),
+            'kernels': {n.replace('r2l_launch_', '').replace('_kernel', ''): v['avg_us'] for n, v in k.items()},
+            'step_roofline': {'algo_bytes_per_px': 52.0, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': round(ach / HBM_PEAK_GBS, 4)}}
+
+
+def fallback_records(torch, lib, clock, dev, cameras, ParametrizedProcessing):
+    """the frames the row-streaming / plane kernels do not take: the learned additive layer of
+    `--adv_noise_layer` (train.py:108,257; pipeline_torch.py:129-131: fixed at 256x256) at BASELINE config 5's per-GPU shard, and
+    a frame width with W % 4 != 0.  fwd+bwd, BatchNorm train mode, eager; kernels from the HIP-event hooks."""
+    from raw2logit_amd.processing.pipeline_torch import append_additive_layer
+    recs = []
+    for what, (B, H, W), additive in (('additive layer (train.py --adv_noise_layer)', (64, 256, 256), True),
+                                      ('W % 4 != 0', (64, 256, 254), False)):
+        gen = torch.Generator(dev).manual_seed(0)
+        raw = torch.randint(0, 4096, (B, H, W), device=dev, generator=gen, dtype=torch.int32).to(torch.float32) / 4095.0
+        cot = torch.randn((B, 3, H, W), device=dev, generator=gen)
+        model = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True)
+        if additive:
+            append_additive_layer(model)
+        model = model.to(dev).train()
+        params = list(model.parameters())
+
+        def step():
+            for p in params:
+                p.grad = None
+            model(raw).backward(cot)
+        clock.preroll(step, None, 0.05)
+        dt = clock.time_steps(step, 50, 10)
+        k = kernel_times(lib, clock, step, 50)
+        us = sum(v['launches'] * v['avg_us'] for v in k.values()) / 50
+        recs.append({'what': what, 'shape': [B, H, W], 'ms_per_step': round(1e3 * dt / 50, 4),
+                     'kernels_us_per_step': round(us, 1), 'Mpix_per_s': round(B * H * W / dt * 50 / 1e6, 1),
+                     'kernels': {n.replace('r2l_launch_', '').replace('_kernel', ''): v['avg_us'] for n, v in k.items()}})
+        del raw, cot, model
+    return recs
+
+
 def main_static(args):
     """BASELINE config 3: one step = the fused static chain over 256x1024x1024 frames per GPU (no exchange between
     ranks: static mode needs no collective)."""
@@ -775,11 +841,21 @@ def main():
     graph_ms = graph_err = graph_local_ms = graph_local_err = None
     static_c3 = small = None
     # (sub-records: a failure in one of them must not cost the headline line -- it is reported in its place)
+    cold = fallback = None
+    if world == 1 and dev.type == 'cuda' and not args.no_small_shapes and not args.raw_u16:
+        try:
+            cold = cold_record(torch, lib, clock, dev, model, raw, cot, args.steps)
+        except Exception as e:                       # noqa: BLE001
+            cold = {'error': '%s: %s' % (type(e).__name__, e)}
     if world == 1 and dev.type == 'cuda' and not args.no_small_shapes:
         try:
             small = small_shape_records(torch, lib, clock, dev, cameras, ParametrizedProcessing)
         except Exception as e:                       # noqa: BLE001
             small = {'error': '%s: %s' % (type(e).__name__, e)}
+        try:
+            fallback = fallback_records(torch, lib, clock, dev, cameras, ParametrizedProcessing)
+        except Exception as e:                       # noqa: BLE001
+            fallback = {'error': '%s: %s' % (type(e).__name__, e)}
     if world == 1 and dev.type == 'cuda' and not args.no_static_c3:
         del raw, cot
         torch.cuda.empty_cache()
@@ -852,8 +928,12 @@ def main():
             out['comm_us'] = comm_us
         if args.graph:
             out['config']['step'] += ' (the whole step replayed as one HIP graph)'
+        if cold is not None:
+            out['cold'] = cold
         if small is not None:
             out['small_shapes'] = small
+        if fallback is not None:
+            out['fallback_paths'] = fallback
         if static_c3 is not None:
             out['static_c3'] = static_c3
         if cpu is not None:

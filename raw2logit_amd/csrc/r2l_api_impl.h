@@ -96,7 +96,7 @@ static void r2l_time_end(hipStream_t s, R2LTimedLaunch& t) {
   r2l_timed.push_back(t);
 }
 // Diagnostic builds (-DR2L_TEST_HOOKS) can put something in front of a launch whose name contains one of the comma-separated
-// substrings of an environment variable, outside the launch's timing events (tests/experiments/mall_probe_step.py):
+// substrings of an environment variable, outside the launch's timing events (tests/experiments/mall_xcd_probe.py):
 //   R2L_EXP_FLUSH  a pass that reads and re-writes a 768 MB scratch allocation (evicts the L2s and the 256 MB memory-side
 //                  cache: what the kernel costs when its predecessor left it nothing);
 //   R2L_EXP_TWICE  an untimed launch of the same kernel (what it costs when everything it touches was touched just now).
@@ -526,7 +526,7 @@ static int r2l_band_rows(int B, int H, int W, long slots, const char* env) {
   return (r2l_env_int(env, bh) + 5) / 6 * 6;
 }
 
-// XCD windows of the band passes (r2l_xcd_window): neighbouring workgroups per XCD; measured per pass (profiles/r05_xcd_windows.txt)
+// XCD windows of the band passes (r2l_xcd_window): neighbouring workgroups per XCD; measured per pass (profiles/r05_mall_xcd.txt)
 #ifndef R2L_XCDM_FS
 #define R2L_XCDM_FS 0   // statistics pass (row-streaming forward)
 #endif
@@ -1300,6 +1300,8 @@ int r2l_isp_step_bwd(const void* raw, int raw_u16, float denom, const float* add
   if (phase == R2L_STEP_B && !gathered_sums) return r2l_fail(-1, "r2l_isp_step_bwd: phase B needs the gathered sums");
   if (bn_mode == R2L_BN_TRAIN && !out) return r2l_fail(-1, "r2l_isp_step_bwd: train-mode BatchNorm needs the saved output");
   const R2LRaw rw = r2l_raw_any(raw, raw_u16, denom);
+  // (before ANY launch: the recomputing BatchNorm sums below read the raw frames, r2l_isp_bwd_impl's own check comes later)
+  if (int e = r2l_check_raw(rw, W, "r2l_isp_step_bwd")) return e;
   const R2LWorkspace ws = r2l_carve(workspace, B, H, W);
   if (workspace_bytes < ws.total) return r2l_fail(-2, "r2l_isp_step_bwd: workspace too small (r2l_isp_workspace_bytes)");
   const float* bn = bn_mode == R2L_BN_NONE ? nullptr : ws.bn;

@@ -19,9 +19,11 @@
 // Host builds (test infrastructure, tests/emul/):
 //   R2L_EMUL                  the SERIAL emulation (tests/emul/r2l_emul.cpp): every phase as a loop over tid, no operation
 //                             between lanes -- it compiles the tile forms of the kernels only (R2L_SERIAL below);
-//   R2L_EMUL + R2L_LOCKSTEP   the LOCK-STEP emulation (tests/emul/r2l_lockstep.cpp): one host thread per lane, the
-//                             workgroups of a launch one after the other; wave shifts / readfirstlane / shuffles / s_barrier
-//                             are rendezvous between the threads of a wavefront resp. workgroup (tests/emul/r2l_lockstep_rt.h).
+//   R2L_EMUL + R2L_LOCKSTEP   the LOCK-STEP emulation (tests/emul/r2l_lockstep.cpp): one FIBER per lane, cooperatively
+//                             scheduled on a single host thread (one lane runs at a time), the workgroups of a launch one after
+//                             the other; wave shifts / readfirstlane / shuffles / s_barrier are rendezvous between the fibers of a
+//                             wavefront resp. workgroup (tests/emul/r2l_lockstep_rt.h).  It checks addresses and undefined
+//                             behaviour; races between lanes are NOT modelled (nothing runs concurrently).
 //                             It compiles EVERY kernel -- the row-streaming forward, the passes over planes, the branch-free
 //                             static loops -- in its device form, for -fsanitize=address,undefined runs of the CPU suite.
 // Both take the host forms of the leaf helpers (packed pairs, LDS reads, coherent loads: `#ifdef R2L_EMUL`).
@@ -89,7 +91,7 @@ R2L_HD float r2l_row_shl1(float x, float edge) { return edge; }
 #define R2L_TREG_DECL(type, name) type name##_all[R2L_NT]
 #define R2L_TREG(name) name##_all[tid]
 #else
-// the lock-step emulation: one host thread per lane -- the device's forms, the lane-to-lane moves as rendezvous
+// the lock-step emulation: one fiber per lane (a single host thread, one lane at a time) -- the device's forms, the lane-to-lane moves as rendezvous
 #define R2L_HAVE_LANE_SHIFTS true
 #define R2L_LANE_ID ((int)(threadIdx.x & 63))
 R2L_HD float r2l_wave_shr1(float x) { return r2l_ls::dpp(x, x, 0x138); }

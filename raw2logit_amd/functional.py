@@ -167,7 +167,6 @@ class CommTimer:
 
 
 _HOST_STAGED = weakref.WeakKeyDictionary()     # process group object -> (backend string, staged); dies with the group
-_HOST_STAGED_DEFAULT = [None]                  # the default group (None): (backend string, staged), re-validated every call
 
 
 def _backend_for_device_tensors(group):
@@ -183,16 +182,16 @@ def _host_staged(group, t):
     multi-rank check on a one-GPU box) cross through a host copy.  RCCL ("nccl") takes device pointers as they are.
     The backend that serves the tensor's DEVICE decides ("cpu:gloo,cuda:nccl" groups hand device tensors to RCCL).
     Cached on the group OBJECT (weakly: an id() can be reused by a later group after destroy_process_group() and a
-    re-init with another backend in the same process); the default group's entry carries its backend string and is
-    re-validated against dist.get_backend() on every call."""
+    re-init with another backend in the same process); group=None resolves to the default group's object first."""
     if not t.is_cuda:
         return False
     if group is None:
-        name = _backend_for_device_tensors(None)
-        ent = _HOST_STAGED_DEFAULT[0]
-        if ent is None or ent[0] != name:
-            ent = _HOST_STAGED_DEFAULT[0] = (name, name == 'gloo')
-        return ent[1]
+        # the default group: key the cache on the default ProcessGroup OBJECT (a re-init after destroy_process_group() makes a
+        # new one), so that the eager data-parallel step pays no backend-string lookup per collective (ADVICE r5)
+        try:
+            group = dist.distributed_c10d._get_default_group()
+        except Exception:                            # noqa: BLE001  (private accessor gone: the per-call lookup still works)
+            return _backend_for_device_tensors(None) == 'gloo'
     try:
         ent = _HOST_STAGED.get(group)
     except TypeError:                                # (a group object that cannot be weakly referenced: no cache)

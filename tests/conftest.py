@@ -37,9 +37,10 @@ LOCKSTEP_LIB = os.path.join(REPO, 'tests', '_build', 'libr2l_lockstep_asan.so')
 
 def build_lockstep():
     """g++ -fsanitize=address,undefined build of the LOCK-STEP emulation (tests/emul/r2l_lockstep.cpp + r2l_lockstep_rt.h: every
-    kernel in its device form, one host thread per lane).  Test infrastructure; loaded only by tests/lockstep_checks.py in a
+    kernel in its device form, one FIBER per lane, cooperatively scheduled on a single host thread: address / UB checks, no model of
+    inter-lane races).  Test infrastructure; loaded only by tests/lockstep_checks.py in a
     subprocess that preloads libasan.  -O0: the run time is thread rendezvous, not arithmetic, and the build takes 40 s
-    instead of 6 min."""
+    instead of 6 min.  (No -pthread: nothing runs concurrently.)"""
     csrc = os.path.join(REPO, 'raw2logit_amd', 'csrc')
     deps = [LOCKSTEP_SRC, os.path.join(REPO, 'tests', 'emul', 'r2l_lockstep_rt.h'), os.path.join(REPO, 'include', 'r2l_isp.h')] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc)]
@@ -48,7 +49,7 @@ def build_lockstep():
     os.makedirs(os.path.dirname(LOCKSTEP_LIB), exist_ok=True)
     tmp = LOCKSTEP_LIB + f'.{os.getpid()}.tmp'
     subprocess.run(['g++', '-std=c++17', '-O0', '-g', '-fno-omit-frame-pointer', '-fsanitize=address,undefined',
-                    '-DR2L_TEST_HOOKS', '-shared', '-fPIC', '-pthread', LOCKSTEP_SRC, '-o', tmp], check=True)
+                    '-DR2L_TEST_HOOKS', '-shared', '-fPIC', LOCKSTEP_SRC, '-o', tmp], check=True)
     os.replace(tmp, LOCKSTEP_LIB)
     return LOCKSTEP_LIB
 

@@ -1,6 +1,6 @@
 """Driver of the LOCK-STEP emulation run (tests/test_lockstep.py starts it in a subprocess under LD_PRELOAD=libasan.so):
 the parity checks of the GPU suite on host memory, served by tests/_build/libr2l_lockstep.so -- every kernel in its device form,
-one host thread per lane, built with -fsanitize=address,undefined (tests/emul/r2l_lockstep_rt.h).
+one fiber per lane on a single host thread (one lane runs at a time: address and UB checks, no inter-lane races), built with -fsanitize=address,undefined (tests/emul/r2l_lockstep_rt.h).
 
     python tests/lockstep_checks.py <library> [group ...]        groups: planes shapes stream passes static canary [fuzz]
 

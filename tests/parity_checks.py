@@ -1,6 +1,8 @@
 """Parity checks shared by the CPU tests (kernel source run by the host emulation) and the GPU tests
 (libr2l_isp.so on cuda:0).  Every check goes through the product's Python modules, i.e. through the C ABI,
 and compares with the oracle (oracle/isp_oracle.py) and with the golden vectors of the reference."""
+import os
+
 import numpy as np
 import torch
 
@@ -128,6 +130,24 @@ def _sample(a, full):
 LOW_BAND_TOL = 7.5e-5
 WELL_CONDITIONED = 3e-3          # pre-gamma value above which the 1e-5 bar itself applies (slope of x^(1/2.2) there: 11)
 DEFAULT_GRAD_RTOL = 1.5e-3      # of max|grad| (round 1: 3e-3; achieved <= 20 % of that on every golden case)
+
+
+ACHIEVED_K = 4.0               # golden cases on the GPU: limit = ACHIEVED_K x the error the shipped kernels achieved on that case
+_ACHIEVED = {}
+
+
+def achieved_grad_baseline():
+    """{'case/parameter': max |grad - float64 oracle| achieved on the GPU} (tests/golden/grad_achieved_gpu.json, written by
+    tests/tools/make_grad_baseline.py from a GPU run's parity log); empty if the file is missing"""
+    if 'v' not in _ACHIEVED:
+        import json
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'grad_achieved_gpu.json')
+        try:
+            with open(path) as f:
+                _ACHIEVED['v'] = json.load(f)['achieved']
+        except (OSError, KeyError, ValueError):
+            _ACHIEVED['v'] = {}
+    return _ACHIEVED['v']
 
 
 PLANE_GRAD_RTOL = 3e-5         # of max|grad|: what a correct float32 kernel reaches on well-conditioned frames (check_frame_shapes)
@@ -325,12 +345,22 @@ def check_param_case(case, golden, device):
                 (case['name'], band, 'max vs reference float64', np.abs(d_mine).max(), np.abs(d_ref).max())
 
     res = {'out_err': float(err.max())}
+    # how much of the case is judged on the relaxed band: a number per case in the parity log
+    report(f'param/{case["name"]}/FRACTION of output samples on the relaxed 7.5e-5 band (pre-gamma <= 3e-3; not an error)',
+           float((~well).mean()), 1.0)
+    on_gpu = torch.device(device).type == 'cuda'
     for k, og in o_grads.items():
         got = NAME2ATTR[k](m).grad.detach().cpu().numpy().reshape(np.asarray(og).shape)
         scale = np.abs(og).max() + 1e-6
         e = np.abs(got - og).max()
-        report(f'param/{case["name"]}/grad {k} vs float64 oracle', e, grad_rtol * scale + flip[k])
-        assert e <= grad_rtol * scale + flip[k], (case['name'], k, 'grad vs oracle', e, scale, flip[k])
+        lim = grad_rtol * scale + flip[k]
+        ach = achieved_grad_baseline().get(f'{case["name"]}/{k}') if on_gpu else None
+        if ach is not None:
+            # ACHIEVED_K x what the shipped kernels reached on this very case (tests/golden/grad_achieved_gpu.json), floored at
+            # the level of a correct float32 kernel on well-conditioned frames, capped by the generic limit
+            lim = min(lim, max(ACHIEVED_K * ach, PLANE_GRAD_RTOL * scale + flip[k]))
+        report(f'param/{case["name"]}/grad {k} vs float64 oracle', e, lim)
+        assert e <= lim, (case['name'], k, 'grad vs oracle', e, scale, flip[k], ach)
         ref = g[pre + 'grad/' + k]
         e2 = np.abs((_sample(got, full) if k == 'additive_layer' else got) - ref).max()
         report(f'param/{case["name"]}/grad {k} vs reference (golden, float32)', e2,
@@ -390,6 +420,76 @@ def check_raw2rgb(golden, device):
         pass
     else:
         raise AssertionError('out_channels=5 must raise AssertionError (pipeline_torch.py:252)')
+
+
+class _StubSmp:
+    """stand-in for the absent third-party package segmentation_models_pytorch, injected into sys.modules for the duration of
+    check_nnprocessing: NNProcessing's body (smp.UnetPlusPlus, reference :97-103) is out of scope, its FRONT END -- the packed
+    three-channel mosaic of raw2rgb, reference :111-114 -- is row a12 of SURVEY.md section 8."""
+    calls = []
+
+    class UnetPlusPlus(torch.nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+            _StubSmp.calls.append(kw)
+            self.scale = torch.nn.Parameter(torch.ones(1))      # something trainable, identity at initialisation
+
+        def forward(self, x):
+            return x * self.scale
+
+
+def check_nnprocessing(golden, device):
+    """NNProcessing (pipeline_torch.py:83-126, processing_mode 'neural_network') with a stub body: what the class hands the
+    U-Net++ -- stages['demosaic'] -- is the raw2rgb kernel's packed mosaic, bit-identical to the reference's (golden
+    raw2rgb/r1_c3_bl0); the gradient arriving at the frames through an identity body is the reference's; normalize_mosaic is
+    applied in front of the body and stored under 'demosaic' like the reference does (:112-114); stages / buffer / retain_grad
+    behave like :117-124."""
+    import sys
+    import types
+    g = golden['raw2rgb']
+    raw_np, key = g['raw2rgb/raw'], 'raw2rgb/r1_c3_bl0/'
+    stub = types.ModuleType('segmentation_models_pytorch')
+    stub.UnetPlusPlus = _StubSmp.UnetPlusPlus
+    _StubSmp.calls.clear()
+    had = sys.modules.get('segmentation_models_pytorch')
+    sys.modules['segmentation_models_pytorch'] = stub
+    try:
+        m = ppt.NNProcessing(track_stages=True, batch_norm_output=False).to(device)
+        assert _StubSmp.calls == [dict(encoder_name='resnet34', encoder_depth=3, decoder_channels=[256, 128, 64],
+                                       in_channels=3, classes=3)], _StubSmp.calls            # reference :97-103
+        raw = torch.from_numpy(raw_np).to(device).requires_grad_(True)
+        y = m(raw)
+        assert list(m.stages) == ['demosaic', 'rgb'] and m.buffer['processed_rgb'] is y
+        assert np.array_equal(m.stages['demosaic'].detach().cpu().numpy(), g[key + 'out'])   # bit exact
+        assert np.array_equal(m.front_end(raw).detach().cpu().numpy(), g[key + 'out'])
+        (y * torch.from_numpy(g[key + 'cot']).to(device)).sum().backward()
+        assert np.array_equal(raw.grad.cpu().numpy(), g[key + 'grad_raw'])
+        assert m.stages['demosaic'].grad is not None and m.stages['rgb'].grad is not None      # retain_grad, reference :119-121
+        report('nnprocessing/front end vs reference (golden raw2rgb/r1_c3_bl0), bit exact', 0.0, 0.0)
+        # normalize_mosaic (train.py:187-190: a T.Normalize) sits between the kernel and the body
+        mean, std = torch.tensor([0.1, 0.2, 0.3], device=device).view(1, 3, 1, 1), torch.tensor([0.5, 0.6, 0.7], device=device).view(1, 3, 1, 1)
+        mn = ppt.NNProcessing(normalize_mosaic=lambda x: (x - mean) / std, batch_norm_output=True).to(device).train()
+        yn = mn(torch.from_numpy(raw_np).to(device))
+        ref = (torch.from_numpy(g[key + 'out']).to(device) - mean) / std
+        assert torch.equal(mn.stages['demosaic'], ref)
+        assert yn.shape == ref.shape and mn.batch_norm is not None and int(mn.batch_norm.num_batches_tracked) == 1
+        # 16-bit containers: the normalisation of dataset.py:86-87 inside the kernel, same bits as the host-normalised frames
+        u16 = np.rint(raw_np.astype(np.float64) * 65535).astype(np.uint16)
+        host = torch.from_numpy(u16.astype(np.float32) / np.float32(65535)).to(device)
+        assert torch.equal(m.front_end(torch.from_numpy(u16.view(np.int16)).to(device)), m.front_end(host))
+    finally:
+        if had is None:
+            sys.modules.pop('segmentation_models_pytorch', None)
+        else:
+            sys.modules['segmentation_models_pytorch'] = had
+    # without the package the class still refuses to construct (the body cannot exist), saying why
+    if had is None:
+        try:
+            ppt.NNProcessing()
+        except ImportError as e:
+            assert 'segmentation_models_pytorch' in str(e)
+        else:
+            raise AssertionError('NNProcessing() without segmentation_models_pytorch must raise ImportError')
 
 
 def check_static_case(case, golden, device, atol=1e-5):

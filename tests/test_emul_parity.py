@@ -19,6 +19,10 @@ def test_raw2rgb(golden, emulation):
     pc.check_raw2rgb(golden, 'cpu')
 
 
+def test_nnprocessing_front_end(golden, emulation):
+    pc.check_nnprocessing(golden, 'cpu')
+
+
 @pytest.mark.parametrize('case', DEVICE_STATIC, ids=[c['name'] for c in DEVICE_STATIC])
 def test_static(case, golden, emulation):
     pc.check_static_case(case, golden, 'cpu')

@@ -35,6 +35,12 @@ def test_raw2rgb(golden, dev):
     pc.check_raw2rgb(golden, dev)
 
 
+def test_nnprocessing_front_end(golden, dev):
+    """NNProcessing's raw2rgb front end (pipeline_torch.py:111-114) on the GPU, the third-party
+    U-Net++ body replaced by a stub injected into sys.modules"""
+    pc.check_nnprocessing(golden, dev)
+
+
 @pytest.mark.parametrize('case', DEVICE_STATIC, ids=[c['name'] for c in DEVICE_STATIC])
 def test_static(case, golden, dev):
     pc.check_static_case(case, golden, dev)

@@ -2,8 +2,9 @@
 
 The row-streaming forward, the passes over planes and the branch-free static loops fetch unconditionally from clamped addresses
 and talk between lanes (DPP shifts, readfirstlane, shuffles, one barrier per row); the serial emulation cannot run them and the
-GPU has no sanitizer on this pool.  tests/emul/r2l_lockstep.cpp compiles EVERY kernel in its device form with one host thread
-per lane (tests/emul/r2l_lockstep_rt.h), built with -fsanitize=address,undefined; tests/lockstep_checks.py runs the GPU suite's
+GPU has no sanitizer on this pool.  tests/emul/r2l_lockstep.cpp compiles EVERY kernel in its device form with one fiber per lane
+(cooperatively scheduled on a single host thread: tests/emul/r2l_lockstep_rt.h -- addresses and undefined behaviour are checked,
+races between lanes are not modelled), built with -fsanitize=address,undefined; tests/lockstep_checks.py runs the GPU suite's
 parity checks on it in a subprocess that preloads libasan, so that the numpy / torch buffers the kernels are handed carry
 malloc redzones: a lane that reads or writes one element past `raw`, `out`, the workspace planes or the kernel's LDS block aborts
 the run.  Reference behaviour being matched: ATen's bounds-checked kernels under `processing/pipeline_torch.py:187-217`."""
