@@ -185,6 +185,9 @@ def parse():
                          f'with exit code {WATCHDOG_EXIT} (every rank) if the trial does not finish in time')
     ap.add_argument('--no-small-shapes', action='store_true',
                     help="skip the small_shapes sub-records (the datasets' 256x256 tiles: BASELINE configs 4 / 5 per GPU)")
+    ap.add_argument('--cold', action='store_true',
+                    help='with --quick: still take the `cold` sub-record (the step with an untimed cache scrub between forward and '
+                         'backward); the default run always takes it')
     ap.add_argument('--raw-u16', action='store_true',
                     help='feed the 12-bit frames as uint16 containers (2 B/px ingest, normalised in-kernel; '
                          'SURVEY.md section 8f) instead of float32: a separate variant, not the headline config')
@@ -842,7 +845,7 @@ def main():
     static_c3 = small = None
     # (sub-records: a failure in one of them must not cost the headline line -- it is reported in its place)
     cold = fallback = None
-    if world == 1 and dev.type == 'cuda' and not args.no_small_shapes and not args.raw_u16:
+    if world == 1 and dev.type == 'cuda' and (args.cold or not args.no_small_shapes) and not args.raw_u16:
         try:
             cold = cold_record(torch, lib, clock, dev, model, raw, cot, args.steps)
         except Exception as e:                       # noqa: BLE001

@@ -268,6 +268,20 @@ int r2l_static_fwd_norm(const void *raw, int frames, float denom, float *out, in
                         const double *camera_host, int debayer, int sharpening, int denoising, double gamma,
                         const float *mean_std_host, void *workspace, size_t workspace_bytes, void *stream);
 
+/* processing()'s numeric arguments (pipeline_numpy.py:70-73: sharp_radius, sharp_amount, median_kernel_size, gaussian_sigma,
+ * fft_fraction; used at :117-122) as launch arguments: options_host = double[R2L_SOPT_COUNT] in host memory, or NULL for the
+ * reference's defaults (then identical to r2l_static_fwd_norm).  What the kernels' windows hold bounds the values:
+ *   gaussian_sigma   (0, 0.625)   scipy's window radius int(4 sigma + 0.5) <= 2 (the 5-tap window of gaussian_denoising);
+ *   sharp_radius     (0, 1.125)   radius int(4 sigma + 0.5) <= 4 (the 9-tap window behind unsharp_masking); sharp_amount any;
+ *   fft_fraction     [0, 0.5];    median_kernel_size 3 only (a 3x3 median network) -- anything else returns -4 with the
+ * reason in r2l_last_error().  An option of a stage the chain does not run is ignored, like the reference's if-chains.    */
+enum { R2L_SOPT_SHARP_RADIUS = 0, R2L_SOPT_SHARP_AMOUNT = 1, R2L_SOPT_GAUSSIAN_SIGMA = 2, R2L_SOPT_FFT_FRACTION = 3,
+       R2L_SOPT_MEDIAN_SIZE = 4, R2L_SOPT_COUNT = 5 };
+int r2l_static_fwd_opts(const void *raw, int frames, float denom, float *out, int B, int H, int W,
+                        const double *camera_host, int debayer, int sharpening, int denoising, double gamma,
+                        const double *options_host, const float *mean_std_host, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* ---- staged execution (track_stages=True, pipeline_torch.py:197-221): one entry point per materialised
  * stage, each with its VJP, so that autograd can hold every stage tensor (retain_grad) and d/d raw exists.
  * Tensors are (B,3,H,W) float32.  Weight gradients are float32 arrays; workspace from

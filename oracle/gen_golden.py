@@ -24,7 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from oracle import isp_oracle as orc  # noqa: E402
-from oracle.golden_cases import (PARAM_CASES, RAW2RGB_CASES, STATIC_CASES, SAMPLE_STRIDE,  # noqa: E402
+from oracle.golden_cases import (PARAM_CASES, RAW2RGB_CASES, STATIC_CASES, STATIC_OPT_CASES, SAMPLE_STRIDE,  # noqa: E402
                                  AUX_CASES, aux_inputs, static_case_frames)
 from oracle import harness  # noqa: E402
 
@@ -255,6 +255,22 @@ def gen_static(ppn, out):
               f'{np.abs(cross - res.transpose(0, 3, 1, 2)).max():.2e})')
 
 
+def gen_static_opts(ppn, out):
+    """processing() with its numeric arguments away from the defaults (pipeline_numpy.py:70-73, :117-122): the reference's own
+    function decides what they mean (scipy's gaussian_filter / median_filter and its fft_denoising are its own calls; the
+    unsharp mask behind sharp_radius / sharp_amount is the restated skimage function, unpinned like every unsharp case)"""
+    for case in STATIC_OPT_CASES:
+        name = case['name']
+        raw_np, _ = static_case_frames(case)
+        cam = orc.CAMERAS[case['camera']]
+        res = np.stack([ppn.processing(img.copy(), *cam, debayer=case['debayer'], sharpening=case['sharpening'],
+                                       denoising=case['denoising'], **case['opts']) for img in raw_np])
+        out[f'{name}/raw'] = raw_np
+        out[f'{name}/out_hwc_f64'] = res
+        mine = orc.static_batch(raw_np, cam, case['debayer'], case['sharpening'], case['denoising'], **case['opts'])
+        print(f'  {name:32s} {str(raw_np.dtype):8s} oracle-vs-reference: {np.abs(mine - res.transpose(0, 3, 1, 2)).max():.2e}')
+
+
 def gen_harness(ppt, out):
     torch.manual_seed(0)
     raw_np = orc.synth_raw(4, 32, 32, seed=21, kind='scene')
@@ -305,7 +321,7 @@ def main():
     gold = os.path.join(REPO, 'tests', 'golden')
     os.makedirs(gold, exist_ok=True)
     for fname, fn, mod in [('param_cases.npz', gen_param_cases, ppt), ('raw2rgb.npz', gen_raw2rgb, ppt),
-                           ('static_cases.npz', gen_static, ppn), ('harness.npz', gen_harness, ppt),
+                           ('static_cases.npz', gen_static, ppn), ('static_opts.npz', gen_static_opts, ppn), ('harness.npz', gen_harness, ppt),
                            ('aux_losses.npz', gen_aux, None)]:
         if len(sys.argv) > 1 and fname.split('.')[0] not in sys.argv[1:]:
             continue          # `python oracle/gen_golden.py static_cases` regenerates one file

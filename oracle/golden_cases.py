@@ -134,6 +134,35 @@ STATIC_CASES = [
 ]
 
 
+# processing()'s numeric arguments (pipeline_numpy.py:70-73, :117-122) away from their defaults -- generated by the reference's
+# own processing() like STATIC_CASES (tests/golden/static_opts.npz)
+STATIC_OPT_CASES = [
+    dict(name='opt_gauss_sigma04', seed=40, shape=(2, 24, 40), kind='scene', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='gaussian_denoising', opts=dict(gaussian_sigma=0.4)),
+    dict(name='opt_gauss_sigma03_radius1', seed=41, shape=(1, 32, 32), kind='dark', camera='drone', dtype='float32',
+         debayer='malvar2004', sharpening='none', denoising='gaussian_denoising', opts=dict(gaussian_sigma=0.3)),
+    dict(name='opt_gauss_sigma06', seed=42, shape=(1, 20, 40), kind='scene', camera='microscopy', dtype='float64',
+         debayer='bilinear', sharpening='unsharp_masking', denoising='gaussian_denoising', opts=dict(gaussian_sigma=0.6)),
+    dict(name='opt_unsharp_r08_a15', seed=43, shape=(1, 32, 40), kind='scene', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='unsharp_masking', denoising='none', opts=dict(sharp_radius=0.8, sharp_amount=1.5)),
+    dict(name='opt_unsharp_r11_a05_median', seed=44, shape=(2, 24, 32), kind='uniform', camera='drone', dtype='float32',
+         debayer='malvar2004', sharpening='unsharp_masking', denoising='median_denoising',
+         opts=dict(sharp_radius=1.1, sharp_amount=0.5, median_kernel_size=3)),
+    dict(name='opt_unsharp_r03_radius1', seed=45, shape=(1, 16, 24), kind='dark', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='unsharp_masking', denoising='gaussian_denoising',
+         opts=dict(sharp_radius=0.3, sharp_amount=2.0, gaussian_sigma=0.55)),
+    dict(name='opt_fft_f02', seed=46, shape=(2, 24, 40), kind='scene', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='fft_denoising', opts=dict(fft_fraction=0.2)),
+    dict(name='opt_fft_f045_unsharp', seed=47, shape=(1, 16, 64), kind='uniform', camera='drone', dtype='float32',
+         debayer='malvar2004', sharpening='unsharp_masking', denoising='fft_denoising',
+         opts=dict(fft_fraction=0.45, sharp_amount=0.7)),
+    # an option of a stage the chain does not run is ignored (the reference's if-chains, :110-122)
+    dict(name='opt_ignored_on_short_chain', seed=48, shape=(1, 16, 16), kind='scene', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='none', denoising='none',
+         opts=dict(gaussian_sigma=3.0, sharp_radius=5.0, median_kernel_size=7, fft_fraction=0.9)),
+]
+
+
 def static_case_frames(case):
     """(frames handed to processing(), 16-bit containers | None) of a static case."""
     import numpy as np

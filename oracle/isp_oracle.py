@@ -652,7 +652,8 @@ def gaussian_kernel1d(sigma=0.5, truncate=4.0):
 
 
 def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear",
-               sharpening="unsharp_masking", denoising="median_filter", gamma=2.2):
+               sharpening="unsharp_masking", denoising="median_filter", gamma=2.2, sharp_radius=1.0, sharp_amount=1.0,
+               median_kernel_size=3, gaussian_sigma=0.5, fft_fraction=0.3):
     """pipeline_numpy.py:70-141, for the branches in scope (unknown strings are silently ignored,
     exactly like the reference's if-chains).  img (H,W) float -- MODIFIED IN PLACE by the black
     level step like the reference.  Returns (H,W,3) float64."""
@@ -666,20 +667,20 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
     if sharpening == "sharpening_filter":
         img = sharpening_filter(img)
     if sharpening == "unsharp_masking":
-        img = unsharp_masking(img, radius=1.0, amount=1.0, multichannel=True)
+        img = unsharp_masking(img, radius=sharp_radius, amount=sharp_amount, multichannel=True)       # :117
     if denoising == "median_denoising":
-        img = median_denoising(img)
+        img = median_denoising(img, size=median_kernel_size)                                          # :119
     if denoising == "gaussian_denoising":
-        img = gaussian_denoising(img)
+        img = gaussian_denoising(img, sigma=gaussian_sigma)                                           # :120
     if denoising == "fft_denoising":
-        img = fft_denoising(img, keep_fraction=0.3)
+        img = fft_denoising(img, keep_fraction=fft_fraction)                                          # :121-122
     img = np.clip(img, 0, 1)
     img = img ** (1.0 / gamma)
     return img
 
 
 def static_batch(raw, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
-                 denoising='gaussian_denoising', gamma=2.2):
+                 denoising='gaussian_denoising', gamma=2.2, **options):
     """RawProcessingPipeline.__call__ (pipeline_numpy.py:55-67) over a batch: (B,H,W) -> (B,3,H,W)
     float32.  Frames are processed in the dtype they come in, like the reference: remove_blacklv works in
     place, so float32 frames (load_image's np.float32 array / (2**bits-1), utils/dataset_utils.py:18-26,
@@ -691,7 +692,7 @@ def static_batch(raw, camera_parameters, debayer='bilinear', sharpening='sharpen
     assert raw.dtype in (np.float32, np.float64), raw.dtype
     for img in raw:
         o = processing(img.copy(), bl, wb, ccm, debayer=debayer,
-                       sharpening=sharpening, denoising=denoising, gamma=gamma)
+                       sharpening=sharpening, denoising=denoising, gamma=gamma, **options)
         out.append(o.transpose(2, 0, 1).astype(np.float32))
     return np.stack(out)
 

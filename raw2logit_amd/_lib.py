@@ -119,6 +119,11 @@ _SIGNATURES = {
                                            ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                            ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_size_t,
                                            ctypes.c_void_p]),
+    'r2l_static_fwd_opts': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.c_void_p]),
     'r2l_static_fwd': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
@@ -192,7 +197,7 @@ def hipcc_command(out_path=LIB_PATH, extra=()):
     # -fno-slp-vectorize: packed f32 is written out by hand where it pays (r2l_p2 pairs of adjacent pixels); the
     # SLP vectoriser's own pairing adds register shuffles and ~100 live VGPRs to the backward kernels
     return ['hipcc', '-O3', '-std=c++17', '-fno-slp-vectorize', '--offload-arch=gfx950', '-shared', '-fPIC',
-            *extra, os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path, '-lrocfft']      # rocFFT: fft_denoising only
+            *extra, os.path.join(CSRC, 'r2l_api.hip'), '-o', out_path, '-ldl']    # (rocFFT: opened at first fft_denoising call)
 
 
 def source_digest():

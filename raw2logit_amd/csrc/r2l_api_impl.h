@@ -1423,13 +1423,53 @@ struct R2LFftPlans {
   size_t work_bytes = 0;
 };
 #ifndef R2L_EMUL
+// rocFFT is NOT a link-time dependency of this library (round 6): fft_denoising is the one stage of the path that is a library
+// call, and an alternate the reference's defaults never take (train.py:100-101 offers it).  The library is opened the first time
+// an fft_denoising chain is asked for; every other entry point works on a box without it.
+#include <dlfcn.h>
+struct R2LRocfft {
+  decltype(&rocfft_setup) setup = nullptr;
+  decltype(&rocfft_plan_create) plan_create = nullptr;
+  decltype(&rocfft_plan_get_work_buffer_size) plan_get_work_buffer_size = nullptr;
+  decltype(&rocfft_execution_info_create) execution_info_create = nullptr;
+  decltype(&rocfft_execution_info_set_stream) execution_info_set_stream = nullptr;
+  decltype(&rocfft_execution_info_set_work_buffer) execution_info_set_work_buffer = nullptr;
+  decltype(&rocfft_execute) execute = nullptr;
+  decltype(&rocfft_execution_info_destroy) execution_info_destroy = nullptr;
+  bool ok = false;
+};
+static const R2LRocfft* r2l_rocfft() {
+  static R2LRocfft api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = nullptr;
+    for (const char* name : {"librocfft.so.0", "librocfft.so", "/opt/rocm/lib/librocfft.so.0", "/opt/rocm/lib/librocfft.so"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return;
+#define R2L_FFT_SYM(field, sym) api.field = (decltype(api.field))dlsym(h, #sym)
+    R2L_FFT_SYM(setup, rocfft_setup);
+    R2L_FFT_SYM(plan_create, rocfft_plan_create);
+    R2L_FFT_SYM(plan_get_work_buffer_size, rocfft_plan_get_work_buffer_size);
+    R2L_FFT_SYM(execution_info_create, rocfft_execution_info_create);
+    R2L_FFT_SYM(execution_info_set_stream, rocfft_execution_info_set_stream);
+    R2L_FFT_SYM(execution_info_set_work_buffer, rocfft_execution_info_set_work_buffer);
+    R2L_FFT_SYM(execute, rocfft_execute);
+    R2L_FFT_SYM(execution_info_destroy, rocfft_execution_info_destroy);
+#undef R2L_FFT_SYM
+    api.ok = api.setup && api.plan_create && api.plan_get_work_buffer_size && api.execution_info_create &&
+             api.execution_info_set_stream && api.execution_info_set_work_buffer && api.execute && api.execution_info_destroy;
+  });
+  return api.ok ? &api : nullptr;
+}
 static int r2l_fft_plans(int W, size_t rows, R2LFftPlans& out) {
+  const R2LRocfft* fft = r2l_rocfft();
+  if (!fft) return r2l_fail(-10, "fft_denoising needs librocfft.so (ROCm), which could not be opened; every other chain works without it");
   static std::mutex mu;
   static std::map<std::pair<int, std::pair<int, size_t>>, R2LFftPlans> cache;  // (device, (W, rows))
   static bool setup = false;
   std::lock_guard<std::mutex> lk(mu);
   if (!setup) {
-    if (rocfft_setup() != rocfft_status_success) return r2l_fail(-10, "rocfft_setup failed");
+    if (fft->setup() != rocfft_status_success) return r2l_fail(-10, "rocfft_setup failed");
     setup = true;
   }
   int dev = 0;
@@ -1440,14 +1480,14 @@ static int r2l_fft_plans(int W, size_t rows, R2LFftPlans& out) {
     // (plans live as long as the process: a caller on another thread may be executing one, so none is destroyed here)
     R2LFftPlans p;
     const size_t len = (size_t)W;
-    if (rocfft_plan_create(&p.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+    if (fft->plan_create(&p.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
                            rocfft_precision_double, 1, &len, rows, nullptr) != rocfft_status_success ||
-        rocfft_plan_create(&p.inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+        fft->plan_create(&p.inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
                            rocfft_precision_double, 1, &len, rows, nullptr) != rocfft_status_success)
       return r2l_fail(-10, "rocfft_plan_create failed");
     size_t w0 = 0, w1 = 0;
-    rocfft_plan_get_work_buffer_size(p.fwd, &w0);
-    rocfft_plan_get_work_buffer_size(p.inv, &w1);
+    fft->plan_get_work_buffer_size(p.fwd, &w0);
+    fft->plan_get_work_buffer_size(p.inv, &w1);
     p.work_bytes = w0 > w1 ? w0 : w1;
     it = cache.emplace(key, p).first;
   }
@@ -1455,14 +1495,16 @@ static int r2l_fft_plans(int W, size_t rows, R2LFftPlans& out) {
   return 0;
 }
 static int r2l_fft_exec(rocfft_plan plan, void* in, void* outp, void* work, size_t work_bytes, void* stream) {
+  const R2LRocfft* fft = r2l_rocfft();
+  if (!fft) return r2l_fail(-10, "librocfft.so could not be opened");
   rocfft_execution_info info = nullptr;
-  if (rocfft_execution_info_create(&info) != rocfft_status_success) return r2l_fail(-10, "rocfft_execution_info_create failed");
-  rocfft_status st = rocfft_execution_info_set_stream(info, stream);
-  if (st == rocfft_status_success && work_bytes) st = rocfft_execution_info_set_work_buffer(info, work, work_bytes);
+  if (fft->execution_info_create(&info) != rocfft_status_success) return r2l_fail(-10, "rocfft_execution_info_create failed");
+  rocfft_status st = fft->execution_info_set_stream(info, stream);
+  if (st == rocfft_status_success && work_bytes) st = fft->execution_info_set_work_buffer(info, work, work_bytes);
   void* ins[1] = {in};
   void* outs[1] = {outp};
-  if (st == rocfft_status_success) st = rocfft_execute(plan, ins, outs, info);
-  rocfft_execution_info_destroy(info);
+  if (st == rocfft_status_success) st = fft->execute(plan, ins, outs, info);
+  fft->execution_info_destroy(info);
   return st == rocfft_status_success ? 0 : r2l_fail(-10, "rocfft_execute failed");
 }
 #endif
@@ -1486,7 +1528,8 @@ static int r2l_fft_layout(int B, int H, int W, R2LFftLayout& L) {
 
 static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int W, const double* camera_host,
                                int debayer, int sharpening, int denoising, double gamma, void* workspace,
-                               size_t workspace_bytes, void* stream, const float* mean_std_host = nullptr) {
+                               size_t workspace_bytes, void* stream, const float* mean_std_host = nullptr,
+                               const R2LStaticOpts& opt = R2LStaticOpts()) {
   if (int e = r2l_check_dims(B, H, W)) return e;
   if (int e = r2l_check_raw(raw, W, "r2l_static_fwd")) return e;
   if (mean_std_host)
@@ -1501,8 +1544,9 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
       denoising != R2L_DENOISE_FFT)
     return r2l_fail(-4, "r2l_static_fwd: denoising must be none, gaussian_denoising, median_denoising or fft_denoising");
   if (!(gamma > 0)) return r2l_fail(-1, "r2l_static_fwd: gamma must be > 0");
+  if (const char* why = r2l_static_opts_problem(opt, sharpening, denoising)) return r2l_fail(-4, std::string("r2l_static_fwd: ") + why);
   R2LStaticArgs a;
-  r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, mean_std_host);
+  r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, mean_std_host, opt);
   const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
 #ifndef R2L_SERIAL
   if (r2l_static_is_chain(W, debayer, sharpening, denoising)) {
@@ -1600,7 +1644,8 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     double* spec = (double*)((char*)workspace + L.spec_off);
     sa.lin_out = rgb;
     if (int e = stream_pass(sa)) return e;
-    const int cut0 = (int)(W * 0.3), cut1 = (int)(W * (1 - 0.3));  // int(c * keep_fraction), int(c * (1 - keep_fraction))
+    // int(c * keep_fraction), int(c * (1 - keep_fraction)) (pipeline_numpy.py:229-230; default 0.3)
+    const int cut0 = (int)(W * opt.fft_fraction), cut1 = (int)(W * (1 - opt.fft_fraction));
 #ifdef R2L_EMUL
     (void)spec;
     r2l_fft_lowpass_rows_host(rgb, L.rows, W, cut0, cut1);
@@ -1742,9 +1787,36 @@ int r2l_static_fwd_u16(const unsigned short* raw, float denom, float* out, int B
   return r2l_static_fwd_impl(r2l_raw_u16(raw, denom), out, B, H, W, camera_host, debayer, sharpening, denoising,
                              gamma, workspace, workspace_bytes, stream);
 }
+static int r2l_static_fwd_any(const void* raw, int frames, float denom, float* out, int B, int H, int W,
+                              const double* camera_host, int debayer, int sharpening, int denoising, double gamma,
+                              const float* mean_std_host, const R2LStaticOpts& opt, void* workspace, size_t workspace_bytes,
+                              void* stream);
 int r2l_static_fwd_norm(const void* raw, int frames, float denom, float* out, int B, int H, int W,
                         const double* camera_host, int debayer, int sharpening, int denoising, double gamma,
                         const float* mean_std_host, void* workspace, size_t workspace_bytes, void* stream) {
+  return r2l_static_fwd_any(raw, frames, denom, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, mean_std_host,
+                            R2LStaticOpts(), workspace, workspace_bytes, stream);
+}
+int r2l_static_fwd_opts(const void* raw, int frames, float denom, float* out, int B, int H, int W,
+                        const double* camera_host, int debayer, int sharpening, int denoising, double gamma,
+                        const double* options_host, const float* mean_std_host, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  R2LStaticOpts o;
+  if (options_host) {
+    o.sharp_radius = options_host[R2L_SOPT_SHARP_RADIUS];
+    o.sharp_amount = options_host[R2L_SOPT_SHARP_AMOUNT];
+    o.gaussian_sigma = options_host[R2L_SOPT_GAUSSIAN_SIGMA];
+    o.fft_fraction = options_host[R2L_SOPT_FFT_FRACTION];
+    const double m = options_host[R2L_SOPT_MEDIAN_SIZE];
+    o.median_kernel_size = (m == (double)(int)m) ? (int)m : -1;
+  }
+  return r2l_static_fwd_any(raw, frames, denom, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, mean_std_host,
+                            o, workspace, workspace_bytes, stream);
+}
+static int r2l_static_fwd_any(const void* raw, int frames, float denom, float* out, int B, int H, int W,
+                              const double* camera_host, int debayer, int sharpening, int denoising, double gamma,
+                              const float* mean_std_host, const R2LStaticOpts& opt, void* workspace, size_t workspace_bytes,
+                              void* stream) {
   R2LRaw rw;
   if (frames == R2L_FRAMES_F32)
     rw = r2l_raw_f32((const float*)raw);
@@ -1755,7 +1827,7 @@ int r2l_static_fwd_norm(const void* raw, int frames, float denom, float* out, in
   else
     return r2l_fail(-1, "r2l_static_fwd_norm: frames must be R2L_FRAMES_F32, _U16 or _F64");
   return r2l_static_fwd_impl(rw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, workspace,
-                             workspace_bytes, stream, mean_std_host);
+                             workspace_bytes, stream, mean_std_host, opt);
 }
 
 // ---- staged (track_stages=True) entry points -------------------------------------------------------

@@ -71,9 +71,33 @@ static inline void r2l_inv3(const double* m, double* o) {
   o[8] = (a * e - b * d) / det;
 }
 
+// processing()'s numeric arguments (pipeline_numpy.py:70-73, used at :117-122); the reference's defaults
+struct R2LStaticOpts {
+  double sharp_radius = 1.0, sharp_amount = 1.0, gaussian_sigma = 0.5, fft_fraction = 0.3;
+  int median_kernel_size = 3;
+};
+// scipy.ndimage.gaussian_filter's window radius for a sigma: int(truncate * sigma + 0.5), truncate = 4.0
+static inline int r2l_scipy_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
+// what the kernels' windows can hold: a 5-tap Gaussian for gaussian_denoising (radius <= 2: sigma < 0.625), a 9-tap one behind
+// unsharp_masking (radius <= 4: sharp_radius < 1.125), the 3x3 median; 0 <= fft_fraction <= 0.5.  NULL: fine.
+static inline const char* r2l_static_opts_problem(const R2LStaticOpts& o, int sharpening, int denoising) {
+  if (denoising == R2L_DENOISE_GAUSSIAN && !(o.gaussian_sigma > 0.0 && r2l_scipy_radius(o.gaussian_sigma) <= 2))
+    return "gaussian_sigma must be in (0, 0.625): scipy's window radius int(4 sigma + 0.5) may not exceed the kernels' 2";
+  if (sharpening == R2L_SHARPEN_UNSHARP && !(o.sharp_radius > 0.0 && r2l_scipy_radius(o.sharp_radius) <= 4))
+    return "sharp_radius must be in (0, 1.125): scipy's window radius int(4 radius + 0.5) may not exceed the kernels' 4";
+  if (sharpening == R2L_SHARPEN_UNSHARP && !(o.sharp_amount == o.sharp_amount))
+    return "sharp_amount is not a number";
+  if (denoising == R2L_DENOISE_MEDIAN && o.median_kernel_size != 3)
+    return "median_kernel_size must be 3 (the kernels hold a 3x3 median network)";
+  if (denoising == R2L_DENOISE_FFT && !(o.fft_fraction >= 0.0 && o.fft_fraction <= 0.5))
+    return "fft_fraction must be in [0, 0.5] (pipeline_numpy.py:212-214)";
+  return nullptr;
+}
+
 static inline void r2l_static_setup(R2LStaticArgs& a, const R2LRaw& raw, float* out, int B, int H, int W,
                                     const double* cam, int debayer, int sharpening, int denoising,
-                                    double gamma, const float* mean_std = nullptr) {
+                                    double gamma, const float* mean_std = nullptr,
+                                    const R2LStaticOpts& opt = R2LStaticOpts()) {
   a.normalize = mean_std != nullptr;
   for (int k = 0; k < 3; ++k) {
     a.nmean[k] = mean_std ? mean_std[k] : 0.f;
@@ -110,22 +134,29 @@ static inline void r2l_static_setup(R2LStaticArgs& a, const R2LRaw& raw, float* 
   static const double KS[9] = {0, -1, 0, -1, 5, -1, 0, -1, 0};  // pipeline_numpy.py:180
   static const double ID[9] = {0, 0, 0, 0, 1, 0, 0, 0, 0};
   for (int i = 0; i < 9; ++i) a.ksharp[i] = (sharpening == R2L_SHARPEN_FILTER) ? KS[i] : ID[i];
-  if (denoising == R2L_DENOISE_GAUSSIAN) {  // scipy.ndimage.gaussian_filter(sigma=0.5): radius 2
+  if (denoising == R2L_DENOISE_GAUSSIAN) {
+    // scipy.ndimage.gaussian_filter(Y, sigma) (pipeline_numpy.py:203-209; default 0.5: radius 2): _gaussian_kernel1d over
+    // radius = int(4 sigma + 0.5) <= 2 taps each side, normalised over THAT window; taps beyond it are zero in the 5-tap frame
+    const int rad = r2l_scipy_radius(opt.gaussian_sigma);
+    const double sg = opt.gaussian_sigma;
     double w[5], s = 0;
     for (int i = 0; i < 5; ++i) {
       const double x = i - 2;
-      w[i] = exp(-0.5 / (0.5 * 0.5) * x * x);
+      w[i] = (x < -rad || x > rad) ? 0.0 : exp(-0.5 / (sg * sg) * x * x);
       s += w[i];
     }
     for (int i = 0; i < 5; ++i) a.gk[i] = w[i] / s;
   } else {
     for (int i = 0; i < 5; ++i) a.gk[i] = (i == 2) ? 1.0 : 0.0;
   }
-  {  // scipy _gaussian_kernel1d(sigma = 1, radius = int(4 * 1 + 0.5) = 4), normalised (skimage unsharp_mask, radius 1)
+  {  // skimage unsharp_mask(Y, radius, amount): scipy _gaussian_kernel1d(sigma = radius, radius = int(4 sigma + 0.5) <= 4),
+     // normalised over its own window (defaults: sigma 1, 9 taps, amount 1)
+    const double sg = sharpening == R2L_SHARPEN_UNSHARP ? opt.sharp_radius : 1.0;  // (unused by any other chain)
+    const int rad = r2l_scipy_radius(sg);
     double w[9], sum = 0;
-    for (int k = -4; k <= 4; ++k) sum += (w[k + 4] = exp(-0.5 * k * k));
+    for (int k = -4; k <= 4; ++k) sum += (w[k + 4] = (k < -rad || k > rad) ? 0.0 : exp(-0.5 / (sg * sg) * k * k));
     for (int k = 0; k <= 4; ++k) a.uk[k] = w[4 + k] / sum;
-    a.amount = 1.0;
+    a.amount = sharpening == R2L_SHARPEN_UNSHARP ? opt.sharp_amount : 1.0;
   }
   a.inv_gamma = (float)(1.0 / gamma);
 }

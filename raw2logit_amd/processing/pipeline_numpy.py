@@ -32,20 +32,17 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
     a float32 frame (what the reference's datasets hand over, dataset.py:86-87; docstring :57) gets the
     float32 subtraction, a float64 frame the float64 one -- on the device exactly as in the caller's array.
     Option strings that name no algorithm skip their stage (the signature default denoising="median_filter"
-    is one)."""
-    if gaussian_sigma != 0.5 and denoising == 'gaussian_denoising':
-        raise NotImplementedError('only gaussian_sigma=0.5 (the reference default) is built')
-    if median_kernel_size != 3 and denoising == 'median_denoising':
-        raise NotImplementedError('only median_kernel_size=3 (the reference default) is built')
-    if (sharp_radius != 1.0 or sharp_amount != 1.0) and sharpening == 'unsharp_masking':
-        raise NotImplementedError('only sharp_radius=1.0, sharp_amount=1.0 (the reference defaults) are built')
-    if fft_fraction != 0.3 and denoising == 'fft_denoising':
-        raise NotImplementedError('only fft_fraction=0.3 (the reference default) is built')
+    is one).  sharp_radius / sharp_amount / median_kernel_size / gaussian_sigma / fft_fraction (:117-122) are launch
+    arguments of the kernels, within what their windows hold (functional.static_pipeline: gaussian_sigma < 0.625,
+    sharp_radius < 1.125, median_kernel_size 3, fft_fraction in [0, 0.5]; anything else raises R2LError with the reason --
+    INTEGRATION.md); weight_chambolle / weight_bregman / sigma_bilateral belong to denoisers this library does not build."""
     if not (isinstance(img, np.ndarray) and img.dtype in (np.float32, np.float64)):
         raise TypeError('processing() takes a float32 or float64 ndarray (dataset.py:86-87 delivers float32)')
     raw = torch.from_numpy(np.ascontiguousarray(img))[None].to(_device())
     out = F_.static_pipeline(raw, (black_level, white_balance, colour_matrix), debayer=debayer,
-                             sharpening=sharpening, denoising=denoising, gamma=gamma)
+                             sharpening=sharpening, denoising=denoising, gamma=gamma, sharp_radius=sharp_radius,
+                             sharp_amount=sharp_amount, median_kernel_size=median_kernel_size,
+                             gaussian_sigma=gaussian_sigma, fft_fraction=fft_fraction)
     img[0::2, 0::2] -= black_level[0]      # side effect of remove_blacklv on the caller's array
     img[0::2, 1::2] -= black_level[1]
     img[1::2, 0::2] -= black_level[2]
@@ -82,8 +79,12 @@ class StaticProcessing(nn.Module):
     raw_bits = 16
 
     def __init__(self, camera_parameters, debayer='bilinear', sharpening='sharpening_filter',
-                 denoising='gaussian_denoising', gamma=2.2, mean=None, std=None):
+                 denoising='gaussian_denoising', gamma=2.2, mean=None, std=None, **options):
         super().__init__()
+        unknown = set(options) - set(F_.STATIC_OPTION_DEFAULTS)
+        if unknown:
+            raise TypeError(f'unknown static options {sorted(unknown)} (have: {sorted(F_.STATIC_OPTION_DEFAULTS)})')
+        self.options = dict(options)          # processing()'s numeric arguments (pipeline_numpy.py:70-73), see static_pipeline
         self.camera_parameters = tuple(list(map(float, p)) for p in camera_parameters)
         self.debayer = debayer
         self.sharpening = sharpening
@@ -103,7 +104,8 @@ class StaticProcessing(nn.Module):
         self.stages = {}
         self.buffer = {}
         rgb = F_.static_pipeline(raw, self.camera_parameters, self.debayer, self.sharpening,
-                                 self.denoising, self.gamma, bits=self.raw_bits, mean_std=self._mean_std_host())
+                                 self.denoising, self.gamma, bits=self.raw_bits, mean_std=self._mean_std_host(),
+                                 **getattr(self, 'options', {}))
         self.buffer['processed_rgb'] = rgb
         return rgb
 

@@ -102,7 +102,7 @@ def golden():
     import numpy as np
     d = os.path.join(REPO, 'tests', 'golden')
     return {n: np.load(os.path.join(d, n + '.npz'), allow_pickle=False)
-            for n in ('param_cases', 'raw2rgb', 'static_cases', 'harness', 'aux_losses')}
+            for n in ('param_cases', 'raw2rgb', 'static_cases', 'static_opts', 'harness', 'aux_losses')}
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):

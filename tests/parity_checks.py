@@ -550,6 +550,54 @@ def check_static_wrappers(golden, device):
         assert e <= 1e-5, (name, e)
 
 
+def check_static_options(golden, device):
+    """processing()'s numeric arguments (pipeline_numpy.py:70-73, used at :117-122) as launch arguments of the static kernels
+    (r2l_static_fwd_opts): every STATIC_OPT_CASES entry against what the reference's own processing() returned, through the batched
+    op, the per-image processing() wrapper and the StaticProcessing module; values outside what the kernels' windows hold raise
+    with the reason -- only where the chain uses the option (the reference's if-chains ignore the rest)."""
+    from oracle.golden_cases import STATIC_OPT_CASES
+    from raw2logit_amd import _lib
+    g = golden['static_opts']
+    for case in STATIC_OPT_CASES:
+        name = case['name']
+        cam = orc.CAMERAS[case['camera']]
+        raw_np = g[name + '/raw']
+        ref = g[name + '/out_hwc_f64'].transpose(0, 3, 1, 2)
+        if raw_np.shape[-1] % 4 and (raw_np.dtype == np.float64):
+            continue
+        out = F_.static_pipeline(torch.from_numpy(raw_np).to(device), cam, case['debayer'], case['sharpening'],
+                                 case['denoising'], **case['opts']).cpu().numpy()
+        e = np.abs(out - ref).max()
+        report(f'static-options/{name} {case["opts"]}', e, 1e-5)
+        assert e <= 1e-5, (name, e)
+        img = raw_np[0].copy()
+        o1 = ppn.processing(img, *cam, debayer=case['debayer'], sharpening=case['sharpening'], denoising=case['denoising'],
+                            **case['opts'])
+        assert np.abs(o1 - g[name + '/out_hwc_f64'][0]).max() <= 1e-5, name
+        mod = ppn.StaticProcessing(cam, case['debayer'], case['sharpening'], case['denoising'], **case['opts'])
+        assert torch.equal(mod(torch.from_numpy(raw_np).to(device)).cpu(), torch.from_numpy(out)), name
+    raw = torch.from_numpy(orc.synth_raw(1, 16, 16, seed=1, kind='scene')).to(device)
+    cam = orc.DRONE_CAMERA_PARAMS
+    bad = [(('bilinear', 'none', 'gaussian_denoising'), dict(gaussian_sigma=0.7), 'gaussian_sigma'),
+           (('bilinear', 'none', 'gaussian_denoising'), dict(gaussian_sigma=0.0), 'gaussian_sigma'),
+           (('bilinear', 'unsharp_masking', 'none'), dict(sharp_radius=1.2), 'sharp_radius'),
+           (('bilinear', 'sharpening_filter', 'median_denoising'), dict(median_kernel_size=5), 'median_kernel_size'),
+           (('bilinear', 'none', 'fft_denoising'), dict(fft_fraction=0.6), 'fft_fraction')]
+    for chain, opts, word in bad:
+        try:
+            F_.static_pipeline(raw, cam, *chain, **opts)
+        except _lib.R2LError as e:
+            assert word in str(e), (opts, str(e))
+        else:
+            raise AssertionError(f'{opts} on {chain} must raise')
+    try:
+        ppn.StaticProcessing(cam, sharp_radios=1.0)
+    except TypeError:
+        pass
+    else:
+        raise AssertionError('an unknown option name must raise TypeError')
+
+
 def check_static_combinations(device):
     """every demosaic x sharpening x denoising combination the device builds (single-launch chains and
     luma-plane passes) against the oracle (the reference's own arithmetic on scipy), float32 and 16-bit input."""

@@ -69,6 +69,10 @@ def test_static_chain_combinations(emulation):
     pc.check_static_combinations('cpu')
 
 
+def test_static_numeric_arguments(golden, emulation):
+    pc.check_static_options(golden, 'cpu')
+
+
 def test_static_normalize_epilogue(emulation):
     pc.check_static_normalize('cpu')
 

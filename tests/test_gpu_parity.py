@@ -434,6 +434,10 @@ def test_static_chain_combinations(dev):
     pc.check_static_combinations(dev)
 
 
+def test_static_numeric_arguments(golden, dev):
+    pc.check_static_options(golden, dev)
+
+
 def test_static_normalize_epilogue(dev):
     pc.check_static_normalize(dev)
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import isp_oracle as orc
-from oracle.golden_cases import PARAM_CASES, RAW2RGB_CASES, STATIC_CASES, SAMPLE_STRIDE
+from oracle.golden_cases import PARAM_CASES, RAW2RGB_CASES, STATIC_CASES, STATIC_OPT_CASES, SAMPLE_STRIDE
 from oracle.gen_golden import build_params
 
 
@@ -123,6 +123,23 @@ def test_static_oracle_matches_reference(case, golden):
     chw = orc.static_batch(raw[:1], orc.CAMERAS[case['camera']], case['debayer'], case['sharpening'],
                            case['denoising'])[0]
     np.testing.assert_allclose(chw, g[case['name'] + '/pipeline_chw_f32'], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize('case', STATIC_OPT_CASES, ids=[c['name'] for c in STATIC_OPT_CASES])
+def test_static_oracle_numeric_arguments_match_reference(case, golden):
+    """processing()'s numeric arguments (pipeline_numpy.py:70-73, :117-122) away from their defaults: the oracle against what
+    the reference's own processing() returned for them (tests/golden/static_opts.npz)"""
+    from oracle.golden_cases import static_case_frames
+    g = golden['static_opts']
+    raw, _ = static_case_frames(case)
+    assert np.array_equal(raw, g[case['name'] + '/raw'])
+    out = np.stack([orc.processing(img.copy(), *orc.CAMERAS[case['camera']], debayer=case['debayer'],
+                                   sharpening=case['sharpening'], denoising=case['denoising'], **case['opts']) for img in raw])
+    np.testing.assert_allclose(out, g[case['name'] + '/out_hwc_f64'], rtol=0, atol=1e-12)
+    if case['name'] != 'opt_ignored_on_short_chain':     # the fixture can tell the options from the defaults
+        dflt = np.stack([orc.processing(img.copy(), *orc.CAMERAS[case['camera']], debayer=case['debayer'],
+                                        sharpening=case['sharpening'], denoising=case['denoising']) for img in raw])
+        assert np.abs(dflt - g[case['name'] + '/out_hwc_f64']).max() > 1e-4
 
 
 def test_reference_constants_pin_the_third_party_restatements():
