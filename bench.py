@@ -550,12 +550,19 @@ def fallback_records(torch, lib, clock, dev, cameras, ParametrizedProcessing):
     a frame width with W % 4 != 0.  fwd+bwd, BatchNorm train mode, eager; kernels from the HIP-event hooks."""
     from raw2logit_amd.processing.pipeline_torch import append_additive_layer
     recs = []
-    for what, (B, H, W), additive in (('additive layer (train.py --adv_noise_layer)', (64, 256, 256), True),
-                                      ('W % 4 != 0', (64, 256, 254), False)):
+    for what, (B, H, W), additive, track in (
+            ('additive layer (train.py --adv_noise_layer)', (64, 256, 256), True, False),
+            ('W % 4 != 0', (64, 256, 254), False, False),
+            ('frame sides not multiples of 64 (tile kernels of the backward below 4 Mi px)', (64, 200, 200), False, False),
+            # model.py:228 (track_images: inputs.requires_grad = True) and track_stages=True: the stage-by-stage kernels, every
+            # stage a tensor autograd holds, d/d raw produced (the fused kernels do not write it)
+            ('track_stages=True with frames requiring grad (model.py:204-254): staged kernels, d/d raw', (64, 256, 256), False, True)):
         gen = torch.Generator(dev).manual_seed(0)
         raw = torch.randint(0, 4096, (B, H, W), device=dev, generator=gen, dtype=torch.int32).to(torch.float32) / 4095.0
+        if track:
+            raw.requires_grad_(True)
         cot = torch.randn((B, 3, H, W), device=dev, generator=gen)
-        model = ParametrizedProcessing(cameras.DRONE, track_stages=False, batch_norm_output=True)
+        model = ParametrizedProcessing(cameras.DRONE, track_stages=track, batch_norm_output=True)
         if additive:
             append_additive_layer(model)
         model = model.to(dev).train()
@@ -564,6 +571,7 @@ def fallback_records(torch, lib, clock, dev, cameras, ParametrizedProcessing):
         def step():
             for p in params:
                 p.grad = None
+            raw.grad = None
             model(raw).backward(cot)
         clock.preroll(step, None, 0.05)
         dt = clock.time_steps(step, 50, 10)

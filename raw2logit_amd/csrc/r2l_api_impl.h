@@ -238,6 +238,8 @@ R2L_KERNEL(r2l_launch_reduce_rows, R2LReduceRowsArgs, r2l_reduce_rows_block, 2 *
 R2L_KERNEL_V(r2l_launch_fwd, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, false>)
 R2L_KERNEL_V(r2l_launch_fwd_ragged, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true, false>)
 R2L_KERNEL_V(r2l_launch_fwd_add, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, true, true, false>)
+// the additive layer on frames that tile exactly -- the reference's only case: its layer is 256 x 256 (pipeline_torch.py:130)
+R2L_KERNEL_V(r2l_launch_fwd_add_exact, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, true, false, false>)
 #ifndef R2L_SERIAL
 // the forward as a row-streaming kernel (r2l_param_stream.h): NW wavefronts side by side cover 256 * NW columns
 #ifndef R2L_FS_OCC
@@ -322,10 +324,11 @@ R2L_KERNEL_V(r2l_launch_bwd1_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_b
 #define R2L_OCC_BWD1S 1
 #endif
 R2L_KERNEL_V(r2l_launch_bwd1_saved, R2LBwd1Args, R2L_LDS3(GBwd1) + GBwd1::PAD + R2L_B1_FRAME_FLOATS, R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, false, true>)
-R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, true, false, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_saved_u16, R2LBwd1Args, R2L_LDS3(GBwd1) + GBwd1::PAD + R2L_B1_FRAME_FLOATS, R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, false, true, true>)
-R2L_KERNEL_V(r2l_launch_bwd1_saved_ragged_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1S, r2l_bwd1_block<GBwd1, false, true, true, true>)
+// (frames that do not tile by 64 below 4 Mi px take r2l_launch_bwd1_ragged -- Y' recomputed in LDS -- also when the forward kept
+// Y': the kept-plane form of the general instantiation needed 76 B of scratch per lane, round 6)
 R2L_KERNEL_V(r2l_launch_bwd1_add, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, false>)
+R2L_KERNEL_V(r2l_launch_bwd1_add_exact, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, false, false>)
 #ifndef R2L_SERIAL
 // kernel B1 as two passes over planes (r2l_param_plane_bwd.h): where the forward kept Y' and no epilogue / additive layer
 R2L_KERNEL_NT_LDS(r2l_launch_bwd1_plane, R2LBwd1Args, R2L_BP_NT, R2L_BP_LDS_FLOATS, 2, r2l_bwd1_plane_block<false, false>)
@@ -355,9 +358,11 @@ R2L_KERNEL_V(r2l_launch_bwd2, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bw
 R2L_KERNEL_V(r2l_launch_fwd_u16, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, false, false, true>)
 R2L_KERNEL_V(r2l_launch_fwd_ragged_u16, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, false, true, true>)
 R2L_KERNEL_V(r2l_launch_fwd_add_u16, R2LFwdArgs, R2L_LDS3(GFwd), 2, r2l_fwd_block<GFwd, true, true, true>)
+R2L_KERNEL_V(r2l_launch_fwd_add_exact_u16, R2LFwdArgs, R2L_LDS3(GFwd), R2L_OCC_FWD, r2l_fwd_block<GFwd, true, false, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_u16, R2LBwd1Args, R2L_LDS3(GBwd1), R2L_OCC_BWD1, r2l_bwd1_block<GBwd1, false, false, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_ragged_u16, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, false, true, true>)
 R2L_KERNEL_V(r2l_launch_bwd1_add_u16, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, true, true>)
+R2L_KERNEL_V(r2l_launch_bwd1_add_exact_u16, R2LBwd1Args, R2L_LDS3(GBwd1), 2, r2l_bwd1_block<GBwd1, true, false, true>)
 R2L_KERNEL_V(r2l_launch_bwd2_u16, R2LBwd2Args, R2L_LDS3(GBwd2), R2L_OCC_BWD2, r2l_bwd2_block<GBwd2, true>)
 // 14 KB of LDS instead of 68 KB: 8 workgroups' worth of loads in flight per CU instead of 2
 R2L_KERNEL_OCC(r2l_launch_bn_reduce, R2LBnReduceArgs, r2l_bn_reduce_block, R2L_RED_FLOATS_N(6), 8)
@@ -887,10 +892,10 @@ static int r2l_isp_fwd_impl(const R2LRaw& raw, const float* params, const float*
   const bool exact = (H % GFwd::TH == 0) && (W % GFwd::TW == 0);
   int e;
   if (raw.u16)
-    e = additive ? r2l_launch_fwd_add_u16(a, grid, stream)
+    e = additive ? (exact ? r2l_launch_fwd_add_exact_u16(a, grid, stream) : r2l_launch_fwd_add_u16(a, grid, stream))
                  : (exact ? r2l_launch_fwd_u16(a, grid, stream) : r2l_launch_fwd_ragged_u16(a, grid, stream));
   else
-    e = additive ? r2l_launch_fwd_add(a, grid, stream)
+    e = additive ? (exact ? r2l_launch_fwd_add_exact(a, grid, stream) : r2l_launch_fwd_add(a, grid, stream))
                  : (exact ? r2l_launch_fwd(a, grid, stream) : r2l_launch_fwd_ragged(a, grid, stream));
   if (e) return e;
   return 0;
@@ -1017,14 +1022,13 @@ static int r2l_isp_bwd_impl(const R2LRaw& raw, const float* params, const float*
 #else
     e1 = 0;
 #endif
-  } else if (saved)
-    e1 = raw.u16 ? (exact ? r2l_launch_bwd1_saved_u16(a1, g1, stream) : r2l_launch_bwd1_saved_ragged_u16(a1, g1, stream))
-                 : (exact ? r2l_launch_bwd1_saved(a1, g1, stream) : r2l_launch_bwd1_saved_ragged(a1, g1, stream));
-  else if (raw.u16)
-    e1 = additive ? r2l_launch_bwd1_add_u16(a1, g1, stream)
+  } else if (saved && exact)
+    e1 = raw.u16 ? r2l_launch_bwd1_saved_u16(a1, g1, stream) : r2l_launch_bwd1_saved(a1, g1, stream);
+  else if (raw.u16)   // (frames that do not tile by 64: Y' recomputed in LDS, kept or not -- a1.yp is not read)
+    e1 = additive ? (exact ? r2l_launch_bwd1_add_exact_u16(a1, g1, stream) : r2l_launch_bwd1_add_u16(a1, g1, stream))
                   : (exact ? r2l_launch_bwd1_u16(a1, g1, stream) : r2l_launch_bwd1_ragged_u16(a1, g1, stream));
   else
-    e1 = additive ? r2l_launch_bwd1_add(a1, g1, stream)
+    e1 = additive ? (exact ? r2l_launch_bwd1_add_exact(a1, g1, stream) : r2l_launch_bwd1_add(a1, g1, stream))
                   : (exact ? r2l_launch_bwd1(a1, g1, stream) : r2l_launch_bwd1_ragged(a1, g1, stream));
   if (e1) return e1;
   const int ntiles2 = B * ((H + GBwd2::TH - 1) / GBwd2::TH) * ((W + GBwd2::TW - 1) / GBwd2::TW);

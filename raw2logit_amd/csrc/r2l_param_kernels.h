@@ -1099,7 +1099,8 @@ R2L_HD void r2l_fwd_pixels(int tid, const float* V, const float* YP, const R2LFw
 
 
 #ifndef R2L_FWD_L
-#define R2L_FWD_L 16  // phases of the forward tile loop that launder tid (bit 4: the pixel phase): 123 VGPRs, no scratch
+#define R2L_FWD_L 17  // phases of the forward tile loop that launder tid (bit 0: the store phase, bit 4: the pixel phase): 121 VGPRs, no scratch
+                      // (round 6: 16 alone had crept back to 128 VGPRs + 12 B of scratch)
 #endif
 template <class G, bool ADD, bool MAYBE_RAGGED, bool U16>
 R2L_BLOCKFN void r2l_fwd_block(const R2LFwdArgs& a, int bid, int nblk, float* lds) {
@@ -1450,6 +1451,7 @@ R2L_HD void r2l_bwd1_row(const float* V, const float* YP, const R2LBwd1Args& a, 
       // torch.clip backward: the gradient passes where 1e-5 <= rgb <= 1, i.e. where clipping left rgb unchanged
       grgb[k][p] = r2l_mk2((rgb[0] == xc[0]) ? gc[0] : 0.f, (rgb[1] == xc[1]) ? gc[1] : 0.f);
     }
+    if (RAGGED) R2L_SCHED_FENCE();  // one channel at a time: the general instantiations have no register to spare for overlap
   }
   r2l_p2 gy2[2], gu[2], gv[2];  // d loss / d (Y'', U, V)
   R2L_PRAGMA_UNROLL
@@ -1691,6 +1693,9 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   constexpr bool GLDS = SAVED && !MAYBE_RAGGED && !ADD && (R2L_B1_GLDS != 0);
   static_assert(!GLDS || G::FH * G::FW + 256 == R2L_B1_FRAME_FLOATS, "staging area of a frame");
   float* YS = GLDS ? YP + G::PLANE + G::PAD : nullptr;
+  // additive layer on frames that do not tile by 64 (never the reference's: its layer is 256 x 256, pipeline_torch.py:130): no
+  // register to spare across the pixel phase -- the raw frame of a tile is fetched when the tile starts, not a tile ahead
+  constexpr bool LATE_RAW = ADD && MAYBE_RAGGED;
   R2LTileWalk w = r2l_walk_init(a.B, a.H, a.W, G::TW, G::TH, bid, nblk);
   R2LTile t, tn;
   bool have = r2l_walk_next(w, a.H, a.W, G::TW, G::TH, t);
@@ -1701,7 +1706,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     int tx_, row_;
     G::thread_tile(tid, tx_, row_, R2L_TREG(regs).py);
   }
-  if (have) r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
+  if (!LATE_RAW && have) r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));
   if (SAVED && !GLDS && have) r2l_fetch_tile<G, 1>(tid, a.yp, t, a.H, a.W, R2L_TREG(pre_yp));
   if (GLDS && have) {
     r2l_stage_frame<G>(tid, a.yp + (size_t)t.b * a.H * a.W, t.oy, t.ox, a.H, a.W, YS);
@@ -1711,6 +1716,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
   R2L_STAMP_DECL
   while (have) {
     R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
+    if (LATE_RAW) r2l_fetch_raw_tile<G, U16>(tid, a.raw, t, a.H, a.W, R2L_TREG(pre));  // (no prefetch: see LATE_RAW)
     r2l_store_v<G, U16>(tid, V, F, R2L_TREG(pre), a.raw);
     if (GLDS)
       r2l_store_plane_s2_staged<G>(tid, YP, YS, t.oy, t.ox, a.H, a.W);
@@ -1751,7 +1757,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
     R2L_STAMP(3)
     }
     R2L_PHASE_BEGIN_IF(ADD || MAYBE_RAGGED)
-    if (haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
+    if (!LATE_RAW && haven) r2l_fetch_raw_tile<G, U16>(tid, a.raw, tn, a.H, a.W, R2L_TREG(pre));
     if (GLDS) {
       // the next tile's Y' frame: one copy per lane behind each of the first window rows of the blur-weight correlation
       // (as a burst all 8 wavefronts would reach them together and queue in the texture-address path).  After the last
@@ -1765,7 +1771,7 @@ R2L_BLOCKFN void r2l_bwd1_block(const R2LBwd1Args& a, int bid, int nblk, float* 
       r2l_glds_wait();  // this wave's copies have landed; behind the phase barrier every wave's have
     } else {
       auto nomid = [](int) {};
-      if (MAYBE_RAGGED && t.ragged)
+      if (MAYBE_RAGGED)
         r2l_bwd1_pixels<G, MAYBE_RAGGED, ADD, false>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs), nomid R2L_SUB_PASS);
       else
         r2l_bwd1_pixels<G, false, ADD, !MAYBE_RAGGED>(tid, V, YP, a, t, R2L_TREG(gpre), R2L_TREG(regs), nomid R2L_SUB_PASS);
