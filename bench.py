@@ -161,7 +161,7 @@ def parse():
                          'e2e-microscopy = BASELINE config 4: ISP (Microscopy parameters) + ResNet-18, CE loss, Adam '
                          'step, 128x256x256 per GPU; e2e-drone = config 5: ISP (Drone parameters) + U-Net, Dice loss, '
                          '64x256x256 per GPU (512 over 8 GPUs)')
-    ap.add_argument('--debayer', choices=('bilinear', 'malvar2004'), default='bilinear')
+    ap.add_argument('--debayer', choices=('bilinear', 'malvar2004', 'menon2007'), default='bilinear')
     ap.add_argument('--sharpening', default='none', help="static workload: 'none' | 'sharpening_filter' | 'unsharp_masking'")
     ap.add_argument('--denoising', default='none', help="static workload: 'none' | 'gaussian_denoising' | 'median_denoising'")
     ap.add_argument('--normalize', action='store_true',

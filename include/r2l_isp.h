@@ -56,7 +56,9 @@ enum {
 };
 
 /* static-pipeline selectors (processing/pipeline_numpy.py:92-122) */
-enum { R2L_DEBAYER_BILINEAR = 0, R2L_DEBAYER_MALVAR2004 = 1 };
+enum { R2L_DEBAYER_BILINEAR = 0, R2L_DEBAYER_MALVAR2004 = 1,
+       R2L_DEBAYER_MENON2007 = 2 /* DDFAPD with the refining step (pipeline_numpy.py:96-97); float64 plane passes, W % 4 == 0,
+                                    workspace from r2l_static_workspace_bytes(); third-party algorithm, parity unpinned */ };
 enum { R2L_SHARPEN_NONE = 0, R2L_SHARPEN_FILTER = 1, R2L_SHARPEN_UNSHARP = 2 };
 enum { R2L_DENOISE_NONE = 0, R2L_DENOISE_GAUSSIAN = 1, R2L_DENOISE_MEDIAN = 2, R2L_DENOISE_FFT = 3 };
 

@@ -50,7 +50,7 @@ def import_reference():
     cd = sys.modules['colour_demosaicing']
     cd.demosaicing_CFA_Bayer_bilinear = orc.demosaicing_CFA_Bayer_bilinear
     cd.demosaicing_CFA_Bayer_Malvar2004 = orc.demosaicing_CFA_Bayer_Malvar2004
-    cd.demosaicing_CFA_Bayer_Menon2007 = None
+    cd.demosaicing_CFA_Bayer_Menon2007 = orc.demosaicing_CFA_Bayer_Menon2007
     sys.modules['dataset'].Subset = object
     sys.modules['utils.base'].np2torch = None
     sys.modules['utils.base'].torch2np = None

@@ -131,6 +131,17 @@ STATIC_CASES = [
          dtype='float32', debayer='malvar2004', sharpening='unsharp_masking', denoising='fft_denoising'),
     dict(name='f64_micro_fft_uniform', seed=29, shape=(1, 16, 64), kind='uniform', camera='microscopy',
          dtype='float64', debayer='bilinear', sharpening='none', denoising='fft_denoising'),
+    # menon2007 (pipeline_numpy.py:96-97): the reference's processing() around the restated third-party demosaic (unpinned)
+    dict(name='f32_drone_menon_short', seed=30, shape=(2, 32, 40), kind='scene', camera='drone', dtype='float32',
+         debayer='menon2007', sharpening='none', denoising='none'),
+    dict(name='f32_drone_menon_default_dark', seed=31, shape=(1, 24, 32), kind='dark', camera='drone', dtype='float32',
+         debayer='menon2007', sharpening='sharpening_filter', denoising='gaussian_denoising'),
+    dict(name='f64_micro_menon_unsharp_median', seed=32, shape=(1, 32, 32), kind='uniform', camera='microscopy',
+         dtype='float64', debayer='menon2007', sharpening='unsharp_masking', denoising='median_denoising'),
+    dict(name='u16_drone_menon_fft_12bit', seed=33, shape=(1, 16, 48), kind='scene', camera='drone', dtype='float32',
+         bits=12, debayer='menon2007', sharpening='sharpening_filter', denoising='fft_denoising'),
+    dict(name='f32_drone_menon_tiny', seed=34, shape=(1, 4, 4), kind='uniform', camera='drone', dtype='float32',
+         debayer='menon2007', sharpening='none', denoising='none'),
 ]
 
 

@@ -36,8 +36,8 @@ Pinning status
   Three pieces of arithmetic live in third-party packages that are NOT vendored in the reference
   tree and are NOT installed in this image -- for those the parity is UNPINNED and rests on the
   published algorithm, restated below:
-    - colour-demosaicing==0.1.6 (environment.yml:296): demosaicing_CFA_Bayer_bilinear and
-      demosaicing_CFA_Bayer_Malvar2004 (call sites pipeline_numpy.py:92-95).  Bilinear is partially
+    - colour-demosaicing==0.1.6 (environment.yml:296): demosaicing_CFA_Bayer_bilinear,
+      demosaicing_CFA_Bayer_Malvar2004 and demosaicing_CFA_Bayer_Menon2007 (call sites pipeline_numpy.py:92-97).  Bilinear is partially
       pinned by the reference's own K_G / K_RB restatement (pipeline_torch.py:13-19).
     - scikit-image==0.18.1 (environment.yml:343): rgb2yuv / yuv2rgb (call sites :184-189, :205-207).
       Pinned by M_RGB_2_YUV / M_YUV_2_RGB in pipeline_torch.py:21-26 (inverse agrees to 3.8e-8).
@@ -548,6 +548,105 @@ def demosaicing_CFA_Bayer_Malvar2004(CFA):
     return np.stack([R, G, B], axis=-1)
 
 
+def _cnv_h(x, y):
+    """colour-demosaicing 0.1.6 `_cnv_h`: scipy.ndimage convolve1d along the columns, mode='mirror' (d c b | a b c d | c b a)"""
+    from scipy.ndimage import convolve1d
+    return convolve1d(x, y, mode='mirror')
+
+
+def _cnv_v(x, y):
+    from scipy.ndimage import convolve1d
+    return convolve1d(x, y, mode='mirror', axis=0)
+
+
+def demosaicing_CFA_Bayer_Menon2007(CFA, refining_step=True):
+    """colour-demosaicing 0.1.6 `demosaicing_CFA_Bayer_Menon2007(CFA, 'RGGB', refining_step=True)` [published algorithm:
+    Menon, Andriani, Calvagno, "Demosaicing With Directional Filtering and a posteriori Decision", IEEE TIP 2007 (DDFAPD);
+    restated from the package's published source; UNPINNED like the other two demosaics -- the package is neither vendored in
+    the reference tree nor installed here, and nothing in the reference pins its output].  Call site: pipeline_numpy.py:96-97.
+
+    1. green by directional 5-tap filters, horizontally (G_H) and vertically (G_V), at the red / blue sites;
+    2. chrominance differences C_H / C_V at those sites, their gradients D_H / D_V two samples ahead, summed over the 5x5
+       kernel k (and its transpose) into the classifiers d_H / d_V; the direction with the SMALLER classifier wins (M = 1:
+       horizontal) -- the a-posteriori decision;
+    3. red / blue at the green sites from the two neighbours of their row resp. column (bilinear on the colour difference),
+       red at the blue sites (and vice versa) along the decided direction;
+    4. the refining step: green at the red / blue sites from the 3-tap mean of R - G (B - G) along the decided direction, then
+       red / blue at the green sites and at the opposite sites again from the refined differences."""
+    from scipy.ndimage import convolve
+    CFA = np.asarray(CFA, dtype=np.float64)
+    Rm, Gm, Bm = masks_CFA_Bayer(CFA.shape)
+    h_0 = np.array([0, 0.5, 0, 0.5, 0])
+    h_1 = np.array([-0.25, 0, 0.5, 0, -0.25])
+    R, G, B = CFA * Rm, CFA * Gm, CFA * Bm
+    G_H = np.where(Gm == 0, _cnv_h(CFA, h_0) + _cnv_h(CFA, h_1), G)
+    G_V = np.where(Gm == 0, _cnv_v(CFA, h_0) + _cnv_v(CFA, h_1), G)
+    C_H = np.where(Rm == 1, R - G_H, 0)
+    C_H = np.where(Bm == 1, B - G_H, C_H)
+    C_V = np.where(Rm == 1, R - G_V, 0)
+    C_V = np.where(Bm == 1, B - G_V, C_V)
+    D_H = np.abs(C_H - np.pad(C_H, ((0, 0), (0, 2)), mode='reflect')[:, 2:])
+    D_V = np.abs(C_V - np.pad(C_V, ((0, 2), (0, 0)), mode='reflect')[2:, :])
+    k = np.array([[0, 0, 1, 0, 1],
+                  [0, 0, 0, 1, 0],
+                  [0, 0, 3, 0, 3],
+                  [0, 0, 0, 1, 0],
+                  [0, 0, 1, 0, 1]], dtype=np.float64)
+    d_H = convolve(D_H, k, mode='constant')
+    d_V = convolve(D_V, np.transpose(k), mode='constant')
+    mask = d_V >= d_H
+    G = np.where(mask, G_H, G_V)
+    M = np.where(mask, 1, 0)
+    R_r = np.transpose(np.any(Rm == 1, axis=1)[np.newaxis]) * np.ones(R.shape)       # red rows
+    B_r = np.transpose(np.any(Bm == 1, axis=1)[np.newaxis]) * np.ones(B.shape)       # blue rows
+    k_b = np.array([0.5, 0, 0.5])
+    R = np.where(np.logical_and(Gm == 1, R_r == 1), G + _cnv_h(R, k_b) - _cnv_h(G, k_b), R)
+    R = np.where(np.logical_and(Gm == 1, B_r == 1) == 1, G + _cnv_v(R, k_b) - _cnv_v(G, k_b), R)
+    B = np.where(np.logical_and(Gm == 1, B_r == 1), G + _cnv_h(B, k_b) - _cnv_h(G, k_b), B)
+    B = np.where(np.logical_and(Gm == 1, R_r == 1) == 1, G + _cnv_v(B, k_b) - _cnv_v(G, k_b), B)
+    R = np.where(np.logical_and(B_r == 1, Bm == 1),
+                 np.where(M == 1, B + _cnv_h(R, k_b) - _cnv_h(B, k_b), B + _cnv_v(R, k_b) - _cnv_v(B, k_b)), R)
+    B = np.where(np.logical_and(R_r == 1, Rm == 1),
+                 np.where(M == 1, R + _cnv_h(B, k_b) - _cnv_h(R, k_b), R + _cnv_v(B, k_b) - _cnv_v(R, k_b)), B)
+    if refining_step:
+        R, G, B = _refining_step_Menon2007(R, G, B, Rm, Gm, Bm, M)
+    return np.stack([R, G, B], axis=-1)
+
+
+def _refining_step_Menon2007(R, G, B, Rm, Gm, Bm, M):
+    """colour-demosaicing 0.1.6 `refining_step_Menon2007` [published algorithm; UNPINNED]"""
+    M = np.asarray(M, dtype=np.float64)
+    # green at the red / blue sites
+    R_G, B_G = R - G, B - G
+    FIR = np.ones(3) / 3
+    B_G_m = np.where(Bm == 1, np.where(M == 1, _cnv_h(B_G, FIR), _cnv_v(B_G, FIR)), 0)
+    R_G_m = np.where(Rm == 1, np.where(M == 1, _cnv_h(R_G, FIR), _cnv_v(R_G, FIR)), 0)
+    G = np.where(Rm == 1, R - R_G_m, G)
+    G = np.where(Bm == 1, B - B_G_m, G)
+    # red / blue at the green sites
+    R_r = np.transpose(np.any(Rm == 1, axis=1)[np.newaxis]) * np.ones(R.shape)
+    R_c = np.any(Rm == 1, axis=0)[np.newaxis] * np.ones(R.shape)
+    B_r = np.transpose(np.any(Bm == 1, axis=1)[np.newaxis]) * np.ones(B.shape)
+    B_c = np.any(Bm == 1, axis=0)[np.newaxis] * np.ones(B.shape)
+    R_G, B_G = R - G, B - G
+    k_b = np.array([0.5, 0, 0.5])
+    R_G_m = np.where(np.logical_and(Gm == 1, B_r == 1), _cnv_v(R_G, k_b), R_G_m)
+    R = np.where(np.logical_and(Gm == 1, B_r == 1), G + R_G_m, R)
+    R_G_m = np.where(np.logical_and(Gm == 1, B_c == 1), _cnv_h(R_G, k_b), R_G_m)
+    R = np.where(np.logical_and(Gm == 1, B_c == 1), G + R_G_m, R)
+    B_G_m = np.where(np.logical_and(Gm == 1, R_r == 1), _cnv_v(B_G, k_b), B_G_m)
+    B = np.where(np.logical_and(Gm == 1, R_r == 1), G + B_G_m, B)
+    B_G_m = np.where(np.logical_and(Gm == 1, R_c == 1), _cnv_h(B_G, k_b), B_G_m)
+    B = np.where(np.logical_and(Gm == 1, R_c == 1), G + B_G_m, B)
+    # red at the blue sites, blue at the red sites
+    R_B = R - B
+    R_B_m = np.where(Bm == 1, np.where(M == 1, _cnv_h(R_B, FIR), _cnv_v(R_B, FIR)), 0)
+    R = np.where(Bm == 1, B + R_B_m, R)
+    R_B_m = np.where(Rm == 1, np.where(M == 1, _cnv_h(R_B, FIR), _cnv_v(R_B, FIR)), 0)
+    B = np.where(Rm == 1, R - R_B_m, B)
+    return R, G, B
+
+
 YUV_FROM_RGB = np.array([[0.299, 0.587, 0.114],
                          [-0.14714119, -0.28886916, 0.43601035],
                          [0.61497538, -0.51496512, -0.10001026]], dtype=np.float64)
@@ -662,6 +761,8 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
         img = demosaicing_CFA_Bayer_bilinear(img)
     if debayer == "malvar2004":
         img = demosaicing_CFA_Bayer_Malvar2004(img)
+    if debayer == "menon2007":
+        img = demosaicing_CFA_Bayer_Menon2007(img)                                                    # :96-97
     img = img * white_balance
     img = np.einsum('ijk,lk->ijl', img, np.array(colour_matrix).reshape(3, 3))
     if sharpening == "sharpening_filter":

@@ -20,6 +20,7 @@
 #include "r2l_static_stream.h"
 #include "r2l_static_chain.h"
 #include "r2l_static_planes.h"
+#include "r2l_static_menon.h"
 #include "r2l_staged_kernels.h"
 #include "r2l_aux_kernels.h"
 
@@ -398,6 +399,7 @@ R2L_STREAM_KERNEL(r2l_launch_static_luma_malvar_f64, 1, R2L_RAW_F64, true, 2)
 R2L_KERNEL(r2l_launch_plane_filter, R2LPlaneArgs, r2l_plane_filter_block, 4)
 R2L_KERNEL(r2l_launch_spec_mask, R2LSpecMaskArgs, r2l_spec_mask_block, 4)
 R2L_KERNEL(r2l_launch_static_finish, R2LStaticFinishArgs, r2l_static_finish_block, 4)
+R2L_KERNEL(r2l_launch_static_menon, R2LMenonArgs, r2l_static_menon_block, 4)
 #ifndef R2L_SERIAL
 // row-streaming luma chains (r2l_static_chain.h): NW wavefronts side by side cover frames up to 256 * NW columns
 #ifndef R2L_CHAIN_OCC
@@ -1377,6 +1379,7 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
 // chains the row-streaming luma-chain kernel covers (r2l_static_chain.h): bilinear + [sharpening_filter] +
 // [gaussian_denoising], frames up to 2048 columns, W % 4 == 0
 static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoising) {
+  if (debayer == R2L_DEBAYER_MENON2007) return false;
 #ifdef R2L_SERIAL
   (void)W; (void)debayer; (void)sharpening; (void)denoising;
   return false;  // (lane shifts and wave-level exchange: not expressible in the one-lane-at-a-time emulation)
@@ -1389,6 +1392,7 @@ static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoisin
 #endif
 }
 static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoising, bool f64_frames = false) {
+  if (debayer == R2L_DEBAYER_MENON2007) return false;  // always plane passes (r2l_static_menon.h)
   if (denoising == R2L_DENOISE_FFT) return false;
   if (sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE) return true;
   if (r2l_static_is_chain(W, debayer, sharpening, denoising)) return true;
@@ -1530,6 +1534,102 @@ static int r2l_fft_layout(int B, int H, int W, R2LFftLayout& L) {
   return 0;
 }
 
+// ---- Menon2007 chains (r2l_static_menon.h): the (B,3,H,W) float64 image + five (B,H,W) planes; behind them, for fft_denoising,
+// the spectrum and rocFFT's work buffer
+struct R2LMenonLayout {
+  size_t spec_off, work_off, total, rows;
+  R2LFftPlans plans;
+};
+static int r2l_menon_layout(int B, int H, int W, bool fft, R2LMenonLayout& L) {
+  const size_t px = (size_t)B * H * W;
+  L.rows = (size_t)3 * B * H;
+  L.spec_off = r2l_align_up(8 * sizeof(double) * px);
+  L.work_off = L.total = L.spec_off;
+  if (fft) {
+    L.work_off = L.spec_off + r2l_align_up(2 * sizeof(double) * L.rows * (size_t)(W / 2 + 1));
+#ifndef R2L_EMUL
+    if (int e = r2l_fft_plans(W, L.rows, L.plans)) return e;
+#endif
+    L.total = L.work_off + r2l_align_up(L.plans.work_bytes);
+  }
+  return 0;
+}
+static int r2l_static_menon_impl(const R2LStaticArgs& a, int B, int H, int W, int sharpening, int denoising,
+                                 const R2LStaticOpts& opt, void* workspace, size_t workspace_bytes, void* stream) {
+  if ((W & 3) || H < 4 || W < 4)
+    return r2l_fail(-4, "r2l_static_fwd: menon2007 runs as plane passes, which need W % 4 == 0 (and frames of at least 4 x 4)");
+  const bool fft = denoising == R2L_DENOISE_FFT;
+  R2LMenonLayout L;
+  if (int e = r2l_menon_layout(B, H, W, fft, L)) return e;
+  if (!workspace || workspace_bytes < L.total)
+    return r2l_fail(-2, "r2l_static_fwd: workspace too small (r2l_static_workspace_bytes)");
+  const size_t px = (size_t)B * H * W;
+  R2LMenonArgs ma;
+  ma.s = a;
+  ma.rgb = (double*)workspace;
+  ma.gh = ma.rgb + 3 * px;
+  ma.gv = ma.gh + px;
+  ma.ch = ma.gv + px;
+  ma.cv = ma.ch + px;
+  ma.m = ma.cv + px;
+  ma.luma = ma.gh;
+  const int ops[2] = {sharpening == R2L_SHARPEN_FILTER ? 1 : (sharpening == R2L_SHARPEN_UNSHARP ? 4 : 0),
+                      denoising == R2L_DENOISE_GAUSSIAN ? 2 : (denoising == R2L_DENOISE_MEDIAN ? 3 : 0)};
+  ma.want_luma = (ops[0] || ops[1]) ? 1 : 0;
+  for (int i = 0; i < 9; ++i) ma.M1[i] = R2L_YUV_FROM_RGB[i];
+  size_t g = (px + R2L_NT - 1) / R2L_NT;
+  if (g > 16384) g = 16384;
+  for (int st = 0; st <= 7; ++st) {
+    ma.stage = st;
+    if (int e = r2l_launch_static_menon(ma, (int)g, stream)) return e;
+  }
+  if (ma.want_luma) {
+    double* cur = ma.gh;     // G_H / G_V are dead behind stage 1: the luma plane and its ping-pong partner
+    double* other = ma.gv;
+    for (int i = 0; i < 2; ++i) {
+      if (!ops[i]) continue;
+      R2LPlaneArgs pa;
+      pa.src = cur;
+      pa.dst = other;
+      pa.B = B;
+      pa.H = H;
+      pa.W = W;
+      pa.op = ops[i];
+      for (int k = 0; k < 5; ++k) pa.gk[k] = a.gk[k];
+      for (int k = 0; k < 5; ++k) pa.uk[k] = a.uk[k];
+      pa.amount = a.amount;
+      size_t gp = (px / 2 + R2L_NT - 1) / R2L_NT;
+      if (gp > 16384) gp = 16384;
+      if (int e = r2l_launch_plane_filter(pa, (int)gp, stream)) return e;
+      double* t = cur;
+      cur = other;
+      other = t;
+    }
+    ma.stage = 8;
+    ma.luma = cur;
+    if (int e = r2l_launch_static_menon(ma, (int)g, stream)) return e;
+  }
+  if (fft) {
+    const int cut0 = (int)(W * opt.fft_fraction), cut1 = (int)(W * (1 - opt.fft_fraction));
+#ifdef R2L_EMUL
+    r2l_fft_lowpass_rows_host(ma.rgb, L.rows, W, cut0, cut1);
+#else
+    double* spec = (double*)((char*)workspace + L.spec_off);
+    void* work = (char*)workspace + L.work_off;
+    if (int e = r2l_fft_exec(L.plans.fwd, ma.rgb, spec, work, L.plans.work_bytes, stream)) return e;
+    R2LSpecMaskArgs sm{spec, L.rows, W, cut0, cut1};
+    size_t gm = (L.rows * (size_t)(W / 2 + 1) + R2L_NT - 1) / R2L_NT;
+    if (gm > 16384) gm = 16384;
+    if (int e = r2l_launch_spec_mask(sm, (int)gm, stream)) return e;
+    if (int e = r2l_fft_exec(L.plans.inv, spec, ma.rgb, work, L.plans.work_bytes, stream)) return e;
+#endif
+  }
+  R2LStaticFinishArgs fa{a, ma.rgb};
+  size_t gf = (px / 4 + R2L_NT - 1) / R2L_NT;
+  if (gf > 16384) gf = 16384;
+  return r2l_launch_static_finish(fa, (int)gf, stream);
+}
+
 static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int W, const double* camera_host,
                                int debayer, int sharpening, int denoising, double gamma, void* workspace,
                                size_t workspace_bytes, void* stream, const float* mean_std_host = nullptr,
@@ -1540,7 +1640,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     for (int k = 0; k < 3; ++k)
       if (!(mean_std_host[3 + k] != 0.f)) return r2l_fail(-1, "r2l_static_fwd_norm: std must be non-zero");
   if (!out || !camera_host) return r2l_fail(-1, "r2l_static_fwd: null pointer");
-  if (debayer != R2L_DEBAYER_BILINEAR && debayer != R2L_DEBAYER_MALVAR2004)
+  if (debayer != R2L_DEBAYER_BILINEAR && debayer != R2L_DEBAYER_MALVAR2004 && debayer != R2L_DEBAYER_MENON2007)
     return r2l_fail(-1, "r2l_static_fwd: unknown debayer");
   if (sharpening != R2L_SHARPEN_NONE && sharpening != R2L_SHARPEN_FILTER && sharpening != R2L_SHARPEN_UNSHARP)
     return r2l_fail(-1, "r2l_static_fwd: unknown sharpening");
@@ -1551,6 +1651,8 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
   if (const char* why = r2l_static_opts_problem(opt, sharpening, denoising)) return r2l_fail(-4, std::string("r2l_static_fwd: ") + why);
   R2LStaticArgs a;
   r2l_static_setup(a, raw, out, B, H, W, camera_host, debayer, sharpening, denoising, gamma, mean_std_host, opt);
+  if (debayer == R2L_DEBAYER_MENON2007)
+    return r2l_static_menon_impl(a, B, H, W, sharpening, denoising, opt, workspace, workspace_bytes, stream);
   const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
 #ifndef R2L_SERIAL
   if (r2l_static_is_chain(W, debayer, sharpening, denoising)) {
@@ -1759,7 +1861,13 @@ int r2l_raw2rgb_fwd_u16(const unsigned short* raw, float denom, const float* bla
                               stream);
 }
 static size_t r2l_static_ws(int B, int H, int W, int debayer, int sharpening, int denoising, bool f64) {
-  if (B < 1 || H < 1 || W < 1 || r2l_static_is_fused(W, debayer, sharpening, denoising, f64)) return 0;
+  if (B < 1 || H < 1 || W < 1) return 0;
+  if (debayer == R2L_DEBAYER_MENON2007) {
+    R2LMenonLayout L;
+    if (r2l_menon_layout(B, H, W, denoising == R2L_DENOISE_FFT, L)) return 0;
+    return L.total;
+  }
+  if (r2l_static_is_fused(W, debayer, sharpening, denoising, f64)) return 0;
   if (denoising == R2L_DENOISE_FFT) {
     R2LFftLayout L;
     if (r2l_fft_layout(B, H, W, L)) return 0;

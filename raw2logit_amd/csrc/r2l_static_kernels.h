@@ -56,6 +56,9 @@ struct R2LStaticArgs {
   float nrcp[3];            // RN(1 / nstd[c])
 };
 
+// skimage.color yuv_from_rgb (scikit-image 0.18.1); the reference's own copy is pipeline_torch.py:21-23
+static const double R2L_YUV_FROM_RGB[9] = {0.299,       0.587,       0.114,       -0.14714119, -0.28886916,
+                                           0.43601035,  0.61497538,  -0.51496512, -0.10001026};
 static inline void r2l_inv3(const double* m, double* o) {
   const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
   const double A = e * i - f * h, Bc = -(d * i - f * g), C = d * h - e * g;
@@ -109,8 +112,7 @@ static inline void r2l_static_setup(R2LStaticArgs& a, const R2LRaw& raw, float* 
   }
   // skimage.color yuv_from_rgb (scikit-image 0.18.1); the reference's own copy is
   // pipeline_torch.py:21-23
-  static const double M1[9] = {0.299,       0.587,       0.114,       -0.14714119, -0.28886916,
-                               0.43601035,  0.61497538,  -0.51496512, -0.10001026};
+  const double* M1 = R2L_YUV_FROM_RGB;
   a.raw = raw;
   a.out = out;
   a.B = B;

@@ -474,7 +474,7 @@ def isp_fused(raw, module, bn_mode=BN_NONE, group=None, epilogue=None):
 # --------------------------------------------------------------------------------------------------
 # static pipeline (processing(), pipeline_numpy.py:70-141), batched
 # --------------------------------------------------------------------------------------------------
-_DEBAYER = {'bilinear': 0, 'malvar2004': 1}
+_DEBAYER = {'bilinear': 0, 'malvar2004': 1, 'menon2007': 2}
 _SHARPEN = {'sharpening_filter': 1, 'unsharp_masking': 2}
 _DENOISE = {'gaussian_denoising': 1, 'median_denoising': 2, 'fft_denoising': 3}
 
@@ -504,7 +504,9 @@ def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='shar
 
     Like the reference's if-chains (pipeline_numpy.py:110-122) a sharpening / denoising string that
     names no algorithm means "skip that stage"; algorithms the reference has but this library does not
-    build (menon2007, tv_chambolle / tv_bregman / bilateral denoising) raise instead of silently differing."""
+    build (tv_chambolle / tv_bregman / bilateral denoising) raise instead of silently differing.  debayer='menon2007'
+    (pipeline_numpy.py:96-97) runs as float64 plane passes (W % 4 == 0): a third-party algorithm restated from its published
+    source, parity unpinned like Malvar2004's."""
     assert raw.ndim == 3, f"needs dims (B, H, W), got {raw.shape}"
     f64 = raw.dtype == torch.float64
     if f64:

@@ -605,7 +605,7 @@ def check_static_combinations(device):
         u = np.random.default_rng(H).integers(0, 4096, (B, H, W)).astype(np.uint16)
         raw_np = u.astype(np.float32) / np.float32(4095)
         raw = torch.from_numpy(raw_np).to(device)
-        for deb in ('bilinear', 'malvar2004'):
+        for deb in ('bilinear', 'malvar2004', 'menon2007'):
             for sh in ('none', 'sharpening_filter', 'unsharp_masking'):
                 for dn in ('none', 'gaussian_denoising', 'median_denoising', 'fft_denoising'):
                     ref = orc.static_batch(raw_np, orc.DRONE_CAMERA_PARAMS, deb, sh, dn)
@@ -1138,7 +1138,9 @@ def check_error_behaviour(device):
     with pytest.raises(ValueError):
         F_.static_pipeline(torch.zeros((1, 8, 6), dtype=torch.int16, device=device), orc.DRONE_CAMERA_PARAMS)
     with pytest.raises(NotImplementedError):
-        F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, debayer='menon2007')
+        F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, debayer='a_debayer_nobody_built')
+    with pytest.raises(_lib.R2LError):                       # menon2007 runs as plane passes: W % 4 == 0
+        F_.static_pipeline(torch.rand((1, 8, 6), device=device), orc.DRONE_CAMERA_PARAMS, debayer='menon2007')
     with pytest.raises(NotImplementedError):
         F_.static_pipeline(raw, orc.DRONE_CAMERA_PARAMS, denoising='tv_chambolle')
     with pytest.raises(NotImplementedError):
