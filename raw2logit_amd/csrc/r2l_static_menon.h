@@ -64,11 +64,17 @@ R2L_BLOCKFN void r2l_static_menon_block(const R2LMenonArgs& ma, int bid, int nbl
   (void)lds;
   const R2LStaticArgs& a = ma.s;
   const int H = a.H, W = a.W;
-  const size_t hw = (size_t)H * W, n = (size_t)a.B * hw;
+  const size_t hw = (size_t)H * W;
+  const long nrows = (long)a.B * H;
   R2L_PHASE_BEGIN
-  for (size_t i = (size_t)bid * R2L_NT + tid; i < n; i += (size_t)nblk * R2L_NT) {
-    const size_t b = i / hw, p = i - b * hw;
-    const int y = (int)(p / (size_t)W), x = (int)(p - (size_t)y * W);
+  // a workgroup walks image rows, its lanes the columns: no per-pixel division (the first form of this loop decomposed a 64-bit
+  // pixel index per lane -- two 64-bit divisions -- and spent more time on that than on the stencils)
+  for (long row = bid; row < nrows; row += nblk)
+  for (int x = tid; x < W; x += R2L_NT) {
+    const size_t b = (size_t)(row / H);
+    const int y = (int)(row - (long)b * H);
+    const size_t p = (size_t)y * W + x;
+    const size_t i = b * hw + p;
     const size_t img = b * hw;          // offset of image b in a (B,H,W) plane
     const size_t img3 = b * 3 * hw;     // ... in the (B,3,H,W) image
     double* Rp = ma.rgb + img3;

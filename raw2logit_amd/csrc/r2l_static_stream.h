@@ -748,13 +748,20 @@ R2L_HD void r2l_static_stream_item_bf(const R2LStaticStreamArgs& sa, int item, i
   const unsigned sbl = ESZ * (unsigned)(le0 ? 0 : sx0 - 2), sbr = ESZ * (unsigned)(sx0 + 256 + 2 <= a.W ? sx0 + 256 : a.W - 2);
   (void)xl; (void)xr; (void)sbl; (void)sbr; (void)le0;
   const int ylast = y1 - 1 + HALO;  // last source row (before the symmetric extension) this band needs
+  // -DR2L_EXP_STATIC_NO_HALO (A/B builds; WRONG RESULTS, timing only): every halo row is fetched from inside the band -- the upper
+  // bound of anything that shares the halo rows of neighbouring bands (the review's "adjacent bands in lock-step", round 6)
+#ifdef R2L_EXP_STATIC_NO_HALO
+#define R2L_BF_ROW(ys_) ((ys_) < y0 ? y0 : ((ys_) > y1 - 1 ? y1 - 1 : (ys_)))
+#else
+#define R2L_BF_ROW(ys_) (ys_)
+#endif
 #if R2L_STREAM_BF_SCALAR_EDGES
   typedef R2LRowStageS<RAWK> StageT;
-#define R2L_BF_FETCH(ys_, st_) r2l_stream_fetch_row_s<RAWK>(a, img, (ys_), xo, sbl, sbr, (st_))
+#define R2L_BF_FETCH(ys_, st_) r2l_stream_fetch_row_s<RAWK>(a, img, R2L_BF_ROW(ys_), xo, sbl, sbr, (st_))
 #define R2L_BF_CONVERT(st_, dst_) r2l_stream_convert_row_s<RAWK, WT>(a, (st_), le0, le, re, (dst_))
 #else
   typedef R2LRowStageT<RAWK> StageT;
-#define R2L_BF_FETCH(ys_, st_) r2l_stream_fetch_row_bf<RAWK, LANES>(a, img, (ys_), xo, xl, xr, le, re, (st_))
+#define R2L_BF_FETCH(ys_, st_) r2l_stream_fetch_row_bf<RAWK, LANES>(a, img, R2L_BF_ROW(ys_), xo, xl, xr, le, re, (st_))
 #define R2L_BF_CONVERT(st_, dst_) r2l_stream_convert_row<RAWK, LANES, WT>(a, (st_), le, re, (dst_))
 #endif
   {
@@ -813,6 +820,7 @@ R2L_HD void r2l_static_stream_item_bf(const R2LStaticStreamArgs& sa, int item, i
 
 #undef R2L_BF_FETCH
 #undef R2L_BF_CONVERT
+#undef R2L_BF_ROW
 
 #define R2L_STREAM_NT 256  // 4 independent wavefronts per workgroup
 template <int DEB, int RAWK, bool LUMA>

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p tests/_build/ab
 while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2
-  hipcc -O3 -std=c++17 -fno-slp-vectorize --offload-arch=gfx950 -shared -fPIC $flags raw2logit_amd/csrc/r2l_api.hip -o tests/_build/ab/$name.so -lrocfft &
+  hipcc -O3 -std=c++17 -fno-slp-vectorize --offload-arch=gfx950 -shared -fPIC $flags raw2logit_amd/csrc/r2l_api.hip -o tests/_build/ab/$name.so -ldl &
 done
 wait
 ls -la tests/_build/ab/
