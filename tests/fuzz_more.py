@@ -35,13 +35,18 @@ def rand_shape(wmul=2, hmax=150, wmax=300):
 
 def fuzz_static():
     B, H, W = rand_shape(wmul=int(rng.choice([2, 4])))
-    deb = ['bilinear', 'malvar2004'][int(rng.integers(0, 2))]
+    deb = ['bilinear', 'malvar2004', 'menon2007'][int(rng.integers(0, 3))]
     sh = ['none', 'sharpening_filter', 'unsharp_masking'][int(rng.integers(0, 3))]
     dn = ['none', 'gaussian_denoising', 'median_denoising', 'fft_denoising'][int(rng.integers(0, 4))]
     cam = [orc.DRONE_CAMERA_PARAMS, orc.MICROSCOPY_CAMERA_PARAMS][int(rng.integers(0, 2))]
     fused = (sh == 'none' and dn == 'none') or (deb == 'bilinear' and sh == 'sharpening_filter' and dn == 'gaussian_denoising')
-    if not fused and W % 4:
+    if (not fused or deb == 'menon2007') and W % 4:
         W += 2            # the plane passes need W % 4 == 0 (documented; the call raises otherwise)
+    # processing()'s numeric arguments (pipeline_numpy.py:70-73), inside what the kernels' windows hold, one case in three
+    opts = {}
+    if rng.integers(0, 3) == 0:
+        opts = dict(gaussian_sigma=float(rng.uniform(0.2, 0.62)), sharp_radius=float(rng.uniform(0.2, 1.12)),
+                    sharp_amount=float(rng.uniform(0.2, 2.5)), fft_fraction=float(rng.uniform(0.05, 0.5)))
     if deb == 'malvar2004' and (H < 6 or W < 6):
         H, W = max(H, 6), max(W, 8)
     if rng.integers(0, 5) == 0:      # 2, 4 or 8 wavefronts side by side in the row-streaming chain kernels
@@ -50,22 +55,22 @@ def fuzz_static():
     if rng.integers(0, 2):
         u[:, : H // 2] = rng.integers(240, 270, (B, H // 2, W))
     raw_np = u.astype(np.float32) / np.float32(4095)
-    ref = orc.static_batch(raw_np, cam, deb, sh, dn)
-    out = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), cam, deb, sh, dn).cpu().numpy()
+    ref = orc.static_batch(raw_np, cam, deb, sh, dn, **opts)
+    out = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), cam, deb, sh, dn, **opts).cpu().numpy()
     e = np.abs(out - ref).max()
-    assert e <= 1e-5, ('static', (B, H, W), deb, sh, dn, e)
+    assert e <= 1e-5, ('static', (B, H, W), deb, sh, dn, opts, e)
     if W % 4 == 0:
-        out16 = F_.static_pipeline(torch.from_numpy(u).to(dev), cam, deb, sh, dn, bits=12).cpu().numpy()
+        out16 = F_.static_pipeline(torch.from_numpy(u).to(dev), cam, deb, sh, dn, bits=12, **opts).cpu().numpy()
         dd = np.abs(out16.astype(np.float64) - out)
         assert np.array_equal(out16, out), ('static u16', (B, H, W), deb, sh, dn, 'max diff', float(dd.max()), 'pixels', int((dd > 0).sum()),
                                             'camera', 'drone' if cam is orc.DRONE_CAMERA_PARAMS else 'microscopy', np.argwhere(dd > 0)[:4].tolist())
     if W % 4 == 0 and rng.integers(0, 3) == 0:      # float64 frames, and the T.Normalize epilogue on float32 ones
-        ref64 = orc.static_batch(raw_np.astype(np.float64), cam, deb, sh, dn)
-        out64 = F_.static_pipeline(torch.from_numpy(raw_np.astype(np.float64)).to(dev), cam, deb, sh, dn).cpu().numpy()
+        ref64 = orc.static_batch(raw_np.astype(np.float64), cam, deb, sh, dn, **opts)
+        out64 = F_.static_pipeline(torch.from_numpy(raw_np.astype(np.float64)).to(dev), cam, deb, sh, dn, **opts).cpu().numpy()
         e64 = np.abs(out64 - ref64).max()
         assert e64 <= 1e-5, ('static f64', (B, H, W), deb, sh, dn, e64)
         ms = [float(v) for v in rng.uniform(0.2, 0.9, 3)] + [float(v) for v in rng.uniform(0.05, 0.3, 3)]
-        outn = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), cam, deb, sh, dn, mean_std=ms).cpu()
+        outn = F_.static_pipeline(torch.from_numpy(raw_np).to(dev), cam, deb, sh, dn, mean_std=ms, **opts).cpu()
         refn = (torch.from_numpy(out) - torch.tensor(ms[:3]).view(1, 3, 1, 1)) / torch.tensor(ms[3:]).view(1, 3, 1, 1)
         assert torch.equal(outn, refn), ('static normalize', (B, H, W), deb, sh, dn)
         e = max(e, e64)
