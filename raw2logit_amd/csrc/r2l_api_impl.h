@@ -1577,7 +1577,7 @@ static int r2l_static_menon_impl(const R2LStaticArgs& a, int B, int H, int W, in
                       denoising == R2L_DENOISE_GAUSSIAN ? 2 : (denoising == R2L_DENOISE_MEDIAN ? 3 : 0)};
   ma.want_luma = (ops[0] || ops[1]) ? 1 : 0;
   for (int i = 0; i < 9; ++i) ma.M1[i] = R2L_YUV_FROM_RGB[i];
-  size_t g = (size_t)B * H;   // one workgroup per image row, at most 16384 of them walking the rows
+  size_t g = (px + R2L_NT - 1) / R2L_NT;
   if (g > 16384) g = 16384;
   for (int st = 0; st <= 7; ++st) {
     ma.stage = st;

@@ -65,16 +65,40 @@ R2L_BLOCKFN void r2l_static_menon_block(const R2LMenonArgs& ma, int bid, int nbl
   const R2LStaticArgs& a = ma.s;
   const int H = a.H, W = a.W;
   const size_t hw = (size_t)H * W;
-  const long nrows = (long)a.B * H;
+#ifndef R2L_MENON_LOOP
+#define R2L_MENON_LOOP 1
+#endif
   R2L_PHASE_BEGIN
-  // a workgroup walks image rows, its lanes the columns: no per-pixel division (the first form of this loop decomposed a 64-bit
-  // pixel index per lane -- two 64-bit divisions -- and spent more time on that than on the stencils)
+#if R2L_MENON_LOOP == 2
+  // a workgroup walks image rows, its lanes the columns (measured 1.8-4x slower than the flat loop: profiles/r06_menon.txt; kept as an A/B switch)
+  const long nrows = (long)a.B * H;
   for (long row = bid; row < nrows; row += nblk)
   for (int x = tid; x < W; x += R2L_NT) {
     const size_t b = (size_t)(row / H);
     const int y = (int)(row - (long)b * H);
     const size_t p = (size_t)y * W + x;
     const size_t i = b * hw + p;
+#else
+  // flat grid-stride loop over the pixels; the index is decomposed in 32-bit arithmetic where the batch allows it
+  const size_t n = (size_t)a.B * hw;
+  const bool small = R2L_MENON_LOOP == 1 && n <= 0xffffffffull;
+  for (size_t i = (size_t)bid * R2L_NT + tid; i < n; i += (size_t)nblk * R2L_NT) {
+    size_t b, p;
+    int y, x;
+    if (small) {
+      const unsigned i32 = (unsigned)i, hw32 = (unsigned)hw;
+      const unsigned b32 = i32 / hw32, p32 = i32 - b32 * hw32, y32 = p32 / (unsigned)W;
+      b = b32;
+      p = p32;
+      y = (int)y32;
+      x = (int)(p32 - y32 * (unsigned)W);
+    } else {
+      b = i / hw;
+      p = i - b * hw;
+      y = (int)(p / (size_t)W);
+      x = (int)(p - (size_t)y * W);
+    }
+#endif
     const size_t img = b * hw;          // offset of image b in a (B,H,W) plane
     const size_t img3 = b * 3 * hw;     // ... in the (B,3,H,W) image
     double* Rp = ma.rgb + img3;
