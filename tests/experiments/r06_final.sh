@@ -14,7 +14,7 @@ python3 tests/tools/merge_pmc.py profiles/r06_pmc_traffic_static.json r06 gpurun
 bash tests/profile_round.sh r06_z > gpurun_out/r06_profile_round.log 2>&1
 python3 tests/tools/merge_pmc.py profiles/r06_pmc_traffic.json r06 gpurun_out/r06_z/pmc_traffic.json
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/r06_z/bench_final.json 2>> gpurun_out/r06_z/bench.err     # (with this round's PMC files in place)
-R2L_PARITY_LOG=$PWD/gpurun_out/r06_parity_gpu.tsv python -m pytest tests -x -q -m gpu 2>&1 | tail -80 > gpurun_out/r06_gputests.log
+R2L_PARITY_LOG=$PWD/gpurun_out/r06_parity_gpu.tsv python -m pytest tests -x -q -m gpu > gpurun_out/r06_gputests.log 2>&1     # (the WHOLE report: a tail lost the one failure this round saw)
 cp profiles/r06_pmc_traffic.json profiles/r06_pmc_traffic_static.json gpurun_out/r06_z/ 2>/dev/null
 for args in "--debayer menon2007" "--debayer menon2007 --sharpening sharpening_filter --denoising gaussian_denoising" "--debayer menon2007 --sharpening unsharp_masking --denoising fft_denoising"; do
   python3 bench.py --workload static --batch 64 --size 1024 --steps 10 --warmup 3 --no-cpu-baseline $args 2>> gpurun_out/r06_z/bench.err | python3 -c "
