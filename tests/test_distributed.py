@@ -23,6 +23,23 @@ def _free_port():
     return p
 
 
+def _spawn_ranks(fn, world, emul_path, out_dir):
+    """mp.spawn over a free port; started over ONCE if the rendezvous itself failed (the port probed free was taken before rank 0
+    bound it -- seen once in this round's CPU runs while another process was opening sockets -- or a peer could not connect):
+    never on an assertion of a worker"""
+    for attempt in (0, 1):
+        try:
+            return mp.spawn(fn, args=(world, _free_port(), emul_path, out_dir), nprocs=world, join=True)
+        except Exception as e:                       # noqa: BLE001
+            text = str(e)
+            rendezvous = any(k in text for k in ('Address already in use', 'EADDRINUSE', 'Connection refused', 'Connection reset',
+                                                 'connect() timed out', 'failed to connect', 'The server socket has failed',
+                                                 'DistNetworkError', 'DistStoreError', 'Broken pipe'))
+            if attempt == 1 or not rendezvous or 'AssertionError' in text:
+                raise
+            print(f'test_distributed: rendezvous failed ({text[-300:]!r}); starting the {world} ranks over on another port')
+
+
 def _worker(rank, world, port, emul_path, out_dir):
     sys.path.insert(0, REPO)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -55,7 +72,8 @@ def _worker(rank, world, port, emul_path, out_dir):
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), y=y.detach().numpy(), g=flat.numpy(),
              rm=m.batch_norm.running_mean.numpy(), rv=m.batch_norm.running_var.numpy(),
              yt=yt.detach().numpy(), gt=flat_t.numpy())
-    dist.destroy_process_group()
+    dist.barrier()                 # (a rank that tears its gloo context down while a peer is still inside its last collective
+    dist.destroy_process_group()   #  aborts that peer: 'terminate called without an active exception', seen with 8 ranks)
 
 
 def test_two_rank_shard_equals_single_process(emulation, tmp_path):
@@ -63,7 +81,7 @@ def test_two_rank_shard_equals_single_process(emulation, tmp_path):
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     import conftest
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), conftest.EMUL_LIB, str(tmp_path)), nprocs=world, join=True)
+    _spawn_ranks(_worker, world, conftest.EMUL_LIB, str(tmp_path))
     B, H, W = 4, 24, 40
     raw = torch.from_numpy(orc.synth_raw(B, H, W, seed=3, kind='scene'))
     cot = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 3, H, W)).astype(np.float32))
@@ -109,7 +127,8 @@ def _single_rank_worker(rank, world, port, emul_path, out_dir):
     np.savez(os.path.join(out_dir, 'single.npz'), y=y.detach().numpy(),
              g=torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy(), comm=np.asarray(sorted(comm)),
              rm=m.batch_norm.running_mean.numpy(), rv=m.batch_norm.running_var.numpy())
-    dist.destroy_process_group()
+    dist.barrier()                 # (a rank that tears its gloo context down while a peer is still inside its last collective
+    dist.destroy_process_group()   #  aborts that peer: 'terminate called without an active exception', seen with 8 ranks)
 
 
 def test_single_rank_takes_the_split_path_when_asked(emulation, tmp_path):
@@ -119,7 +138,7 @@ def test_single_rank_takes_the_split_path_when_asked(emulation, tmp_path):
     from oracle import isp_oracle as orc
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     import conftest
-    mp.spawn(_single_rank_worker, args=(1, _free_port(), conftest.EMUL_LIB, str(tmp_path)), nprocs=1, join=True)
+    _spawn_ranks(_single_rank_worker, 1, conftest.EMUL_LIB, str(tmp_path))
     r = np.load(os.path.join(str(tmp_path), 'single.npz'))
     assert list(r['comm']) == ['bn statistics all-gather', 'bn-bwd sums all-gather', 'grad all-reduce']
     B, H, W = 3, 24, 40
@@ -177,7 +196,8 @@ def _c5_worker(rank, world, port, emul_path, out_dir):
         out[f'g{step}'] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), rm=m.batch_norm.running_mean.numpy(),
              rv=m.batch_norm.running_var.numpy(), nbt=m.batch_norm.num_batches_tracked.numpy(), **out)
-    dist.destroy_process_group()
+    dist.barrier()                 # (a rank that tears its gloo context down while a peer is still inside its last collective
+    dist.destroy_process_group()   #  aborts that peer: 'terminate called without an active exception', seen with 8 ranks)
 
 
 def test_config5_partition_eight_ranks(emulation, tmp_path):
@@ -189,7 +209,7 @@ def test_config5_partition_eight_ranks(emulation, tmp_path):
     from raw2logit_amd.processing.pipeline_torch import ParametrizedProcessing
     import conftest
     world = C5_WORLD
-    mp.spawn(_c5_worker, args=(world, _free_port(), conftest.EMUL_LIB, str(tmp_path)), nprocs=world, join=True)
+    _spawn_ranks(_c5_worker, world, conftest.EMUL_LIB, str(tmp_path))
     r = [np.load(os.path.join(str(tmp_path), f'rank{k}.npz')) for k in range(world)]
     raw, cot = _c5_inputs()
     m = ParametrizedProcessing(orc.DRONE_CAMERA_PARAMS, batch_norm_output=True).train()
