@@ -275,10 +275,13 @@ int r2l_static_fwd_norm(const void *raw, int frames, float denom, float *out, in
  * reference's defaults (then identical to r2l_static_fwd_norm).  What the kernels' windows hold bounds the values:
  *   gaussian_sigma   (0, 0.625)   scipy's window radius int(4 sigma + 0.5) <= 2 (the 5-tap window of gaussian_denoising);
  *   sharp_radius     (0, 1.125)   radius int(4 sigma + 0.5) <= 4 (the 9-tap window behind unsharp_masking); sharp_amount any;
- *   fft_fraction     [0, 0.5];    median_kernel_size 3 only (a 3x3 median network) -- anything else returns -4 with the
- * reason in r2l_last_error().  An option of a stage the chain does not run is ignored, like the reference's if-chains.    */
+ *   fft_fraction     [0, 0.5];    median_kernel_size 3 (the fused kernels' network) or 5 (then the chain runs as luma-plane
+ * passes: W % 4 == 0, workspace from r2l_static_workspace_bytes_opts) -- anything else returns -4 with the reason in
+ * r2l_last_error().  An option of a stage the chain does not run is ignored, like the reference's if-chains.             */
 enum { R2L_SOPT_SHARP_RADIUS = 0, R2L_SOPT_SHARP_AMOUNT = 1, R2L_SOPT_GAUSSIAN_SIGMA = 2, R2L_SOPT_FFT_FRACTION = 3,
        R2L_SOPT_MEDIAN_SIZE = 4, R2L_SOPT_COUNT = 5 };
+size_t r2l_static_workspace_bytes_opts(int frames, int B, int H, int W, int debayer, int sharpening, int denoising,
+                                       const double *options_host);
 int r2l_static_fwd_opts(const void *raw, int frames, float denom, float *out, int B, int H, int W,
                         const double *camera_host, int debayer, int sharpening, int denoising, double gamma,
                         const double *options_host, const float *mean_std_host, void *workspace,

@@ -167,6 +167,11 @@ STATIC_OPT_CASES = [
     dict(name='opt_fft_f045_unsharp', seed=47, shape=(1, 16, 64), kind='uniform', camera='drone', dtype='float32',
          debayer='malvar2004', sharpening='unsharp_masking', denoising='fft_denoising',
          opts=dict(fft_fraction=0.45, sharp_amount=0.7)),
+    dict(name='opt_median5', seed=49, shape=(2, 24, 40), kind='scene', camera='drone', dtype='float32',
+         debayer='bilinear', sharpening='sharpening_filter', denoising='median_denoising', opts=dict(median_kernel_size=5)),
+    dict(name='opt_median5_menon_unsharp_f64', seed=50, shape=(1, 16, 24), kind='uniform', camera='microscopy', dtype='float64',
+         debayer='menon2007', sharpening='unsharp_masking', denoising='median_denoising',
+         opts=dict(median_kernel_size=5, sharp_amount=0.8)),
     # an option of a stage the chain does not run is ignored (the reference's if-chains, :110-122)
     dict(name='opt_ignored_on_short_chain', seed=48, shape=(1, 16, 16), kind='scene', camera='drone', dtype='float32',
          debayer='bilinear', sharpening='none', denoising='none',

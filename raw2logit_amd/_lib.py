@@ -119,6 +119,7 @@ _SIGNATURES = {
                                            ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                            ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_size_t,
                                            ctypes.c_void_p]),
+    'r2l_static_workspace_bytes_opts': (ctypes.c_size_t, [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_double)]),
     'r2l_static_fwd_opts': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),

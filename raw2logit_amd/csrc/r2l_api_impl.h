@@ -1378,8 +1378,9 @@ int r2l_raw2rgb_bwd(const float* grad_out, float* grad_raw, double* grad_black_l
 // gaussian_denoising; everything else runs as luma-plane passes and needs two float64 planes of workspace
 // chains the row-streaming luma-chain kernel covers (r2l_static_chain.h): bilinear + [sharpening_filter] +
 // [gaussian_denoising], frames up to 2048 columns, W % 4 == 0
-static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoising) {
+static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoising, int median_size = 3) {
   if (debayer == R2L_DEBAYER_MENON2007) return false;
+  if (denoising == R2L_DENOISE_MEDIAN && median_size != 3) return false;  // the 5x5 median runs as a luma-plane pass
 #ifdef R2L_SERIAL
   (void)W; (void)debayer; (void)sharpening; (void)denoising;
   return false;  // (lane shifts and wave-level exchange: not expressible in the one-lane-at-a-time emulation)
@@ -1391,9 +1392,10 @@ static bool r2l_static_is_chain(int W, int debayer, int sharpening, int denoisin
          !(sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE);
 #endif
 }
-static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoising, bool f64_frames = false) {
+static bool r2l_static_is_fused(int W, int debayer, int sharpening, int denoising, bool f64_frames = false, int median_size = 3) {
   if (debayer == R2L_DEBAYER_MENON2007) return false;  // always plane passes (r2l_static_menon.h)
   if (denoising == R2L_DENOISE_FFT) return false;
+  if (denoising == R2L_DENOISE_MEDIAN && median_size != 3) return false;
   if (sharpening == R2L_SHARPEN_NONE && denoising == R2L_DENOISE_NONE) return true;
   if (r2l_static_is_chain(W, debayer, sharpening, denoising)) return true;
   if (f64_frames) return false;  // the tile kernel of the default chain stages float32 frames in LDS
@@ -1574,7 +1576,7 @@ static int r2l_static_menon_impl(const R2LStaticArgs& a, int B, int H, int W, in
   ma.m = ma.cv + px;
   ma.luma = ma.gh;
   const int ops[2] = {sharpening == R2L_SHARPEN_FILTER ? 1 : (sharpening == R2L_SHARPEN_UNSHARP ? 4 : 0),
-                      denoising == R2L_DENOISE_GAUSSIAN ? 2 : (denoising == R2L_DENOISE_MEDIAN ? 3 : 0)};
+                      denoising == R2L_DENOISE_GAUSSIAN ? 2 : (denoising == R2L_DENOISE_MEDIAN ? (opt.median_kernel_size == 5 ? 5 : 3) : 0)};
   ma.want_luma = (ops[0] || ops[1]) ? 1 : 0;
   for (int i = 0; i < 9; ++i) ma.M1[i] = R2L_YUV_FROM_RGB[i];
   size_t g = (px + R2L_NT - 1) / R2L_NT;
@@ -1655,7 +1657,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     return r2l_static_menon_impl(a, B, H, W, sharpening, denoising, opt, workspace, workspace_bytes, stream);
   const int ntiles = B * ((H + GStatic::TH - 1) / GStatic::TH) * ((W + GStatic::TW - 1) / GStatic::TW);
 #ifndef R2L_SERIAL
-  if (r2l_static_is_chain(W, debayer, sharpening, denoising)) {
+  if (r2l_static_is_chain(W, debayer, sharpening, denoising, opt.median_kernel_size)) {
     R2LStaticChainArgs ca;
     ca.s = a;
     // Bands: every band re-computes 7 rows of halo, so tall bands are cheaper (256x1024x1024: 64 rows 1134 us,
@@ -1685,7 +1687,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     return table[kind][deb][sh][dn](ca, (int)grid, stream);
   }
 #endif
-  if (!r2l_static_is_fused(W, debayer, sharpening, denoising, raw.f64 != nullptr)) {
+  if (!r2l_static_is_fused(W, debayer, sharpening, denoising, raw.f64 != nullptr, opt.median_kernel_size)) {
     // luma-plane passes: raw -> Y | sharpen | denoise | raw + Y'' -> RGB
     if (W & 3) return r2l_fail(-4, "r2l_static_fwd: this chain runs as plane passes, which need W % 4 == 0");
     const size_t plane_bytes = sizeof(double) * (size_t)B * H * W;
@@ -1722,7 +1724,7 @@ static int r2l_static_fwd_impl(const R2LRaw& raw, float* out, int B, int H, int 
     double* cur = p0;
     double* other = p1;
     const int ops[2] = {sharpening == R2L_SHARPEN_FILTER ? 1 : (sharpening == R2L_SHARPEN_UNSHARP ? 4 : 0),
-                        denoising == R2L_DENOISE_GAUSSIAN ? 2 : (denoising == R2L_DENOISE_MEDIAN ? 3 : 0)};
+                        denoising == R2L_DENOISE_GAUSSIAN ? 2 : (denoising == R2L_DENOISE_MEDIAN ? (opt.median_kernel_size == 5 ? 5 : 3) : 0)};
     for (int i = 0; i < 2; ++i) {
       if (!ops[i]) continue;
       R2LPlaneArgs pa;
@@ -1860,14 +1862,14 @@ int r2l_raw2rgb_fwd_u16(const unsigned short* raw, float denom, const float* bla
   return r2l_raw2rgb_fwd_impl(r2l_raw_u16(raw, denom), black_level, out, B, H, W, reduce_size, out_channels,
                               stream);
 }
-static size_t r2l_static_ws(int B, int H, int W, int debayer, int sharpening, int denoising, bool f64) {
+static size_t r2l_static_ws(int B, int H, int W, int debayer, int sharpening, int denoising, bool f64, int median_size = 3) {
   if (B < 1 || H < 1 || W < 1) return 0;
   if (debayer == R2L_DEBAYER_MENON2007) {
     R2LMenonLayout L;
     if (r2l_menon_layout(B, H, W, denoising == R2L_DENOISE_FFT, L)) return 0;
     return L.total;
   }
-  if (r2l_static_is_fused(W, debayer, sharpening, denoising, f64)) return 0;
+  if (r2l_static_is_fused(W, debayer, sharpening, denoising, f64, median_size)) return 0;
   if (denoising == R2L_DENOISE_FFT) {
     R2LFftLayout L;
     if (r2l_fft_layout(B, H, W, L)) return 0;
@@ -1880,6 +1882,15 @@ size_t r2l_static_workspace_bytes(int B, int H, int W, int debayer, int sharpeni
 }
 size_t r2l_static_workspace_bytes_f64(int B, int H, int W, int debayer, int sharpening, int denoising) {
   return r2l_static_ws(B, H, W, debayer, sharpening, denoising, true);
+}
+size_t r2l_static_workspace_bytes_opts(int frames, int B, int H, int W, int debayer, int sharpening, int denoising,
+                                       const double* options_host) {
+  int med = 3;
+  if (options_host) {
+    const double m = options_host[R2L_SOPT_MEDIAN_SIZE];
+    med = (m == (double)(int)m) ? (int)m : 3;
+  }
+  return r2l_static_ws(B, H, W, debayer, sharpening, denoising, frames == R2L_FRAMES_F64, med);
 }
 int r2l_static_fwd_f64(const double* raw, float* out, int B, int H, int W, const double* camera_host,
                        int debayer, int sharpening, int denoising, double gamma, void* workspace,

@@ -82,7 +82,7 @@ struct R2LStaticOpts {
 // scipy.ndimage.gaussian_filter's window radius for a sigma: int(truncate * sigma + 0.5), truncate = 4.0
 static inline int r2l_scipy_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
 // what the kernels' windows can hold: a 5-tap Gaussian for gaussian_denoising (radius <= 2: sigma < 0.625), a 9-tap one behind
-// unsharp_masking (radius <= 4: sharp_radius < 1.125), the 3x3 median; 0 <= fft_fraction <= 0.5.  NULL: fine.
+// unsharp_masking (radius <= 4: sharp_radius < 1.125), the 3x3 median (5x5: as a luma-plane pass); 0 <= fft_fraction <= 0.5.  NULL: fine.
 static inline const char* r2l_static_opts_problem(const R2LStaticOpts& o, int sharpening, int denoising) {
   if (denoising == R2L_DENOISE_GAUSSIAN && !(o.gaussian_sigma > 0.0 && r2l_scipy_radius(o.gaussian_sigma) <= 2))
     return "gaussian_sigma must be in (0, 0.625): scipy's window radius int(4 sigma + 0.5) may not exceed the kernels' 2";
@@ -90,8 +90,8 @@ static inline const char* r2l_static_opts_problem(const R2LStaticOpts& o, int sh
     return "sharp_radius must be in (0, 1.125): scipy's window radius int(4 radius + 0.5) may not exceed the kernels' 4";
   if (sharpening == R2L_SHARPEN_UNSHARP && !(o.sharp_amount == o.sharp_amount))
     return "sharp_amount is not a number";
-  if (denoising == R2L_DENOISE_MEDIAN && o.median_kernel_size != 3)
-    return "median_kernel_size must be 3 (the kernels hold a 3x3 median network)";
+  if (denoising == R2L_DENOISE_MEDIAN && o.median_kernel_size != 3 && o.median_kernel_size != 5)
+    return "median_kernel_size must be 3 (fused kernels) or 5 (luma-plane passes)";
   if (denoising == R2L_DENOISE_FFT && !(o.fft_fraction >= 0.0 && o.fft_fraction <= 0.5))
     return "fft_fraction must be in [0, 0.5] (pipeline_numpy.py:212-214)";
   return nullptr;

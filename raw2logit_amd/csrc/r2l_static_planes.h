@@ -4,6 +4,7 @@
 //   op 1  sharpening_filter   convolve2d(Y, [[0,-1,0],[-1,5,-1],[0,-1,0]], 'same', fill 0)          :180-191
 //   op 2  gaussian_denoising  scipy.ndimage.gaussian_filter(Y, 0.5): 5 taps per axis, 'reflect'        :203-209
 //   op 3  median_denoising    scipy.ndimage.median_filter(Y, 3): 3x3, 'reflect'                        :194-200
+//   op 5  median_denoising    ... with median_kernel_size=5 (pipeline_numpy.py:119): 5x5, 'reflect' -- plane passes only
 //   op 4  unsharp_masking     skimage.filters.unsharp_mask(Y, radius 1, amount 1, multichannel=True) as the
 //                             reference calls it (:117, :170-177): every COLUMN is a "channel", so the Gaussian
 //                             (sigma 1, 9 taps, 'reflect') runs along the rows only; Y + (Y - blurred)   [unpinned:
@@ -66,6 +67,21 @@ R2L_HD double r2l_plane_px(const R2LPlaneArgs& a, const double* img, int y, int 
     for (int k = 1; k <= 4; ++k)
       blurred += (img[(size_t)r2l_symmetric(y - k, a.H) * a.W + x] + img[(size_t)r2l_symmetric(y + k, a.H) * a.W + x]) * a.uk[k];
     return c + (c - blurred) * a.amount;
+  }
+  if (a.op == 5) {  // scipy.ndimage.median_filter(Y, 5): the 13th smallest of the 5x5 window, 'reflect' (= symmetric) borders
+    double q[25];
+    R2L_PRAGMA_UNROLL
+    for (int i = 0; i < 5; ++i)
+      R2L_PRAGMA_UNROLL
+    for (int j = 0; j < 5; ++j)
+      q[i * 5 + j] = img[(size_t)r2l_symmetric(y + i - 2, a.H) * a.W + r2l_symmetric(x + j - 2, a.W)];
+    // selection network: pass k leaves the minimum of q[k ..] in q[k]; 13 passes, 234 compare-exchanges, every index a
+    // compile-time constant (the window stays in registers)
+    R2L_PRAGMA_UNROLL
+    for (int k = 0; k <= 12; ++k)
+      R2L_PRAGMA_UNROLL
+    for (int j = k + 1; j < 25; ++j) r2l_cswap(q[k], q[j]);
+    return q[12];
   }
   double p[9];
   R2L_PRAGMA_UNROLL
@@ -149,7 +165,7 @@ R2L_BLOCKFN void r2l_plane_filter_block(const R2LPlaneArgs& a, int bid, int nblk
     const int y = (int)(rem / a.W), x = (int)(rem - (size_t)y * a.W);
     const double* img = a.src + b * hw;
     double o0, o1;
-    if (y >= r && y + r < a.H && x >= rx && x + 1 + rx < a.W) {
+    if (a.op != 5 && y >= r && y + r < a.H && x >= rx && x + 1 + rx < a.W) {   // (op 5: the per-pixel form everywhere)
       r2l_plane_px2(a, img, y, x, o0, o1);
     } else {
       o0 = r2l_plane_px(a, img, y, x);

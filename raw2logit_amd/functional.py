@@ -490,7 +490,7 @@ def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='shar
     sharp_radius, sharp_amount, median_kernel_size, gaussian_sigma, fft_fraction: processing()'s numeric arguments
     (pipeline_numpy.py:70-73, used at :117-122), launch arguments of the kernels (r2l_static_fwd_opts).  What the kernels'
     windows hold bounds them: gaussian_sigma in (0, 0.625), sharp_radius in (0, 1.125), fft_fraction in [0, 0.5],
-    median_kernel_size 3 -- other values of an option the chain USES raise R2LError with the reason; an option of a stage the
+    median_kernel_size 3 or 5 (5: the chain runs as luma-plane passes, W % 4 == 0) -- other values of an option the chain USES raise R2LError with the reason; an option of a stage the
     chain does not run is ignored like the reference's if-chains ignore it.
 
     mean_std: six host floats (mean[3], std[3]) -- the T.Normalize(mean, std) that train.py:157-171 composes
@@ -530,21 +530,24 @@ def static_pipeline(raw, camera_parameters, debayer='bilinear', sharpening='shar
     lib, stream = _lib.library_for(raw)
     out = torch.empty((B, 3, H, W), dtype=torch.float32, device=raw.device)
     codes = (_DEBAYER[debayer], _SHARPEN.get(sharpening, 0), _DENOISE.get(denoising, 0))
-    nws = (lib.r2l_static_workspace_bytes_f64 if f64 else lib.r2l_static_workspace_bytes)(B, H, W, *codes)
-    ws = torch.empty(nws, dtype=torch.uint8, device=raw.device) if nws else None      # 0: single-launch chains
-    tail = (ptr(out), B, H, W, cam, *codes, float(gamma), ptr(ws), nws, stream)
     opts = dict(sharp_radius=sharp_radius, sharp_amount=sharp_amount, gaussian_sigma=gaussian_sigma,
                 fft_fraction=fft_fraction, median_kernel_size=median_kernel_size)
-    if opts != STATIC_OPTION_DEFAULTS:
+    custom = opts != STATIC_OPTION_DEFAULTS
+    frames = 2 if f64 else (0 if denom is None else 1)
+    if custom:
         ov = (ctypes.c_double * 5)(float(sharp_radius), float(sharp_amount), float(gaussian_sigma), float(fft_fraction),
                                    float(median_kernel_size))         # R2L_SOPT_* order (include/r2l_isp.h)
+        nws = lib.r2l_static_workspace_bytes_opts(frames, B, H, W, *codes, ov)     # (a 5x5 median runs as plane passes)
+    else:
+        nws = (lib.r2l_static_workspace_bytes_f64 if f64 else lib.r2l_static_workspace_bytes)(B, H, W, *codes)
+    ws = torch.empty(nws, dtype=torch.uint8, device=raw.device) if nws else None      # 0: single-launch chains
+    tail = (ptr(out), B, H, W, cam, *codes, float(gamma), ptr(ws), nws, stream)
+    if custom:
         ms = (ctypes.c_float * 6)(*[float(v) for v in mean_std]) if mean_std is not None else None
-        frames = 2 if f64 else (0 if denom is None else 1)
         lib.check(lib.r2l_static_fwd_opts(ptr(raw), frames, float(denom or 1.0), ptr(out), B, H, W, cam, *codes,
                                           float(gamma), ov, ms, ptr(ws), nws, stream), 'r2l_static_fwd_opts')
     elif mean_std is not None:
         ms = (ctypes.c_float * 6)(*[float(v) for v in mean_std])
-        frames = 2 if f64 else (0 if denom is None else 1)
         lib.check(lib.r2l_static_fwd_norm(ptr(raw), frames, float(denom or 1.0), ptr(out), B, H, W, cam, *codes,
                                           float(gamma), ms, ptr(ws), nws, stream), 'r2l_static_fwd_norm')
     elif f64:

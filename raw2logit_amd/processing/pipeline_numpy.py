@@ -34,7 +34,7 @@ def processing(img, black_level, white_balance, colour_matrix, debayer="bilinear
     Option strings that name no algorithm skip their stage (the signature default denoising="median_filter"
     is one).  sharp_radius / sharp_amount / median_kernel_size / gaussian_sigma / fft_fraction (:117-122) are launch
     arguments of the kernels, within what their windows hold (functional.static_pipeline: gaussian_sigma < 0.625,
-    sharp_radius < 1.125, median_kernel_size 3, fft_fraction in [0, 0.5]; anything else raises R2LError with the reason --
+    sharp_radius < 1.125, median_kernel_size 3 or 5, fft_fraction in [0, 0.5]; anything else raises R2LError with the reason --
     INTEGRATION.md); weight_chambolle / weight_bregman / sigma_bilateral belong to denoisers this library does not build."""
     if not (isinstance(img, np.ndarray) and img.dtype in (np.float32, np.float64)):
         raise TypeError('processing() takes a float32 or float64 ndarray (dataset.py:86-87 delivers float32)')

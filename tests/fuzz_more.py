@@ -46,7 +46,10 @@ def fuzz_static():
     opts = {}
     if rng.integers(0, 3) == 0:
         opts = dict(gaussian_sigma=float(rng.uniform(0.2, 0.62)), sharp_radius=float(rng.uniform(0.2, 1.12)),
-                    sharp_amount=float(rng.uniform(0.2, 2.5)), fft_fraction=float(rng.uniform(0.05, 0.5)))
+                    sharp_amount=float(rng.uniform(0.2, 2.5)), fft_fraction=float(rng.uniform(0.05, 0.5)),
+                    median_kernel_size=int(rng.choice([3, 5])))
+        if opts['median_kernel_size'] == 5 and dn == 'median_denoising' and W % 4:
+            W += 2            # (the 5x5 median runs as plane passes)
     if deb == 'malvar2004' and (H < 6 or W < 6):
         H, W = max(H, 6), max(W, 8)
     if rng.integers(0, 5) == 0:      # 2, 4 or 8 wavefronts side by side in the row-streaming chain kernels

@@ -581,7 +581,7 @@ def check_static_options(golden, device):
     bad = [(('bilinear', 'none', 'gaussian_denoising'), dict(gaussian_sigma=0.7), 'gaussian_sigma'),
            (('bilinear', 'none', 'gaussian_denoising'), dict(gaussian_sigma=0.0), 'gaussian_sigma'),
            (('bilinear', 'unsharp_masking', 'none'), dict(sharp_radius=1.2), 'sharp_radius'),
-           (('bilinear', 'sharpening_filter', 'median_denoising'), dict(median_kernel_size=5), 'median_kernel_size'),
+           (('bilinear', 'sharpening_filter', 'median_denoising'), dict(median_kernel_size=7), 'median_kernel_size'),
            (('bilinear', 'none', 'fft_denoising'), dict(fft_fraction=0.6), 'fft_fraction')]
     for chain, opts, word in bad:
         try:
