@@ -37,6 +37,20 @@ def test_gpus_2_launches_two_ranks(emulation):
     assert 'grad all-reduce' in out['config']['step']
 
 
+def test_gpus_8_launches_eight_ranks(emulation):
+    """the world size the driver's scaling run ends on: `python bench.py --gpus 8` starts eight ranks (gloo, kernels served by the
+    host emulation), the barrier / max-over-ranks timing protocol, the split step calls around the two all-gathers and the
+    asynchronous gradient all-reduce complete on every rank, rank 0 prints ONE line with n_gpus == 8 and the weak-scaling batch"""
+    r = _run(['--gpus', '8'], {}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out['n_gpus'] == 8 and out['config']['global_batch'] == 16 and out['scaling'] == 'weak'
+    assert out['value'] > 0 and out['ms_per_step'] > 0 and 'ms_per_step_graph' not in out      # no graph trial unless asked for
+    assert 'batch shard x8' in out['config']['parallelism']
+
+
 def test_single_rank_line(emulation):
     r = _run(['--gpus', '1'], {})
     assert r.returncode == 0, r.stderr[-2000:]
