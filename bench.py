@@ -707,7 +707,10 @@ def main_e2e(args):
         out = {'metric': 'training-step Mpix/s (raw pixels): ISP fwd+bwd + task model fwd+bwd + Adam',
                'value': round(world * B * S * S * args.steps / dt / 1e6, 1), 'unit': 'Mpix/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
-               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+               'data': 'synthetic' + (f' -- {world} gloo ranks SHARING GPU(s): functional check of the multi-rank device path, not a '
+                                      f'measurement' if dev.type == 'cuda' and world > 1 and
+                                      os.environ.get('R2L_BENCH_BACKEND', 'nccl') != 'nccl' else ''),
                'config': {'workload': ('BASELINE config 4: ParametrizedProcessing (Microscopy camera parameters, '
                                        'BatchNorm train) + ResNet-18 (16 classes), CE loss, Adam'
                                        if micro else
